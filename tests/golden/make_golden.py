@@ -1,0 +1,215 @@
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE UNMODIFIED REFERENCE.
+
+Build-container only (needs /root/reference; see oracle/refharness.py for how it is
+imported on CPU without its missing third-party packages).  Re-run with
+    python tests/golden/make_golden.py
+Outputs (committed, data only -- no reference source):
+  tiny_func.npz    function-level outputs of the reference on the tiny config
+                   (encode_image, GradCAM, compute_trans_mat, PAR, SegFormerHead,
+                   DecoderTransformer)
+  tiny_voc.npz     whole `WeCLIP.forward` (VOC model) + losses + backward, normal branch
+  tiny_voc_seg.npz same with the seg-trans branch (iter_num > 15000)
+  vitb_224.npz     BASELINE config 0: ViT-B/16-sized synthetic weights, one 224x224 image,
+                   encode + GradCAM(2 classes) + transition matrix + refinement
+Inputs are regenerated from oracle/synth.py seeds; each fixture stores a checksum of the
+weights and the image so a drifting RNG is detected instead of silently mis-compared.
+"""
+import ast
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import refharness, synth  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+TINY, TINY_HW, TINY_LABELS, checksum = synth.TINY, synth.TINY_HW, synth.TINY_LABELS, synth.checksum
+
+
+def _script_fn(name):
+    """Pull one function out of scripts/dist_clip_voc.py without importing the script
+    (it needs omegaconf/tensorboard at import time)."""
+    src = open(os.path.join(refharness.REF, "scripts", "dist_clip_voc.py")).read()
+    tree = ast.parse(src)
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            ns = {"np": np, "torch": torch, "F": torch.nn.functional}
+            exec(compile(ast.Module([node], []), "dist_clip_voc.py", "exec"), ns)
+            return ns[name]
+    raise KeyError(name)
+
+
+def make_tiny_func():
+    from clip.clip_tool import ClipOutputTarget, compute_trans_mat
+    from pytorch_grad_cam import GradCAM
+    from WeCLIP_model.model_attn_aff_voc import reshape_transform
+    from WeCLIP_model.PAR import PAR
+    from WeCLIP_model.segformer_head import SegFormerHead
+    from WeCLIP_model.Decoder.TransDecoder import DecoderTransformer
+
+    sd = synth.make_clip_state_dict(**TINY)
+    m = refharness.build_clip(sd)
+    H, W = TINY_HW
+    img = synth.make_images(2, H, W)
+    with torch.no_grad():
+        fts, attns = m.encode_image(img, H, W, require_all_fts=True)
+    for name, p in m.named_parameters():
+        p.requires_grad = "11" in name
+    cam = GradCAM(model=m, target_layers=[m.visual.transformer.resblocks[-1].ln_1],
+                  reshape_transform=reshape_transform)
+    bg, fg = synth.make_text_features(20, 25, TINY["embed_dim"])
+    out = dict(weights_ck=checksum(sd.values()), img_ck=checksum([img]),
+               fts_last=fts[-1].numpy(), fts_first=fts[0].numpy(),
+               attn=torch.stack(attns, 0).numpy())
+    cams, probs, last = [], [], []
+    for i, ids in enumerate(TINY_LABELS):
+        text = torch.cat([fg[ids], bg], 0)
+        for j in range(len(ids)):
+            g, p, a = cam(input_tensor=[fts[-1][:, i:i + 1], text, H, W],
+                          targets=[ClipOutputTarget(j)], target_size=None)
+            cams.append(g[0])
+            probs.append(p.detach().numpy()[0])
+            last.append(a.detach().numpy()[0])
+    out.update(cams=np.stack(cams), probs=np.stack(probs), attn_last=np.stack(last))
+    g = torch.Generator().manual_seed(11)
+    wgt = torch.rand(24, 24, generator=g) + 0.05
+    out.update(trans_in=wgt.numpy(), trans_out=compute_trans_mat(wgt).numpy())
+    par = PAR(num_iter=20, dilations=[1, 2, 4, 8, 12, 24])
+    masks = torch.rand(1, 3, H, W, generator=g)
+    out.update(par_masks=masks.numpy(), par_out=par(img[:1], masks).numpy())
+    par2 = PAR(num_iter=3, dilations=[1, 2, 4, 8, 12, 24])   # odd size, 5 channels
+    img2 = synth.make_images(1, 37, 53, seed=5)
+    masks2 = torch.rand(1, 5, 37, 53, generator=g)
+    out.update(par2_masks=masks2.numpy(), par2_out=par2(img2, masks2).numpy())
+    fuse_sd, dec_sd = synth.make_head_state_dicts(width=TINY["width"])
+    head = SegFormerHead(in_channels=[TINY["width"]] * 4, embedding_dim=256, num_classes=21, index=11).eval()
+    head.load_state_dict(fuse_sd)
+    dec = DecoderTransformer(width=256, layers=3, heads=8, output_dim=21).eval()
+    dec.load_state_dict(dec_sd)
+    toks = torch.stack(fts, 0)[:, 1:].permute(0, 2, 3, 1).reshape(11, 2, -1, H // 16, W // 16)
+    with torch.no_grad():
+        f = head(toks)
+        seg, dmaps = dec(f)
+    out.update(head_out=f.numpy(), dec_out=seg.numpy(), dec_map0=dmaps[0].numpy())
+    np.savez_compressed(os.path.join(OUT, "tiny_func.npz"), **out)
+    print("tiny_func.npz written")
+
+
+def make_tiny_whole(seg_trans):
+    from PIL import Image
+    from WeCLIP_model.model_attn_aff_voc import WeCLIP
+    from utils.camutils import cams_to_affinity_label
+    from utils.losses import get_aff_loss
+    get_seg_loss = _script_fn("get_seg_loss")
+    get_mask_by_radius = _script_fn("get_mask_by_radius")
+
+    sd = synth.make_clip_state_dict(**TINY)
+    H, W = TINY_HW
+    img = synth.make_images(2, H, W)
+    bg, fg = synth.make_text_features(20, 25, TINY["embed_dim"])
+    fuse_sd, dec_sd = synth.make_head_state_dicts(width=TINY["width"])
+    with tempfile.TemporaryDirectory() as tmp:
+        ck = os.path.join(tmp, "clip_tiny.pt")
+        # clip.load: torch.jit.load fails -> torch.load state-dict branch (clip/clip.py:128-143)
+        torch.save(sd, ck)
+        os.makedirs(os.path.join(tmp, "SegmentationClassAug"))
+        names = []
+        for i, ids in enumerate(TINY_LABELS):
+            png = np.zeros((H, W), np.uint8)
+            for j, c in enumerate(ids):
+                png[4 + 8 * j: 12 + 8 * j, 4:20] = c + 1
+            png[-3:, -3:] = 255
+            Image.fromarray(png).save(os.path.join(tmp, "SegmentationClassAug", f"im{i}.png"))
+            names.append(f"im{i}")
+        model = WeCLIP(num_classes=21, clip_model=ck, embedding_dim=256,
+                       in_channels=[TINY["width"]] * 4, dataset_root_path=tmp, device="cpu")
+        model.bg_text_features, model.fg_text_features = bg, fg
+        model.decoder_fts_fuse.load_state_dict(fuse_sd)
+        model.decoder.load_state_dict(dec_sd)
+        model.eval()
+        if seg_trans:
+            model.iter_num = 20000
+        seg, cam_labels, ap = model(img, names)
+    segs = torch.nn.functional.interpolate(seg, size=cam_labels.shape[1:], mode="bilinear",
+                                           align_corners=False)
+    mask = get_mask_by_radius(h=H // 16, w=W // 16, radius=8)
+    aff_label = cams_to_affinity_label(cam_labels.clone(), mask=torch.from_numpy(mask), ignore_index=255)
+    attn_loss, _, _ = get_aff_loss(ap, aff_label)
+    seg_loss = get_seg_loss(segs, cam_labels.type(torch.long), ignore_index=255)
+    loss = seg_loss + 0.1 * attn_loss
+    loss.backward()
+    grads = {}
+    for n, p in list(model.decoder.named_parameters()) + list(model.decoder_fts_fuse.named_parameters()):
+        grads[n] = p.grad
+    keep = ["linear_pred.weight", "linear_pred.bias", "transformer.resblocks.2.attn.in_proj_bias",
+            "transformer.resblocks.0.ln_1.weight", "transformer.resblocks.0.mlp.c_fc.bias",
+            "linears_modulelist.10.proj_2.bias", "linears_modulelist.0.proj.bias", "linear_fuse.bias"]
+    out = dict(weights_ck=checksum(sd.values()), img_ck=checksum([img]),
+               seg=seg.detach().numpy(), cam_labels=cam_labels.numpy().astype(np.uint8),
+               attn_pred=ap.detach().numpy(), aff_label=aff_label.numpy().astype(np.uint8),
+               attn_loss=np.float32(attn_loss.item()), seg_loss=np.float32(seg_loss.item()),
+               grad_norms=np.array([float(grads[n].norm()) for n in sorted(grads)], np.float64),
+               grad_names=np.array(sorted(grads)))
+    for n in keep:
+        out["grad:" + n] = grads[n].numpy()
+    fn = "tiny_voc_seg.npz" if seg_trans else "tiny_voc.npz"
+    np.savez_compressed(os.path.join(OUT, fn), **out)
+    print(fn, "written; labels present:", np.unique(out["cam_labels"]))
+
+
+def make_vitb_224():
+    from clip.clip_tool import ClipOutputTarget, compute_trans_mat
+    from clip.utils import scoremap2bbox
+    from pytorch_grad_cam import GradCAM
+    from WeCLIP_model.model_attn_aff_voc import reshape_transform
+
+    sd = synth.make_clip_state_dict(seed=0, with_text=True)
+    m = refharness.build_clip(sd)
+    H = W = 224
+    img = synth.make_images(1, H, W, seed=100)
+    with torch.no_grad():
+        fts, attns = m.encode_image(img, H, W, require_all_fts=True)
+    for name, p in m.named_parameters():
+        p.requires_grad = "11" in name
+    cam = GradCAM(model=m, target_layers=[m.visual.transformer.resblocks[-1].ln_1],
+                  reshape_transform=reshape_transform)
+    bg, fg = synth.make_text_features(20, 25, 512)
+    ids = [0, 1]
+    text = torch.cat([fg[ids], bg], 0)
+    cams, probs, refined = [], None, []
+    for j in range(2):
+        g, p, a = cam(input_tensor=[fts[-1], text, H, W], targets=[ClipOutputTarget(j)], target_size=None)
+        cams.append(g[0])
+        probs = p.detach().numpy()
+        if j == 0:
+            aw = torch.cat([torch.stack(attns, 0)[:, 0], a.detach()], 0)[:, 1:, 1:][-8:].mean(0)
+            T = compute_trans_mat(aw)
+        box, cnt = scoremap2bbox(scoremap=g[0], threshold=0.4, multi_contour_eval=True)
+        mask = torch.zeros(14, 14)
+        for i_ in range(cnt):
+            x0, y0, x1, y1 = box[i_]
+            mask[y0:y1, x0:x1] = 1
+        refined.append((T * mask.view(1, -1)) @ torch.from_numpy(g[0]).view(-1, 1))
+    out = dict(weights_ck=checksum([sd[k] for k in sorted(sd) if k.startswith("visual")]),
+               img_ck=checksum([img]),
+               fts_last=fts[-1][:, 0].numpy().astype(np.float32),
+               fts5_cls=fts[5][0, 0].numpy(), attn10_rows=attns[10][0, ::16].numpy(),
+               attn_last_rows=a.detach()[0, ::16].numpy(),
+               probs=probs, cams=np.stack(cams), trans_diag=T.diagonal().numpy(),
+               trans_rows=T[::28].numpy(), refined=torch.stack(refined).reshape(2, 14, 14).numpy())
+    np.savez_compressed(os.path.join(OUT, "vitb_224.npz"), **out)
+    print("vitb_224.npz written; probs[:3] =", probs[0, :3])
+
+
+if __name__ == "__main__":
+    refharness.install()
+    torch.manual_seed(0)
+    make_tiny_func()
+    make_tiny_whole(False)
+    make_tiny_whole(True)
+    make_vitb_224()

@@ -1,0 +1,130 @@
+"""Pin the CPU oracle (oracle/weclip_oracle.py) against outputs of the UNMODIFIED reference
+captured in tests/golden/*.npz by tests/golden/make_golden.py (CPU only, no GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+from oracle import weclip_oracle as O
+
+TINY, (H, W), LABELS = synth.TINY, synth.TINY_HW, synth.TINY_LABELS
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    sd = synth.make_clip_state_dict(**TINY)
+    img = synth.make_images(2, H, W)
+    bg, fg = synth.make_text_features(20, 25, TINY["embed_dim"])
+    fuse, dec = synth.make_head_state_dicts(width=TINY["width"])
+    return sd, img, bg, fg, fuse, dec
+
+
+def _check_inputs(g, sd, img):
+    if synth.checksum(sd.values()) != g["weights_ck"] or synth.checksum([img]) != g["img_ck"]:
+        pytest.skip("synthetic RNG stream differs from the one the fixture was generated with")
+
+
+def test_encoder_and_gradcam_match_reference(tiny, golden):
+    sd, img, bg, fg, _, _ = tiny
+    g = golden("tiny_func.npz")
+    _check_inputs(g, sd, img)
+    xs, maps = O.encode_image(img, sd, heads=1)
+    assert len(xs) == 11 and len(maps) == 11
+    np.testing.assert_allclose(xs[-1].numpy(), g["fts_last"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(xs[0].numpy(), g["fts_first"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(torch.stack(maps).numpy(), g["attn"], rtol=0, atol=1e-6)
+    n = 0
+    for i, ids in enumerate(LABELS):
+        text = torch.cat([fg[ids], bg], 0)
+        for j in range(len(ids)):
+            cam, probs, pm, _ = O.grad_cam(xs[-1][:, i:i + 1], text, j, sd, 1, H // 16, W // 16)
+            np.testing.assert_allclose(probs.numpy()[0], g["probs"][n], rtol=1e-4, atol=1e-8)
+            np.testing.assert_allclose(pm.numpy()[0], g["attn_last"][n], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(cam, g["cams"][n], rtol=0, atol=2e-4)
+            assert g["cams"][n].max() > 0.5          # fixture has signal
+            n += 1
+
+
+def test_trans_mat_matches_reference(golden):
+    g = golden("tiny_func.npz")
+    out = O.compute_trans_mat(torch.from_numpy(g["trans_in"]))
+    np.testing.assert_allclose(out.numpy(), g["trans_out"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(out.numpy(), out.numpy().T, rtol=1e-5, atol=1e-9)   # symmetric
+
+
+def test_par_matches_reference(tiny, golden):
+    _, img, *_ = tiny
+    g = golden("tiny_func.npz")
+    out = O.par(img[:1], torch.from_numpy(g["par_masks"]))
+    np.testing.assert_allclose(out.numpy(), g["par_out"], rtol=0, atol=2e-5)
+    # mass property: aff sums to 1.01 => 1.01^20 growth
+    ratio = out.sum().item() / g["par_masks"].sum()
+    assert abs(ratio - 1.01 ** 20) < 0.02
+    img2 = synth.make_images(1, 37, 53, seed=5)
+    out2 = O.par(img2, torch.from_numpy(g["par2_masks"]), num_iter=3)
+    np.testing.assert_allclose(out2.numpy(), g["par2_out"], rtol=0, atol=1e-5)
+
+
+def test_head_and_decoder_match_reference(tiny, golden):
+    sd, img, _, _, fuse, dec = tiny
+    g = golden("tiny_func.npz")
+    xs, _ = O.encode_image(img, sd, heads=1)
+    toks = torch.stack(xs, 0)[:, 1:].permute(0, 2, 3, 1).reshape(11, 2, -1, H // 16, W // 16)
+    f = O.segformer_head(toks, fuse)
+    np.testing.assert_allclose(f.numpy(), g["head_out"], rtol=0, atol=2e-5)
+    seg, maps = O.decoder(f, dec)
+    np.testing.assert_allclose(seg.numpy(), g["dec_out"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(maps[0].numpy(), g["dec_map0"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("seg_trans", [False, True])
+def test_whole_forward_and_backward_match_reference(tiny, golden, seg_trans):
+    sd, img, bg, fg, fuse, dec = tiny
+    g = golden("tiny_voc_seg.npz" if seg_trans else "tiny_voc.npz")
+    _check_inputs(g, sd, img)
+    fuse = {k: v.clone().requires_grad_(True) for k, v in fuse.items()}
+    dec = {k: v.clone().requires_grad_(True) for k, v in dec.items()}
+    seg, labels, ap = O.weclip_forward(img, LABELS, sd, fuse, dec, bg, fg, heads=1,
+                                       seg_trans=seg_trans)
+    np.testing.assert_allclose(seg.detach().numpy(), g["seg"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(ap.detach().numpy(), g["attn_pred"], rtol=0, atol=1e-5)
+    mism = (labels.numpy() != g["cam_labels"]).mean()
+    assert mism <= 1e-3, f"{mism:.2%} label pixels differ from the reference"
+    assert len(np.unique(g["cam_labels"])) >= 3
+    loss, ls, la = O.train_losses(seg, torch.from_numpy(g["cam_labels"].astype(np.int64)), ap)
+    assert abs(ls.item() - g["seg_loss"]) < 1e-4 and abs(la.item() - g["attn_loss"]) < 1e-5
+    al = O.cams_to_affinity_label(torch.from_numpy(g["cam_labels"].astype(np.int64)),
+                                  O.radius_mask(H // 16, W // 16))
+    assert (al.numpy().astype(np.uint8) == g["aff_label"]).all()
+    loss.backward()
+    grads = {**{k: v.grad for k, v in dec.items()}, **{k: v.grad for k, v in fuse.items()}}
+    for k in g.files:
+        if k.startswith("grad:"):
+            np.testing.assert_allclose(grads[k[5:]].numpy(), g[k], rtol=1e-3, atol=1e-6)
+    names = [str(n) for n in g["grad_names"]]
+    norms = np.array([float(grads[n].norm()) for n in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-3, atol=1e-7)
+
+
+def test_vitb_224_config0_matches_reference(golden):
+    """BASELINE config 0: ViT-B/16-sized weights, 224x224, encode + GradCAM + affinity."""
+    g = golden("vitb_224.npz")
+    sd = synth.make_clip_state_dict(seed=0, with_text=False)
+    img = synth.make_images(1, 224, 224, seed=100)
+    if synth.checksum([sd[k] for k in sorted(sd) if k.startswith("visual")]) != g["weights_ck"]:
+        pytest.skip("synthetic RNG stream differs from fixture")
+    bg, fg = synth.make_text_features(20, 25, 512)
+    xs, maps = O.encode_image(img, sd, heads=12)
+    np.testing.assert_allclose(xs[-1][:, 0].numpy(), g["fts_last"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(maps[10][0, ::16].numpy(), g["attn10_rows"], rtol=0, atol=1e-6)
+    text = torch.cat([fg[[0, 1]], bg], 0)
+    for j in range(2):
+        cam, probs, pm, _ = O.grad_cam(xs[-1], text, j, sd, 12, 14, 14)
+        np.testing.assert_allclose(probs.numpy(), g["probs"], rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(cam, g["cams"][j], rtol=0, atol=1e-3)
+        if j == 0:
+            m12 = torch.cat([torch.stack([m[0] for m in maps]), pm], 0)
+            T = O.compute_trans_mat(O.affinity_weight(m12))
+            np.testing.assert_allclose(T[::28].numpy(), g["trans_rows"], rtol=1e-4, atol=1e-9)
+        r = O.refine_cam(T, cam, O.box_mask(cam, 0.4))
+        np.testing.assert_allclose(r.numpy(), g["refined"][j], rtol=1e-3, atol=1e-6)
