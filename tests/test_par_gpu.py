@@ -1,0 +1,85 @@
+"""PAR parity on the MI355X: HIP path (through the C ABI) vs the CPU oracle / reference goldens."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+from oracle import weclip_oracle as O
+
+pytestmark = pytest.mark.gpu
+DIL = [1, 2, 4, 8, 12, 24]
+
+
+@pytest.fixture(scope="module")
+def PAR():
+    from weclip_vit_comer_amd.WeCLIP_model.PAR import PAR
+    return PAR
+
+
+def test_par_matches_reference_golden(PAR, golden):
+    g = golden("tiny_func.npz")
+    img = synth.make_images(2, *synth.TINY_HW)[:1].cuda()
+    out = PAR(DIL, 20).cuda()(img, torch.from_numpy(g["par_masks"]).cuda())
+    np.testing.assert_allclose(out.cpu().numpy(), g["par_out"], rtol=0, atol=3e-5)
+    # ragged size (37x53, smaller than the largest dilation), 5 channels, 3 iterations
+    img2 = synth.make_images(1, 37, 53, seed=5).cuda()
+    out2 = PAR(DIL, 3).cuda()(img2, torch.from_numpy(g["par2_masks"]).cuda())
+    np.testing.assert_allclose(out2.cpu().numpy(), g["par2_out"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 48, 80), (3, 3, 96, 64), (2, 6, 33, 130)])
+def test_par_matches_oracle(PAR, shape):
+    b, C, H, W = shape
+    img = synth.make_images(b, H, W, seed=3)
+    g = torch.Generator().manual_seed(4)
+    masks = torch.rand(b, C, H, W, generator=g)
+    mod = PAR(DIL, 20).cuda()
+    aff = mod.affinity(img.cuda()).cpu()
+    out = mod(img.cuda(), masks.cuda()).cpu()
+    for i in range(b):
+        ref_aff = O.par_affinity(img[i:i + 1])
+        np.testing.assert_allclose(aff[i].numpy(), ref_aff.numpy(), rtol=0, atol=2e-6)
+        ref = O.par(img[i:i + 1], masks[i:i + 1])
+        np.testing.assert_allclose(out[i].numpy(), ref[0].numpy(), rtol=0, atol=3e-5)
+
+
+def test_par_image_resized_to_mask_size(PAR):
+    """val mode: image at another size than the masks (PAR.py:67, align_corners=True)."""
+    img = synth.make_images(1, 40, 56, seed=9)
+    masks = torch.rand(1, 3, 64, 80, generator=torch.Generator().manual_seed(1))
+    out = PAR(DIL, 4).cuda()(img.cuda(), masks.cuda()).cpu()
+    ref = O.par(img, masks, num_iter=4)
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=0, atol=2e-5)
+
+
+def test_par_full_size_properties(PAR):
+    """BASELINE size 512x512, K+1 = 3: mass growth 1.01^20 and constant-mask fixed point."""
+    B, C, H, W = 4, 3, 512, 512
+    img = synth.make_images(B, H, W, seed=100).cuda()
+    masks = torch.rand(B, C, H, W, device="cuda")
+    mod = PAR(DIL, 20).cuda()
+    aff = mod.affinity(img)
+    s = aff.sum(1)
+    assert (s - 1.01).abs().max().item() < 1e-5          # softmax + 0.01*softmax
+    out = mod(img, masks)
+    ratio = (out.sum() / masks.sum()).item()
+    assert abs(ratio - 1.01 ** 20) < 5e-3
+    ones = torch.ones(B, C, H, W, device="cuda")
+    out1 = mod(img, ones)
+    assert (out1 - 1.01 ** 20).abs().max().item() < 1e-4  # linear operator with row sums 1.01
+    # linearity in the masks
+    a, b = torch.rand_like(masks), torch.rand_like(masks)
+    lin = mod(img, 2 * a + 3 * b) - (2 * mod(img, a) + 3 * mod(img, b))
+    assert lin.abs().max().item() < 1e-4
+
+
+def test_refine_labels(PAR):
+    from weclip_vit_comer_amd.WeCLIP_model.PAR import refine_labels
+    masks = torch.rand(2, 4, 40, 70, device="cuda")
+    masks[0, 3] = -1.0                                     # padded channel must be ignored
+    keys = torch.tensor([[0, 4, 8, 99], [0, 1, 15, 20]], device="cuda")
+    nch = torch.tensor([3, 4], dtype=torch.int32, device="cuda")
+    lab = refine_labels(masks, keys, nch)
+    ref0 = keys[0][masks[0, :3].argmax(0)]
+    ref1 = keys[1][masks[1].argmax(0)]
+    assert (lab[0] == ref0).all() and (lab[1] == ref1).all()

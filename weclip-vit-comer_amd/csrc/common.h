@@ -1,0 +1,80 @@
+// Shared helpers for the weclip_hip C-ABI library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define WC_OK 0
+#define WC_ERR_ARG 1
+#define WC_ERR_HIP 2
+
+extern "C" void wc_set_error(const char* fmt, ...);
+
+#define WC_CHECK_ARG(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            wc_set_error(__VA_ARGS__);          \
+            return WC_ERR_ARG;                  \
+        }                                       \
+    } while (0)
+
+#define WC_LAUNCH_CHECK(name)                                                     \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) {                                                   \
+            wc_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+            return WC_ERR_HIP;                                                    \
+        }                                                                         \
+    } while (0)
+
+static inline int wc_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// 64-lane wavefront reductions (DPP/shuffle based).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide reductions for blockDim.x <= 1024 (<=16 waves); `red` is >=16 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += red[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
+    return r;
+}
+__device__ __forceinline__ float block_min(float v, float* red) {
+    v = wave_min(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < nw; ++i) r = fminf(r, red[i]);
+    return r;
+}

@@ -1,0 +1,234 @@
+// Pixel-Adaptive Refinement (PAR) for gfx950.
+// Replaces the stock-op composition of reference WeCLIP_model/PAR.py:39-92
+// (replicate F.pad + one-hot dilated conv2d per dilation, std/softmax over the 48 taps,
+// 20 x gather-multiply-sum) with two HBM-streaming stencil kernels:
+//   par_affinity_kernel : img (B,3,H,W) -> aff (B,T,H,W), T = 8 * n_dilations taps, once
+//   par_iter_kernel     : masks <- sum_t aff_t * masks(nbr_t), one launch per iteration
+// Neighbour fetch is by index clamping (== replicate padding).  Everything is fp32.
+// Layout: aff is tap-major planes so a wave reads 64 consecutive x of one plane (256 B).
+#include "common.h"
+
+#define PAR_MAX_TAPS 64
+
+struct ParTaps {
+    int n;
+    int dy[PAR_MAX_TAPS];
+    int dx[PAR_MAX_TAPS];
+    float pi[PAR_MAX_TAPS];   // w2 * softmax_t(-(pos_t/(std(pos)+1e-8)/w1)^2)
+};
+
+__device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+// One thread per pixel; 4 passes over the taps (mean, variance, softmax stats, write) re-reading
+// the image through L1/L2 (3 planes of H*W floats are cache resident); runs once per image.
+__global__ __launch_bounds__(256) void par_affinity_kernel(const float* __restrict__ img,
+                                                            float* __restrict__ aff, int H, int W,
+                                                            float w1, ParTaps taps) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const long HW = (long)H * W;
+    const float* I = img + (long)blockIdx.z * 3 * HW;
+    const long p = (long)y * W + x;
+    const float c0 = I[p], c1 = I[HW + p], c2 = I[2 * HW + p];
+    const int T = taps.n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const long o = (long)clampi(y + taps.dy[t], H - 1) * W + clampi(x + taps.dx[t], W - 1);
+        s0 += I[o]; s1 += I[HW + o]; s2 += I[2 * HW + o];
+    }
+    const float m0 = s0 / T, m1 = s1 / T, m2 = s2 / T;
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const long o = (long)clampi(y + taps.dy[t], H - 1) * W + clampi(x + taps.dx[t], W - 1);
+        const float a = I[o] - m0, b = I[HW + o] - m1, c = I[2 * HW + o] - m2;
+        q0 += a * a; q1 += b * b; q2 += c * c;
+    }
+    // unbiased std (torch.std default), PAR.py:77
+    const float d0 = sqrtf(q0 / (T - 1)) + 1e-8f, d1 = sqrtf(q1 / (T - 1)) + 1e-8f,
+                d2 = sqrtf(q2 / (T - 1)) + 1e-8f;
+    float mx = -INFINITY, sum = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const long o = (long)clampi(y + taps.dy[t], H - 1) * W + clampi(x + taps.dx[t], W - 1);
+        const float a = fabsf(I[o] - c0) / d0 / w1, b = fabsf(I[HW + o] - c1) / d1 / w1,
+                    c = fabsf(I[2 * HW + o] - c2) / d2 / w1;
+        const float e = -(a * a + b * b + c * c) / 3.0f;
+        const float nm = fmaxf(mx, e);
+        sum = sum * __expf(mx - nm) + __expf(e - nm);
+        mx = nm;
+    }
+    const float inv = 1.0f / sum;
+    float* A = aff + (long)blockIdx.z * T * HW + p;
+    for (int t = 0; t < T; ++t) {
+        const long o = (long)clampi(y + taps.dy[t], H - 1) * W + clampi(x + taps.dx[t], W - 1);
+        const float a = fabsf(I[o] - c0) / d0 / w1, b = fabsf(I[HW + o] - c1) / d1 / w1,
+                    c = fabsf(I[2 * HW + o] - c2) / d2 / w1;
+        const float e = -(a * a + b * b + c * c) / 3.0f;
+        A[(long)t * HW] = __expf(e - mx) * inv + taps.pi[t];
+    }
+}
+
+// One PAR iteration.  Thread = one pixel, CG channels at a time (aff value reused across the
+// channel group).  HBM traffic per launch: T*H*W*4 (aff) + 2*C*H*W*4 (masks in/out); the
+// neighbour gathers of `min` hit L1/L2 (C planes of H*W floats).
+template <int CG>
+__global__ __launch_bounds__(256) void par_iter_kernel(const float* __restrict__ aff,
+                                                        const float* __restrict__ min,
+                                                        float* __restrict__ mout, int C, int H,
+                                                        int W, ParTaps taps) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const long HW = (long)H * W;
+    const long p = (long)y * W + x;
+    const int T = taps.n;
+    const float* A = aff + (long)blockIdx.z * T * HW + p;
+    const float* M = min + (long)blockIdx.z * C * HW;
+    float* O = mout + (long)blockIdx.z * C * HW + p;
+    for (int cb = 0; cb < C; cb += CG) {
+        float acc[CG];
+        const float* Mc[CG];
+#pragma unroll
+        for (int k = 0; k < CG; ++k) {
+            acc[k] = 0.f;
+            Mc[k] = M + (long)(cb + k < C ? cb + k : C - 1) * HW;
+        }
+        for (int t = 0; t < T; ++t) {
+            const float a = A[(long)t * HW];
+            const long o = (long)clampi(y + taps.dy[t], H - 1) * W + clampi(x + taps.dx[t], W - 1);
+#pragma unroll
+            for (int k = 0; k < CG; ++k) acc[k] = fmaf(a, Mc[k][o], acc[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < CG; ++k)
+            if (cb + k < C) O[(long)(cb + k) * HW] = acc[k];
+    }
+}
+
+// labels[b,y,x] = valid_key[b, argmax_c masks[b,c,y,x]] over the first nch[b] channels
+// (first maximum wins like torch.argmax).  model_attn_aff_voc.py:49-57.
+__global__ __launch_bounds__(256) void par_labels_kernel(const float* __restrict__ masks,
+                                                          const long* __restrict__ valid_key,
+                                                          const int* __restrict__ nch,
+                                                          long* __restrict__ labels, int C, long HW) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int b = blockIdx.y;
+    const int n = nch ? nch[b] : C;
+    const float* M = masks + (long)b * C * HW + p;
+    float best = M[0];
+    int bi = 0;
+    for (int c = 1; c < n; ++c) {
+        const float v = M[(long)c * HW];
+        if (v > best) { best = v; bi = c; }
+    }
+    labels[(long)b * HW + p] = valid_key[(long)b * C + bi];
+}
+
+static int build_taps(ParTaps* tp, const int* dilations, int n_dil, float w1, float w2) {
+    if (n_dil < 1 || n_dil * 8 > PAR_MAX_TAPS) return 1;
+    static const int DY[8] = {-1, -1, -1, 0, 0, 1, 1, 1};   // get_kernel() order, PAR.py:10-24
+    static const int DX[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+    const int T = n_dil * 8;
+    float pos[PAR_MAX_TAPS];
+    for (int d = 0; d < n_dil; ++d)
+        for (int k = 0; k < 8; ++k) {
+            const int t = d * 8 + k;
+            tp->dy[t] = DY[k] * dilations[d];
+            tp->dx[t] = DX[k] * dilations[d];
+            pos[t] = (float)dilations[d] * ((DY[k] != 0 && DX[k] != 0) ? sqrtf(2.0f) : 1.0f);
+        }
+    float mean = 0.f;
+    for (int t = 0; t < T; ++t) mean += pos[t];
+    mean /= T;
+    float var = 0.f;
+    for (int t = 0; t < T; ++t) var += (pos[t] - mean) * (pos[t] - mean);
+    const float sd = sqrtf(var / (T - 1)) + 1e-8f;
+    float e[PAR_MAX_TAPS], mx = -INFINITY, sum = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float v = pos[t] / sd / w1;
+        e[t] = -(v * v);
+        mx = fmaxf(mx, e[t]);
+    }
+    for (int t = 0; t < T; ++t) sum += expf(e[t] - mx);
+    for (int t = 0; t < T; ++t) tp->pi[t] = w2 * expf(e[t] - mx) / sum;
+    tp->n = T;
+    return 0;
+}
+
+extern "C" int wc_par_affinity(const float* img, float* aff, int B, int H, int W,
+                               const int* dilations, int n_dil, void* stream) {
+    WC_CHECK_ARG(img && aff && B > 0 && H > 0 && W > 0, "wc_par_affinity: bad argument");
+    ParTaps tp;
+    WC_CHECK_ARG(build_taps(&tp, dilations, n_dil, 0.3f, 0.01f) == 0, "wc_par_affinity: 1..8 dilations");
+    dim3 grid(wc_cdiv(W, 64), wc_cdiv(H, 4), B);
+    hipLaunchKernelGGL(par_affinity_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, aff, H, W,
+                       0.3f, tp);
+    WC_LAUNCH_CHECK("par_affinity_kernel");
+    return WC_OK;
+}
+
+static int launch_iter(const float* aff, const float* src, float* dst, int B, int C, int H, int W,
+                       const ParTaps& tp, hipStream_t st) {
+    dim3 grid(wc_cdiv(W, 64), wc_cdiv(H, 4), B);
+    if (C <= 2)
+        hipLaunchKernelGGL(par_iter_kernel<2>, grid, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
+    else if (C == 3)
+        hipLaunchKernelGGL(par_iter_kernel<3>, grid, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
+    else
+        hipLaunchKernelGGL(par_iter_kernel<4>, grid, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
+    WC_LAUNCH_CHECK("par_iter_kernel");
+    return WC_OK;
+}
+
+extern "C" int wc_par_iterate(const float* aff, const float* masks_in, float* masks_out, int B, int C,
+                              int H, int W, const int* dilations, int n_dil, void* stream) {
+    WC_CHECK_ARG(aff && masks_in && masks_out && masks_in != masks_out && B > 0 && C > 0,
+                 "wc_par_iterate: bad argument (in-place not allowed)");
+    ParTaps tp;
+    WC_CHECK_ARG(build_taps(&tp, dilations, n_dil, 0.3f, 0.01f) == 0, "wc_par_iterate: 1..8 dilations");
+    return launch_iter(aff, masks_in, masks_out, B, C, H, W, tp, (hipStream_t)stream);
+}
+
+// Whole PAR.forward for images already at mask resolution (PAR.py:64-92).
+// Images are processed in groups of `group` so that a group's aff planes (T*H*W*4 B each)
+// stay resident in the 256 MiB Infinity Cache across the num_iter sweeps.
+// Workspaces: aff_ws >= min(group,B)*T*H*W floats, tmp >= B*C*H*W floats.
+extern "C" int wc_par_forward(const float* img, const float* masks, float* out, float* tmp,
+                              float* aff_ws, int B, int C, int H, int W, const int* dilations,
+                              int n_dil, int num_iter, int group, void* stream) {
+    WC_CHECK_ARG(img && masks && out && tmp && aff_ws && B > 0 && C > 0 && H > 0 && W > 0 &&
+                     num_iter >= 1 && group >= 1,
+                 "wc_par_forward: bad argument");
+    WC_CHECK_ARG(out != masks && tmp != masks && out != tmp, "wc_par_forward: buffers must not alias");
+    ParTaps tp;
+    WC_CHECK_ARG(build_taps(&tp, dilations, n_dil, 0.3f, 0.01f) == 0, "wc_par_forward: 1..8 dilations");
+    hipStream_t st = (hipStream_t)stream;
+    const long HW = (long)H * W;
+    for (int b0 = 0; b0 < B; b0 += group) {
+        const int nb = (B - b0 < group) ? B - b0 : group;
+        dim3 grid(wc_cdiv(W, 64), wc_cdiv(H, 4), nb);
+        hipLaunchKernelGGL(par_affinity_kernel, grid, dim3(256), 0, st, img + (long)b0 * 3 * HW, aff_ws,
+                           H, W, 0.3f, tp);
+        WC_LAUNCH_CHECK("par_affinity_kernel");
+        const float* src = masks + (long)b0 * C * HW;
+        for (int i = 0; i < num_iter; ++i) {
+            float* dst = (((num_iter - i) & 1) ? out : tmp) + (long)b0 * C * HW;
+            int rc = launch_iter(aff_ws, src, dst, nb, C, H, W, tp, st);
+            if (rc) return rc;
+            src = dst;
+        }
+    }
+    return WC_OK;
+}
+
+extern "C" int wc_par_labels(const float* masks, const int64_t* valid_key, const int* nch,
+                             int64_t* labels, int B, int C, int H, int W, void* stream) {
+    WC_CHECK_ARG(masks && valid_key && labels && B > 0 && C > 0, "wc_par_labels: bad argument");
+    const long HW = (long)H * W;
+    dim3 grid(wc_cdiv(HW, 256), B);
+    hipLaunchKernelGGL(par_labels_kernel, grid, dim3(256), 0, (hipStream_t)stream, masks,
+                       (const long*)valid_key, nch, (long*)labels, C, HW);
+    WC_LAUNCH_CHECK("par_labels_kernel");
+    return WC_OK;
+}
