@@ -56,6 +56,47 @@ int wc_par_labels(const float* masks, const int64_t* valid_key, const int* nch, 
 int wc_bilinear_resize(const float* src, float* dst, int planes, int Hs, int Ws, int Hd, int Wd,
                        int align_corners, void* stream);
 
+/* ---- MFMA GEMM ------------------------------------------------------------------------ */
+/* C[M,N] = epilogue(sum_{s<nseg} A_s[M,K] * W_s[N,K]^T), fp16 operands (K contiguous), fp32
+ * accumulate on v_mfma_f32_32x32x16_f16.  Replaces F.linear / nn.Linear / 1x1 Conv2d / bmm at
+ * clip/myAtt.py:201 (in-proj), :321 (fp16 out-proj), clip/model.py:198-202 (MLP), :264-268
+ * (patch-embed conv k16 s16 == GEMM), :420 (visual.proj), WeCLIP_model/segformer_head.py:22-28,76,
+ * WeCLIP_model/Decoder/TransDecoder.py:122, WeCLIP_model/model_attn_aff_voc.py:136 (bmm).
+ * nseg 2/3 = split precision (x = hi + lo): extra (A,W) pairs are accumulated into the same tile.
+ * epilogue: v = acc + bias[n]; if round16: v = fp16(v); if n < scale_cols: v *= scale;
+ *           v = act(v) (0 none, 1 QuickGELU, 2 ReLU, 3 sigmoid); v += resid[m*ldr + n];
+ *           C32[m,n] = v; C16[m,n] = fp16(v); C16lo[m,n] = fp16(v - C16).
+ * batch > 1: operand/output/residual batch strides sA/sW/sC/sR in elements.  K % 64 == 0, lda/ldw % 8 == 0. */
+int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const void* W0, const void* W1,
+                const void* W2, int nseg, int M, int N, int K, long lda, long ldw, int batch,
+                long sA, long sW, long sC, const float* bias, const float* resid, long ldr, long sR,
+                float* C32,
+                void* C16, void* C16lo, long ldc, int act, int round16, float scale,
+                int scale_cols, void* stream);
+/* fp32 -> fp16 hi (+ lo = fp16(x - hi), may be NULL): `.half()` casts of weights/activations
+ * (clip/model.py:457-478 convert_weights; clip/myAtt.py:321). */
+int wc_split_f16(const float* x, void* hi, void* lo, long n, void* stream);
+
+/* ---- LayerNorm ------------------------------------------------------------------------ */
+/* clip/model.py:177-183 (`LayerNorm.forward`, fp32 math).  x (rows, D) f32 with row stride ldx;
+ * outputs (each optional): y32 f32, y16 fp16 hi, y16lo fp16 residual; all dense (rows, D). */
+int wc_layernorm(const float* x, long ldx, const float* w, const float* b, float eps, float* y32,
+                 void* y16, void* y16lo, long rows, int D, void* stream);
+
+/* ---- multi-head attention -------------------------------------------------------------- */
+/* Packed in-projection output qkv (B*L, 3E) fp16, E = H*DH, q pre-scaled by log2(e)/sqrt(DH)
+ * (wc_gemm_f16 scale/scale_cols).  DH in {32, 64}.
+ * wc_attn_vt:   V^T (B,H,DH,Lp) fp16, keys contiguous, zero padded to Lp (Lp % 64 == 0).
+ * wc_attn_fwd:  clip/myAtt.py:21-64 without materialising the scores: out (B*L, E) fp16 =
+ *               softmax(QK^T)V with heads merged (the `.half()` input of the out-projection,
+ *               myAtt.py:319-321); lse (B,H,L) f32 = log2-sum-exp2 of each score row.
+ * wc_attn_mean: clip/myAtt.py:325-326: mean (B,L,L) f32 = (1/H) sum_h softmax_h. */
+int wc_attn_vt(const void* qkv, void* vt, int B, int L, int Lp, int H, int DH, void* stream);
+int wc_attn_fwd(const void* qkv, const void* vt, void* out, float* lse, int B, int L, int Lp, int H,
+                int DH, void* stream);
+int wc_attn_mean(const void* qkv, const float* lse, float* mean, int B, int L, int H, int DH,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,121 @@
+"""GEMM / LayerNorm / attention HIP kernels vs fp32 CPU references (through the C ABI)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from weclip_vit_comer_amd import ops
+    return ops
+
+
+def _rel(a, b):
+    return ((a - b).abs().max() / b.abs().max()).item()
+
+
+def test_mfma_layout_identity(ops):
+    """A = I with an ASYMMETRIC W catches swapped row/col maps."""
+    K = 64
+    a = torch.eye(K, dtype=torch.float16, device="cuda")
+    w = (torch.arange(96 * K, device="cuda").reshape(96, K) % 251).to(torch.float16)  # asymmetric ints
+    out = torch.empty(K, 96, device="cuda")
+    ops.gemm(a, w, K, 96, K, out32=out)
+    assert torch.equal(out, w.float().t())
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 21, 64), (1025, 2304, 768), (333, 768, 3072), (128, 128, 128)])
+def test_gemm_fp16_exact_products(ops, M, N, K):
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).half()
+    w = (torch.randn(N, K, generator=g) * 0.05).half()
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ref = a.double() @ w.double().t() + bias.double()
+    out = torch.empty(M, N, device="cuda")
+    ops.gemm(a.cuda(), w.cuda(), M, N, K, bias=bias.cuda(), out32=out)
+    assert _rel(out.cpu().double(), ref) < 2e-6          # fp32 accumulation of exact fp16 products
+    # epilogue: QuickGELU + residual + fp16 hi/lo outputs
+    out16 = torch.empty(M, N, device="cuda", dtype=torch.float16)
+    lo16 = torch.empty_like(out16)
+    ops.gemm(a.cuda(), w.cuda(), M, N, K, bias=bias.cuda(), resid=res.cuda(), out32=out, out16=out16,
+             out16lo=lo16, act=1)
+    ref2 = ref * torch.sigmoid(1.702 * ref) + res.double()
+    assert _rel(out.cpu().double(), ref2) < 2e-6
+    assert _rel((out16.float() + lo16.float()).cpu().double(), ref2) < 2e-6
+    # forced-fp16 rounding before the residual (out-projection semantics)
+    ops.gemm(a.cuda(), w.cuda(), M, N, K, bias=bias.cuda(), resid=res.cuda(), out32=out, round16=True)
+    ref3 = (a.double() @ w.double().t() + bias.double()).float().half().double() + res.double()
+    assert ((out.cpu().double() - ref3).abs() > 1e-6).float().mean().item() < 2e-3   # fp16 rounding ties
+
+
+def test_gemm_split_precision_and_scale(ops):
+    M, N, K = 300, 192, 256
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.04
+    ref = x.double() @ w.double().t()
+    out = torch.empty(M, N, device="cuda")
+    ops.gemm(ops.split_f16(x.cuda()), ops.split_f16(w.cuda()), M, N, K, out32=out)
+    e1 = _rel(out.cpu().double(), ref)
+    ops.gemm(ops.split_f16(x.cuda(), True), ops.split_f16(w.cuda(), True), M, N, K, out32=out)
+    e3 = _rel(out.cpu().double(), ref)
+    assert e1 < 2e-3 and e3 < 5e-6, (e1, e3)
+    ops.gemm(ops.split_f16(x.cuda(), True), ops.split_f16(w.cuda(), True), M, N, K, out32=out,
+             scale=0.5, scale_cols=64)
+    ref[:, :64] *= 0.5
+    assert _rel(out.cpu().double(), ref) < 5e-6
+
+
+def test_gemm_batched(ops):
+    Bn, M, N, K = 3, 130, 70, 64
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(Bn, M, K, generator=g).half()
+    w = torch.randn(Bn, N, K, generator=g).half()
+    out = torch.empty(Bn, M, N, device="cuda")
+    ops.gemm(a.cuda(), w.cuda(), M, N, K, out32=out, batch=Bn, sA=M * K, sW=N * K, sC=M * N, act=3)
+    ref = torch.sigmoid(torch.bmm(a.double(), w.double().transpose(1, 2)))
+    assert _rel(out.cpu().double(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("D", [64, 256, 768])
+def test_layernorm(ops, D):
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(1000, D, generator=g) * 3 + 1
+    w = torch.randn(D, generator=g)
+    b = torch.randn(D, generator=g)
+    y32, sp = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), want32=True, with_lo=True)
+    ref = torch.nn.functional.layer_norm(x, (D,), w, b, 1e-5)
+    assert (y32.cpu() - ref).abs().max().item() < 5e-6
+    assert ((sp.hi.float() + sp.lo.float()).cpu() - ref).abs().max().item() < 5e-6
+    assert torch.equal(sp.hi.cpu(), y32.cpu().half())
+
+
+@pytest.mark.parametrize("B,L,H,DH", [(2, 25, 1, 64), (1, 197, 12, 64), (2, 1025, 12, 64), (2, 1024, 8, 32),
+                                      (1, 130, 8, 32)])
+def test_attention_vs_reference(ops, B, L, H, DH):
+    """Same arithmetic as clip/myAtt.py:21-64,325-326 on fp16-rounded q,k,v."""
+    E = H * DH
+    g = torch.Generator().manual_seed(L)
+    qkv = torch.randn(B * L, 3 * E, generator=g)
+    qkv[:, :E] *= 1.5
+    q = (qkv[:, :E] * ops.q_scale(DH)).half()
+    k, v = qkv[:, E:2 * E].half(), qkv[:, 2 * E:].half()
+    packed = torch.cat([q, k, v], 1).contiguous()
+    o16, lse, mean = ops.attention(packed.cuda(), B, L, H, DH)
+    qf = q.float().view(B, L, H, DH).permute(0, 2, 1, 3).double() / ops.LOG2E
+    kf = k.float().view(B, L, H, DH).permute(0, 2, 1, 3).double()
+    vf = v.float().view(B, L, H, DH).permute(0, 2, 1, 3).double()
+    s = qf @ kf.transpose(-1, -2)
+    p = torch.softmax(s, -1)
+    o = (p @ vf).permute(0, 2, 1, 3).reshape(B * L, E)
+    np.testing.assert_allclose(mean.cpu().double().numpy(), p.mean(1).numpy(), rtol=2e-4, atol=1e-7)
+    assert abs(mean.sum().item() / (B * L) - 1.0) < 1e-4                    # rows sum to 1
+    ref_lse = torch.logsumexp(s, -1) * ops.LOG2E
+    assert (lse.cpu().double() - ref_lse).abs().max().item() < 1e-4
+    # P is rounded to fp16 before PV and O to fp16 on output
+    assert (o16.cpu().double() - o).abs().max().item() < 4e-3 * max(1.0, o.abs().max().item())

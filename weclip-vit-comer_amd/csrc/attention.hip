@@ -1,0 +1,376 @@
+// Multi-head self-attention forward for gfx950 (MFMA fp16, fp32 softmax), in two kernels.
+//
+// Replaces reference clip/myAtt.py:21-64 (`_scaled_dot_product_attention`: q/sqrt(d), bmm,
+// softmax, bmm -- two materialised (B*H, L, L) fp32 tensors) and :325-326 (head-mean of the
+// probabilities), fed by the packed in-projection output (myAtt.py:201,257-268).
+//
+//   attn_fwd_kernel  : flash-style O = softmax(Q K^T) V with online softmax; never writes the
+//                      L x L scores; emits O rounded to fp16 (what myAtt.py:321 feeds the fp16
+//                      out-projection) and the per-row log-sum-exp (base 2).
+//   attn_mean_kernel : mean_h P_h = (1/H) sum_h exp2(Q_h K_h^T - LSE_h) for a 128x128 tile,
+//                      the H-head sum held in MFMA accumulators, written once, coalesced
+//                      (the returned `attn_output_weights.sum(dim=1) / num_heads`).
+//   vt_kernel        : V^T (B,H,dh,Lp) from the packed qkv buffer (keys contiguous, zero padded)
+//                      so PV fragments are 8-byte LDS reads.
+//
+// Input `qkv` is the in-projection GEMM output (B*L, 3E) fp16 with q pre-multiplied by
+// log2(e)/sqrt(dh) (wc_gemm_f16 scale/scale_cols), so every exponential is a bare v_exp_f32.
+//
+// MFMA layouts (v_mfma_f32_32x32x16_f16): A[i=lane&31][k=8*(lane>>5)+j], B[k][j=lane&31],
+// D col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The forward computes S^T = K Q^T so
+// a lane owns one query (softmax statistics are lane-local) and then O^T = V^T P^T taking the
+// S^T accumulators as B operand directly (k order inside a 16-step: 8*(j>>2) + 4*(lane>>5) + (j&3)).
+#include "common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define NEG_BIG (-1.0e30f)
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vt_kernel(const __half* __restrict__ qkv,
+                                                  __half* __restrict__ vt, int L, int Lp, int H,
+                                                  int DH, int E) {
+    // block: 64 tokens x 64 dims of one (b, h-slice); grid (Lp/64, E/64, B)
+    __shared__ __half tile[64][66];
+    const int l0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const int l = l0 + r;
+        tile[r][c] = (l < L) ? qkv[((long)b * L + l) * 3 * E + 2 * E + c0 + c] : __float2half(0.f);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;      // c: dim within slice, r: token
+        const int e = c0 + c;                  // column in E = h*DH + d
+        const int h = e / DH, d = e - h * DH;
+        vt[(((long)b * H + h) * DH + d) * Lp + l0 + r] = tile[r][c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const __half* __restrict__ qkv,
+                                                        const __half* __restrict__ vt,
+                                                        __half* __restrict__ out,
+                                                        float* __restrict__ lse, int L, int Lp, int H,
+                                                        int E) {
+    constexpr int KS = DH / 16;          // k-steps of QK^T
+    constexpr int DT = DH / 32;          // 32-row tiles of O^T
+    constexpr int KROW = DH * 2 + 16;    // bytes per K row in LDS (padded)
+    constexpr int VROW = 136;            // bytes per V^T row in LDS (64 keys + 8 B pad)
+    constexpr int KBUF = 64 * KROW, VBUF = DH * VROW;
+    constexpr int KCH = DH / 8;          // 16-B chunks per K row
+    constexpr int NKC = 64 * KCH / 256;  // K chunks per thread (2 for DH=64, 1 for DH=32)
+    constexpr int NVC = DH * 8 / 256;    // V chunks per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][KBUF + VBUF]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hh = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+    const int qr = qrow < L ? qrow : L - 1;
+    const long ldq = 3L * E;
+    const __half* base = qkv + (long)b * L * ldq + (long)h * DH;
+    const __half* vbase = vt + ((long)b * H + h) * DH * Lp;
+
+    f16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+        qf[s] = *reinterpret_cast<const f16x8*>(base + (long)qr * ldq + 16 * s + 8 * hh);
+
+    uint4 rk[NKC], rv[NVC];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NKC; ++i) {
+            const int c = tid + 256 * i;
+            int key = t * 64 + c / KCH;
+            if (key > L - 1) key = L - 1;
+            rk[i] = *reinterpret_cast<const uint4*>(base + E + (long)key * ldq + (c % KCH) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NVC; ++i) {
+            const int c = tid + 256 * i;
+            rv[i] = *reinterpret_cast<const uint4*>(vbase + (long)(c >> 3) * Lp + t * 64 + (c & 7) * 8);
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* kb = smem + buf * (KBUF + VBUF);
+        char* vb = kb + KBUF;
+#pragma unroll
+        for (int i = 0; i < NKC; ++i) {
+            const int c = tid + 256 * i;
+            *reinterpret_cast<uint4*>(kb + (c / KCH) * KROW + (c % KCH) * 16) = rk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NVC; ++i) {
+            const int c = tid + 256 * i;
+            uint2* p = reinterpret_cast<uint2*>(vb + (c >> 3) * VROW + (c & 7) * 16);
+            p[0] = make_uint2(rv[i].x, rv[i].y);
+            p[1] = make_uint2(rv[i].z, rv[i].w);
+        }
+    };
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m = NEG_BIG, lsum = 0.f;
+
+    const int nt = (L + 63) / 64;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) gload(t + 1);
+        const char* kb = smem + buf * (KBUF + VBUF);
+        const char* vb = kb + KBUF;
+        f32x16 s[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 a0 = *reinterpret_cast<const f16x8*>(kb + l31 * KROW + ks * 32 + hh * 16);
+            const f16x8 a1 = *reinterpret_cast<const f16x8*>(kb + (32 + l31) * KROW + ks * 32 + hh * 16);
+            s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf[ks], s[0], 0, 0, 0);
+            s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf[ks], s[1], 0, 0, 0);
+        }
+        if (t == nt - 1) {   // mask padded keys of the last tile
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= L) s[ti][r] = NEG_BIG;
+                }
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        lsum *= alpha;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        float ps = 0.f;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[ti][r] - mn);
+                s[ti][r] = p;
+                ps += p;
+            }
+        lsum += ps;
+        // O^T += V^T P^T over the 64 keys = 4 k-steps of 16
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            f16x8 pb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pb[j] = (_Float16)s[s2 >> 1][(s2 & 1) * 8 + j];
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const char* vr = vb + (d * 32 + l31) * VROW + (16 * s2 + 4 * hh) * 2;
+                const f16x4 v0 = *reinterpret_cast<const f16x4*>(vr);
+                const f16x4 v1 = *reinterpret_cast<const f16x4*>(vr + 16);
+                f16x8 va;
+                va[0] = v0[0]; va[1] = v0[1]; va[2] = v0[2]; va[3] = v0[3];
+                va[4] = v1[0]; va[5] = v1[1]; va[6] = v1[2]; va[7] = v1[3];
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb, o[d], 0, 0, 0);
+            }
+        }
+        if (t + 1 < nt) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / ltot;
+    if (qrow < L) {
+        __half* orow = out + ((long)b * L + qrow) * E + (long)h * DH;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                __half hv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) hv[k] = __float2half(o[d][g * 4 + k] * inv);
+                *reinterpret_cast<uint2*>(orow + d * 32 + 8 * g + 4 * hh) = *reinterpret_cast<uint2*>(hv);
+            }
+        if (hh == 0) lse[((long)b * H + h) * L + qrow] = m + log2f(ltot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_mean_kernel(const __half* __restrict__ qkv,
+                                                         const float* __restrict__ lse,
+                                                         float* __restrict__ mean, int L, int H, int E) {
+    constexpr int KS = DH / 16;
+    constexpr int ROW = DH * 2 + 16;
+    constexpr int TB = 128 * ROW;        // bytes of one 128-row operand tile
+    constexpr int CH = DH / 8;           // 16-B chunks per row
+    constexpr int NC = 128 * CH / 256;   // chunks per thread per operand (4 for DH=64, 2 for 32)
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][Q tile | K tile | lse 128 f32]
+    constexpr int BUF = 2 * TB + 512;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hh = lane >> 5, l31 = lane & 31;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int k0 = blockIdx.x * 128, q0 = blockIdx.y * 128, b = blockIdx.z;
+    const long ldq = 3L * E;
+    const __half* base = qkv + (long)b * L * ldq;
+
+    uint4 rq[NC], rk[NC];
+    float rl = 0.f;
+    auto gload = [&](int h) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = tid + 256 * i;
+            int qr = q0 + c / CH, kr = k0 + c / CH;
+            if (qr > L - 1) qr = L - 1;
+            if (kr > L - 1) kr = L - 1;
+            rq[i] = *reinterpret_cast<const uint4*>(base + (long)qr * ldq + h * DH + (c % CH) * 8);
+            rk[i] = *reinterpret_cast<const uint4*>(base + (long)kr * ldq + E + h * DH + (c % CH) * 8);
+        }
+        if (tid < 128) {
+            int qr = q0 + tid;
+            if (qr > L - 1) qr = L - 1;
+            rl = lse[((long)b * H + h) * L + qr];
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* qb = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = tid + 256 * i;
+            *reinterpret_cast<uint4*>(qb + (c / CH) * ROW + (c % CH) * 16) = rq[i];
+            *reinterpret_cast<uint4*>(qb + TB + (c / CH) * ROW + (c % CH) * 16) = rk[i];
+        }
+        if (tid < 128) reinterpret_cast<float*>(qb + 2 * TB)[tid] = rl;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int h = 0; h < H; ++h) {
+        const int buf = h & 1;
+        if (h + 1 < H) gload(h + 1);
+        const char* qb = smem + buf * BUF;
+        const float* ls = reinterpret_cast<const float*>(qb + 2 * TB);
+        f32x16 s[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float nl = -ls[wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh];
+                s[mi][0][r] = nl;
+                s[mi][1][r] = nl;
+            }
+        const char* As = qb + (wr * 64 + l31) * ROW + hh * 16;
+        const char* Bs = qb + TB + (wc * 64 + l31) * ROW + hh * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 a0 = *reinterpret_cast<const f16x8*>(As + ks * 32);
+            const f16x8 a1 = *reinterpret_cast<const f16x8*>(As + 32 * ROW + ks * 32);
+            const f16x8 b0 = *reinterpret_cast<const f16x8*>(Bs + ks * 32);
+            const f16x8 b1 = *reinterpret_cast<const f16x8*>(Bs + 32 * ROW + ks * 32);
+            s[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, s[0][0], 0, 0, 0);
+            s[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, s[0][1], 0, 0, 0);
+            s[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, s[1][0], 0, 0, 0);
+            s[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, s[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] += __builtin_amdgcn_exp2f(s[mi][ni][r]);
+        if (h + 1 < H) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    const float invh = 1.0f / H;
+    float* mb = mean + (long)b * L * L;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int key = k0 + wc * 64 + ni * 32 + l31;
+            if (key >= L) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = q0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (q < L) mb[(long)q * L + key] = acc[mi][ni][r] * invh;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int wc_attn_vt(const void* qkv, void* vt, int B, int L, int Lp, int H, int DH, void* stream) {
+    const int E = H * DH;
+    WC_CHECK_ARG(qkv && vt && B > 0 && L > 0 && Lp >= L && Lp % 64 == 0 && E % 64 == 0,
+                 "wc_attn_vt: need Lp %% 64 == 0, Lp >= L, (H*DH) %% 64 == 0");
+    dim3 grid(Lp / 64, E / 64, B);
+    hipLaunchKernelGGL(vt_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const __half*)qkv,
+                       (__half*)vt, L, Lp, H, DH, E);
+    WC_LAUNCH_CHECK("vt_kernel");
+    return WC_OK;
+}
+
+extern "C" int wc_attn_fwd(const void* qkv, const void* vt, void* out, float* lse, int B, int L, int Lp,
+                           int H, int DH, void* stream) {
+    const int E = H * DH;
+    WC_CHECK_ARG(qkv && vt && out && lse && B > 0 && L > 0 && Lp >= L && Lp % 64 == 0,
+                 "wc_attn_fwd: bad argument");
+    WC_CHECK_ARG(DH == 64 || DH == 32, "wc_attn_fwd: head dim must be 32 or 64 (got %d)", DH);
+    WC_CHECK_ARG(E % 8 == 0 && B <= 65535 && H <= 65535, "wc_attn_fwd: bad shape");
+    dim3 grid(wc_cdiv(L, 128), H, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (DH == 64) {
+        const size_t lds = 2 * (64 * (64 * 2 + 16) + 64 * 136);
+        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), lds, st, (const __half*)qkv,
+                           (const __half*)vt, (__half*)out, lse, L, Lp, H, E);
+    } else {
+        const size_t lds = 2 * (64 * (32 * 2 + 16) + 32 * 136);
+        hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), lds, st, (const __half*)qkv,
+                           (const __half*)vt, (__half*)out, lse, L, Lp, H, E);
+    }
+    WC_LAUNCH_CHECK("attn_fwd_kernel");
+    return WC_OK;
+}
+
+extern "C" int wc_attn_mean(const void* qkv, const float* lse, float* mean, int B, int L, int H, int DH,
+                            void* stream) {
+    const int E = H * DH;
+    WC_CHECK_ARG(qkv && lse && mean && B > 0 && L > 0 && H > 0, "wc_attn_mean: bad argument");
+    WC_CHECK_ARG(DH == 64 || DH == 32, "wc_attn_mean: head dim must be 32 or 64 (got %d)", DH);
+    const int nt = wc_cdiv(L, 128);
+    dim3 grid(nt, nt, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (DH == 64) {
+        const size_t lds = 2 * (2 * 128 * (64 * 2 + 16) + 512);
+        hipLaunchKernelGGL(attn_mean_kernel<64>, grid, dim3(256), lds, st, (const __half*)qkv, lse, mean,
+                           L, H, E);
+    } else {
+        const size_t lds = 2 * (2 * 128 * (32 * 2 + 16) + 512);
+        hipLaunchKernelGGL(attn_mean_kernel<32>, grid, dim3(256), lds, st, (const __half*)qkv, lse, mean,
+                           L, H, E);
+    }
+    WC_LAUNCH_CHECK("attn_mean_kernel");
+    return WC_OK;
+}

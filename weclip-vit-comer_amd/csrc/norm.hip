@@ -1,0 +1,82 @@
+// Row LayerNorm (fp32 statistics) for gfx950.  Replaces `LayerNorm.forward`
+// (reference clip/model.py:177-183, WeCLIP_model/Decoder/TransDecoder.py:50-56): fp32 in,
+// fp32 math, and the result written in the formats the next consumer wants -- fp32 and/or an
+// fp16 hi(+lo) pair that feeds the MFMA GEMM without a separate cast pass.
+// One 64-lane wave per row (wavefront shuffle reductions), 4 rows per 256-thread block.
+#include "common.h"
+
+template <int MAXV>   // MAXV float4 per lane => D <= 256*MAXV
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ b, float eps,
+                                                         float* __restrict__ y32,
+                                                         __half* __restrict__ y16,
+                                                         __half* __restrict__ y16lo, long rows, int D,
+                                                         long ldx) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = D >> 2;   // float4 per row
+    const float4* xr = reinterpret_cast<const float4*>(x + row * ldx);
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nv) {
+            v[i] = xr[j];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nv) {
+            const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + bb * bb) + (c * c + d * d);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    const float4* wr = reinterpret_cast<const float4*>(w);
+    const float4* br = reinterpret_cast<const float4*>(b);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nv) {
+            const float4 ww = wr[j], bb = br[j];
+            float o[4] = {(v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y,
+                          (v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w};
+            const long off = row * D + 4L * j;
+            if (y32) *reinterpret_cast<float4*>(y32 + off) = make_float4(o[0], o[1], o[2], o[3]);
+            if (y16) {
+                __half h[4], l[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    h[k] = __float2half(o[k]);
+                    l[k] = __float2half(o[k] - __half2float(h[k]));
+                }
+                *reinterpret_cast<uint2*>(y16 + off) = *reinterpret_cast<uint2*>(h);
+                if (y16lo) *reinterpret_cast<uint2*>(y16lo + off) = *reinterpret_cast<uint2*>(l);
+            }
+        }
+    }
+}
+
+extern "C" int wc_layernorm(const float* x, long ldx, const float* w, const float* b, float eps,
+                            float* y32, void* y16, void* y16lo, long rows, int D, void* stream) {
+    WC_CHECK_ARG(x && w && b && rows > 0 && D > 0 && D % 4 == 0 && D <= 4096 && ldx >= D && ldx % 4 == 0,
+                 "wc_layernorm: need D %% 4 == 0, D <= 4096, ldx %% 4 == 0");
+    WC_CHECK_ARG(y32 || y16, "wc_layernorm: no output requested");
+    dim3 grid(wc_cdiv(rows, 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (D <= 256)
+        hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, st, x, w, b, eps, y32, (__half*)y16, (__half*)y16lo, rows, D, ldx);
+    else if (D <= 1024)
+        hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, x, w, b, eps, y32, (__half*)y16, (__half*)y16lo, rows, D, ldx);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<16>, grid, dim3(256), 0, st, x, w, b, eps, y32, (__half*)y16, (__half*)y16lo, rows, D, ldx);
+    WC_LAUNCH_CHECK("layernorm_kernel");
+    return WC_OK;
+}

@@ -1,0 +1,96 @@
+"""Typed Python wrappers over the C ABI (include/weclip_hip.h).  Tensors in, tensors out; every
+wrapper allocates its outputs with torch (device memory + current stream only) and calls the
+HIP library.  No arithmetic happens in torch here."""
+import math
+
+import torch
+
+from . import _lib as L
+
+F16 = torch.float16
+F32 = torch.float32
+LOG2E = 1.4426950408889634
+
+
+class Split:
+    """An fp32 tensor represented for the MFMA GEMM as fp16 `hi` (+ optional fp16 `lo` with
+    x ~= hi + lo).  `lo is None` means single-pass fp16 precision."""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi, lo=None):
+        self.hi, self.lo = hi, lo
+
+
+def split_f16(x, with_lo=False):
+    """fp32 tensor -> Split (hi = fp16(x), lo = fp16(x - hi))."""
+    L.require_gpu()
+    x = x.detach().float().contiguous()
+    hi = torch.empty(x.shape, device=x.device, dtype=F16)
+    lo = torch.empty(x.shape, device=x.device, dtype=F16) if with_lo else None
+    L.lib().wc_split_f16(L.ptr(x, F32, "x"), L.ptr(hi), L.ptr(lo), x.numel(), L.stream())
+    return Split(hi, lo)
+
+
+def gemm(a, w, M, N, K, *, lda=None, ldw=None, bias=None, resid=None, ldr=None, sR=None,
+         out32=None, out16=None, out16lo=None, ldc=None, act=0, round16=False, scale=1.0,
+         scale_cols=0, batch=1, sA=0, sW=0, sC=0):
+    """C = epilogue(A W^T).  `a`, `w`: Split (or fp16 tensors).  Segments accumulated:
+    (a.hi,w.hi) [+ (a.lo,w.hi)] [+ (a.hi,w.lo)]."""
+    a = a if isinstance(a, Split) else Split(a)
+    w = w if isinstance(w, Split) else Split(w)
+    segs = [(a.hi, w.hi)]
+    if a.lo is not None:
+        segs.append((a.lo, w.hi))
+    if w.lo is not None:
+        segs.append((a.hi, w.lo))
+    lda = K if lda is None else lda
+    ldw = K if ldw is None else ldw
+    ldc = N if ldc is None else ldc
+    ap = [L.ptr(s[0], F16, "A") for s in segs] + [None] * (3 - len(segs))
+    wp = [L.ptr(s[1], F16, "W") for s in segs] + [None] * (3 - len(segs))
+    ldr = ldc if ldr is None else ldr
+    sR = sC if sR is None else sR
+    L.lib().wc_gemm_f16(ap[0], ap[1], ap[2], wp[0], wp[1], wp[2], len(segs), M, N, K, lda, ldw,
+                        batch, sA, sW, sC, L.ptr(bias, F32, "bias"), L.ptr(resid, F32, "resid"),
+                        ldr, sR, L.ptr(out32, F32, "out32"), L.ptr(out16, F16, "out16"),
+                        L.ptr(out16lo, F16, "out16lo"), ldc, act, 1 if round16 else 0,
+                        float(scale), scale_cols, L.stream())
+
+
+def layernorm(x, weight, bias, *, eps=1e-5, want32=False, want16=True, with_lo=False, rows=None,
+              D=None, ldx=None):
+    """Row LayerNorm of fp32 x (rows, D).  Returns (y32 or None, Split or None)."""
+    D = x.shape[-1] if D is None else D
+    rows = x.numel() // D if rows is None else rows
+    ldx = D if ldx is None else ldx
+    dev = x.device
+    y32 = torch.empty(rows, D, device=dev, dtype=F32) if want32 else None
+    hi = torch.empty(rows, D, device=dev, dtype=F16) if want16 else None
+    lo = torch.empty(rows, D, device=dev, dtype=F16) if (want16 and with_lo) else None
+    L.lib().wc_layernorm(L.ptr(x, F32, "x"), ldx, L.ptr(weight, F32, "ln.weight"),
+                         L.ptr(bias, F32, "ln.bias"), eps, L.ptr(y32), L.ptr(hi), L.ptr(lo), rows, D,
+                         L.stream())
+    return y32, (Split(hi, lo) if want16 else None)
+
+
+def attention(qkv16, B, Lq, H, DH, want_mean=True):
+    """qkv16 (B*L, 3E) fp16 with q pre-scaled by log2(e)/sqrt(DH).
+    Returns (o16 (B*L, E) fp16, lse (B,H,L) f32, mean (B,L,L) f32 or None)."""
+    E = H * DH
+    dev = qkv16.device
+    Lp = (Lq + 63) // 64 * 64
+    vt = torch.empty(B, H, DH, Lp, device=dev, dtype=F16)
+    lib = L.lib()
+    lib.wc_attn_vt(L.ptr(qkv16, F16, "qkv"), L.ptr(vt), B, Lq, Lp, H, DH, L.stream())
+    o16 = torch.empty(B * Lq, E, device=dev, dtype=F16)
+    lse = torch.empty(B, H, Lq, device=dev, dtype=F32)
+    lib.wc_attn_fwd(L.ptr(qkv16), L.ptr(vt), L.ptr(o16), L.ptr(lse), B, Lq, Lp, H, DH, L.stream())
+    mean = None
+    if want_mean:
+        mean = torch.empty(B, Lq, Lq, device=dev, dtype=F32)
+        lib.wc_attn_mean(L.ptr(qkv16), L.ptr(lse), L.ptr(mean), B, Lq, H, DH, L.stream())
+    return o16, lse, mean
+
+
+def q_scale(DH):
+    return LOG2E / math.sqrt(DH)
