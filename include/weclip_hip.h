@@ -97,6 +97,13 @@ int wc_attn_fwd(const void* qkv, const void* vt, void* out, float* lse, int B, i
 int wc_attn_mean(const void* qkv, const float* lse, float* mean, int B, int L, int H, int DH,
                  void* stream);
 
+/* ---- ViT patch embedding ---------------------------------------------------------------- */
+/* clip/model.py:264-272.  wc_patchify: img (B,3,H,W) f32 -> im2col rows (B*h*w, 3*P*P) fp16 hi
+ * (+lo, may be NULL) in the conv weight's (c,ky,kx) order, so conv1 == wc_gemm_f16.
+ * wc_cls_rows: x[b,0,:] = class_embedding + pos[0] for the token tensor x (B,L,E) f32. */
+int wc_patchify(const float* img, void* hi, void* lo, int B, int H, int W, int P, void* stream);
+int wc_cls_rows(float* x, const float* cls, const float* pos0, int B, int L, int E, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
