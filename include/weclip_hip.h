@@ -66,13 +66,17 @@ int wc_bilinear_resize(const float* src, float* dst, int planes, int Hs, int Ws,
  * epilogue: v = acc + bias[n]; if round16: v = fp16(v); if n < scale_cols: v *= scale;
  *           v = act(v) (0 none, 1 QuickGELU, 2 ReLU, 3 sigmoid); v += resid[m*ldr + n];
  *           C32[m,n] = v; C16[m,n] = fp16(v); C16lo[m,n] = fp16(v - C16).
+ *           P32 (optional) receives the pre-activation value.  act 4 (backward of QuickGELU,
+ *           clip/model.py:186-188): v *= d/du[u*sigmoid(1.702u)] at u = aux[arow*ldaux + n],
+ *           arow = rowmap[m / rpg]*rpg + m % rpg (rowmap NULL: arow = m).
  * batch > 1: operand/output/residual batch strides sA/sW/sC/sR in elements.  K % 64 == 0, lda/ldw % 8 == 0. */
 int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const void* W0, const void* W1,
                 const void* W2, int nseg, int M, int N, int K, long lda, long ldw, int batch,
                 long sA, long sW, long sC, const float* bias, const float* resid, long ldr, long sR,
                 float* C32,
                 void* C16, void* C16lo, long ldc, int act, int round16, float scale,
-                int scale_cols, void* stream);
+                int scale_cols, float* P32, const float* aux, const int* rowmap, int rpg,
+                long ldaux, void* stream);
 /* fp32 -> fp16 hi (+ lo = fp16(x - hi), may be NULL): `.half()` casts of weights/activations
  * (clip/model.py:457-478 convert_weights; clip/myAtt.py:321). */
 int wc_split_f16(const float* x, void* hi, void* lo, long n, void* stream);
@@ -89,11 +93,12 @@ int wc_layernorm(const float* x, long ldx, const float* w, const float* b, float
  * wc_attn_vt:   V^T (B,H,DH,Lp) fp16, keys contiguous, zero padded to Lp (Lp % 64 == 0).
  * wc_attn_fwd:  clip/myAtt.py:21-64 without materialising the scores: out (B*L, E) fp16 =
  *               softmax(QK^T)V with heads merged (the `.half()` input of the out-projection,
- *               myAtt.py:319-321); lse (B,H,L) f32 = log2-sum-exp2 of each score row.
+ *               myAtt.py:319-321); out32 (optional) the same before fp16 rounding;
+ *               lse (B,H,L) f32 = log2-sum-exp2 of each score row.
  * wc_attn_mean: clip/myAtt.py:325-326: mean (B,L,L) f32 = (1/H) sum_h softmax_h. */
 int wc_attn_vt(const void* qkv, void* vt, int B, int L, int Lp, int H, int DH, void* stream);
-int wc_attn_fwd(const void* qkv, const void* vt, void* out, float* lse, int B, int L, int Lp, int H,
-                int DH, void* stream);
+int wc_attn_fwd(const void* qkv, const void* vt, void* out, float* out32, float* lse, int B, int L,
+                int Lp, int H, int DH, void* stream);
 int wc_attn_mean(const void* qkv, const float* lse, float* mean, int B, int L, int H, int DH,
                  void* stream);
 
@@ -103,6 +108,42 @@ int wc_attn_mean(const void* qkv, const float* lse, float* mean, int B, int L, i
  * wc_cls_rows: x[b,0,:] = class_embedding + pos[0] for the token tensor x (B,L,E) f32. */
 int wc_patchify(const float* img, void* hi, void* lo, int B, int H, int W, int P, void* stream);
 int wc_cls_rows(float* x, const float* cls, const float* pos0, int B, int L, int E, void* stream);
+
+/* ---- GradCAM on the last CLIP block (analytic, batched over (image, class) pairs) ------- */
+/* Replaces pytorch_grad_cam/base_cam.py:62-154, grad_cam.py:16-23,
+ * activations_and_gradients.py:19-47 (autograd through CLIP.forward_last_layer,
+ * clip/model.py:407-429).  P pairs; pair_img[p] = image of pair p, pair_cls[p] = index of the
+ * target row among that pair's text rows.  L tokens, E width, Ed joint embedding width.
+ *
+ * wc_cam_head: x2 (B,L,E) f32 block output -> ln_post, mean over patch tokens, @proj (E,Ed),
+ *   cosine logits against pre-normalised text rows text[text_idx[p,t]] (t < n_text[p], row
+ *   stride Tmax), softmax -> probs (P,Tmax); df (P,E) = d probs[p,cls] / d pooled feature.
+ *   partial: workspace B*ceil(L/64)*E f32.  logit_scale = exp(CLIP.logit_scale).
+ * wc_lnpost_bwd: dx2 (P,L,E) = gs * backward of ln_post+mean-pool (token 0 gets 0);
+ *   written as f32 and as fp16 hi/lo GEMM operands.
+ * wc_ln2_bwd_add: g16 = fp16((dx2 + LN2_bwd(da2; x1)) / gs): the gradient arriving at the fp16
+ *   out-projection output (autograd rounds it to fp16, clip/myAtt.py:321).
+ * wc_attn_bwd_colsum: column sums over tokens of dq,dk,dv -> c (P,3E) f32 from the packed
+ *   qkv (B*L,3E fp16, q pre-scaled), dO (P*L,E fp16), o32 (B*L,E), lse (B,H,L).
+ *   Workspaces: delta,u,dS0,P0 each (P,H,L) f32.
+ * wc_rowvec_matmul: out (P,E) = scale * c (P,N) @ W (N,E), fp32 FMA.
+ * wc_cam_map: cam (P,L-1) = scale_cam(scale_cam(relu(A w))) with A = a32[img, 1:, :]
+ *   (base_cam.py:56-60,144-154; utils/image.py:51-61). */
+int wc_cam_head(const float* x2, const float* lnw, const float* lnb, const float* proj,
+                const float* text, const int* text_idx, const int* n_text, const int* pair_img,
+                const int* pair_cls, float logit_scale, float* partial, float* probs, float* df,
+                int B, int P, int L, int E, int Ed, int Tmax, void* stream);
+int wc_lnpost_bwd(const float* df, const float* x2, const float* lnw, float gs, const int* pair_img,
+                  float* d32, void* dhi, void* dlo, int P, int L, int E, void* stream);
+int wc_ln2_bwd_add(const float* da2, const float* dx2, const float* x1, const float* lnw, float gs,
+                   const int* pair_img, void* g16, int P, int L, int E, void* stream);
+int wc_attn_bwd_colsum(const void* qkv, const void* dO, const float* o32, const float* lse,
+                       const int* pair_img, float* delta, float* u, float* dS0, float* P0, float* c,
+                       int P, int L, int H, int DH, void* stream);
+int wc_rowvec_matmul(const float* c, const float* W, float* out, int P, int N, int E, float scale,
+                     void* stream);
+int wc_cam_map(const float* a32, const float* w, const int* pair_img, float* cam, int P, int L, int E,
+               void* stream);
 
 #ifdef __cplusplus
 }

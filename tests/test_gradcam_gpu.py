@@ -1,0 +1,67 @@
+"""Block-12 forward + analytic GradCAM on the HIP path vs the reference goldens (K7/K8)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+
+class Target:
+    def __init__(self, category):
+        self.category = category
+
+
+def _run(sd, img, heads_embed, labels, H, W):
+    from weclip_vit_comer_amd import clip
+    from weclip_vit_comer_amd.pytorch_grad_cam import GradCAM
+    model, _ = clip.load(sd, device="cuda")
+    fts, attns = model.encode_image(img.cuda(), H, W, require_all_fts=True)
+    cam = GradCAM(model=model, target_layers=[model.visual.transformer.resblocks[-1].ln_1])
+    bg, fg = synth.make_text_features(20, 25, heads_embed)
+    out = []
+    for i, ids in enumerate(labels):
+        text = torch.cat([fg[ids], bg], 0).cuda()
+        for j in range(len(ids)):
+            g, p, a = cam(input_tensor=[fts[-1][:, i:i + 1], text, H, W], targets=[Target(j)])
+            out.append((g[0], p.cpu().numpy()[0], a.cpu().numpy()[0]))
+    return out
+
+
+@pytest.mark.parametrize("precision", ["fast", "exact"])
+def test_tiny_gradcam_matches_reference(golden, precision):
+    from weclip_vit_comer_amd import config
+    config.precision = precision
+    try:
+        g = golden("tiny_func.npz")
+        sd = synth.make_clip_state_dict(**synth.TINY)
+        H, W = synth.TINY_HW
+        out = _run(sd, synth.make_images(2, H, W), synth.TINY["embed_dim"], synth.TINY_LABELS, H, W)
+        for n, (cam, probs, attn) in enumerate(out):
+            ep = np.abs(probs - g["probs"][n]).max() / g["probs"][n].max()
+            ec = np.abs(cam - g["cams"][n]).max()
+            ea = np.abs(attn - g["attn_last"][n]).max() / g["attn_last"][n].max()
+            print(f"[{precision}] tiny pair {n}: probs rel {ep:.2e}  cam abs {ec:.2e}  attn rel {ea:.2e}")
+            assert ep < 5e-3 and ea < 5e-3
+            assert ec < 3e-2
+    finally:
+        config.precision = "fast"
+
+
+@pytest.mark.parametrize("precision", ["fast", "exact"])
+def test_vitb_224_gradcam_matches_reference(golden, precision):
+    """BASELINE config 0 on the GPU path: CAM logits (class probabilities) and CAM maps."""
+    from weclip_vit_comer_amd import config
+    config.precision = precision
+    try:
+        g = golden("vitb_224.npz")
+        sd = synth.make_clip_state_dict(seed=0, with_text=False)
+        out = _run(sd, synth.make_images(1, 224, 224, seed=100), 512, [[0, 1]], 224, 224)
+        for j, (cam, probs, attn) in enumerate(out):
+            ep = (np.abs(probs - g["probs"][0]) / g["probs"][0]).max()
+            ec = np.abs(cam - g["cams"][j]).max()
+            print(f"[{precision}] vitb224 class {j}: CAM-logit rel err {ep:.2e}  CAM map abs err {ec:.2e}")
+            assert ep < 1e-2 and ec < 5e-2
+    finally:
+        config.precision = "fast"

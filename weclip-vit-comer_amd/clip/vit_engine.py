@@ -46,17 +46,22 @@ def run_block(pk, x, B, L, want_mean=True, keep=None):
     a32, a = ops.layernorm(x, pk.ln1_w, pk.ln1_b, want32=keep is not None, with_lo=ex)
     qkv = torch.empty(M, 3 * E, device=dev, dtype=F16)
     ops.gemm(a, pk.in_w, M, 3 * E, E, bias=pk.in_b, out16=qkv, scale=ops.q_scale(DH), scale_cols=E)
-    o16, lse, mean = ops.attention(qkv, B, L, H, DH, want_mean=want_mean)
+    o32 = None
+    if keep is not None:
+        o16, lse, mean, o32 = ops.attention(qkv, B, L, H, DH, want_mean=want_mean, want_o32=True)
+    else:
+        o16, lse, mean = ops.attention(qkv, B, L, H, DH, want_mean=want_mean)
     x1 = torch.empty(M, E, device=dev, dtype=F32)
     ops.gemm(o16, pk.out_w, M, E, E, bias=pk.out_b, resid=x, out32=x1, round16=True)
     _, a2 = ops.layernorm(x1, pk.ln2_w, pk.ln2_b, with_lo=ex)
     z = Split(torch.empty(M, 4 * E, device=dev, dtype=F16),
               torch.empty(M, 4 * E, device=dev, dtype=F16) if ex else None)
-    ops.gemm(a2, pk.fc_w, M, 4 * E, E, bias=pk.fc_b, out16=z.hi, out16lo=z.lo, act=1)
+    u32 = torch.empty(M, 4 * E, device=dev, dtype=F32) if keep is not None else None
+    ops.gemm(a2, pk.fc_w, M, 4 * E, E, bias=pk.fc_b, out16=z.hi, out16lo=z.lo, act=1, pre32=u32)
     x2 = torch.empty(M, E, device=dev, dtype=F32)
     ops.gemm(z, pk.pj_w, M, E, 4 * E, bias=pk.pj_b, resid=x1, out32=x2)
     if keep is not None:
-        keep.update(a32=a32, a=a, qkv=qkv, o16=o16, lse=lse, x1=x1, a2=a2, z=z)
+        keep.update(a32=a32, qkv=qkv, o32=o32, lse=lse, x1=x1, u32=u32)
     return x2, mean
 
 

@@ -54,6 +54,7 @@ template <int DH>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const __half* __restrict__ qkv,
                                                         const __half* __restrict__ vt,
                                                         __half* __restrict__ out,
+                                                        float* __restrict__ out32,
                                                         float* __restrict__ lse, int L, int Lp, int H,
                                                         int E) {
     constexpr int KS = DH / 16;          // k-steps of QK^T
@@ -203,6 +204,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __half* __restrict_
 #pragma unroll
                 for (int k = 0; k < 4; ++k) hv[k] = __float2half(o[d][g * 4 + k] * inv);
                 *reinterpret_cast<uint2*>(orow + d * 32 + 8 * g + 4 * hh) = *reinterpret_cast<uint2*>(hv);
+                if (out32)
+                    *reinterpret_cast<float4*>(out32 + ((long)b * L + qrow) * E + (long)h * DH + d * 32 + 8 * g + 4 * hh) =
+                        make_float4(o[d][g * 4] * inv, o[d][g * 4 + 1] * inv, o[d][g * 4 + 2] * inv, o[d][g * 4 + 3] * inv);
             }
         if (hh == 0) lse[((long)b * H + h) * L + qrow] = m + log2f(ltot);
     }
@@ -332,8 +336,8 @@ extern "C" int wc_attn_vt(const void* qkv, void* vt, int B, int L, int Lp, int H
     return WC_OK;
 }
 
-extern "C" int wc_attn_fwd(const void* qkv, const void* vt, void* out, float* lse, int B, int L, int Lp,
-                           int H, int DH, void* stream) {
+extern "C" int wc_attn_fwd(const void* qkv, const void* vt, void* out, float* out32, float* lse, int B,
+                           int L, int Lp, int H, int DH, void* stream) {
     const int E = H * DH;
     WC_CHECK_ARG(qkv && vt && out && lse && B > 0 && L > 0 && Lp >= L && Lp % 64 == 0,
                  "wc_attn_fwd: bad argument");
@@ -344,11 +348,11 @@ extern "C" int wc_attn_fwd(const void* qkv, const void* vt, void* out, float* ls
     if (DH == 64) {
         const size_t lds = 2 * (64 * (64 * 2 + 16) + 64 * 136);
         hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), lds, st, (const __half*)qkv,
-                           (const __half*)vt, (__half*)out, lse, L, Lp, H, E);
+                           (const __half*)vt, (__half*)out, out32, lse, L, Lp, H, E);
     } else {
         const size_t lds = 2 * (64 * (32 * 2 + 16) + 32 * 136);
         hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), lds, st, (const __half*)qkv,
-                           (const __half*)vt, (__half*)out, lse, L, Lp, H, E);
+                           (const __half*)vt, (__half*)out, out32, lse, L, Lp, H, E);
     }
     WC_LAUNCH_CHECK("attn_fwd_kernel");
     return WC_OK;

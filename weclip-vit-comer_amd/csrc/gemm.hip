@@ -43,6 +43,11 @@ struct GemmArgs {
     int round16;          // round (acc+bias) through fp16 first (forced-fp16 out-proj, myAtt.py:321)
     float scale;          // multiply columns n < scale_cols by scale (q / sqrt(dh), myAtt.py:54)
     int scale_cols;
+    float* P32;           // optional fp32 copy of the pre-activation value (acc + bias)
+    const float* aux;     // act 4: v *= QuickGELU'(aux[arow*ldaux + n]), arow = rowmap[m / rpg]*rpg + m % rpg
+    const int* rowmap;
+    int rpg;
+    long ldaux;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -149,7 +154,14 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
                 float v = acc[mi][ni][r] + bv;
                 if (g.round16) v = __half2float(__float2half(v));
                 v *= sc;
-                v = apply_act(v, g.act);
+                if (g.P32) g.P32[cb + (long)row * g.ldc + col] = v;
+                if (g.act == 4) {
+                    const long arow = g.rowmap ? (long)g.rowmap[row / g.rpg] * g.rpg + row % g.rpg : row;
+                    const float u = g.aux[arow * g.ldaux + col];
+                    const float sg = 1.0f / (1.0f + __expf(-1.702f * u));
+                    v *= sg * (1.0f + 1.702f * u * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
+                } else
+                    v = apply_act(v, g.act);
                 const long o = cb + (long)row * g.ldc + col;
                 if (g.resid) v += g.resid[zb * g.sR + (long)row * g.ldr + col];
                 if (g.C32) g.C32[o] = v;
@@ -166,7 +178,8 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
                            const void* W1, const void* W2, int nseg, int M, int N, int K, long lda,
                            long ldw, int batch, long sA, long sW, long sC, const float* bias,
                            const float* resid, long ldr, long sR, float* C32, void* C16, void* C16lo, long ldc, int act,
-                           int round16, float scale, int scale_cols, void* stream) {
+                           int round16, float scale, int scale_cols, float* P32, const float* aux,
+                           const int* rowmap, int rpg, long ldaux, void* stream) {
     WC_CHECK_ARG(nseg >= 1 && nseg <= 3, "wc_gemm_f16: nseg must be 1..3");
     WC_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % BK == 0, "wc_gemm_f16: need M,N>0 and K %% 64 == 0 (got M=%d N=%d K=%d)", M, N, K);
     WC_CHECK_ARG(A0 && W0 && (nseg < 2 || (A1 && W1)) && (nseg < 3 || (A2 && W2)),
@@ -176,7 +189,8 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
     WC_CHECK_ARG(((uintptr_t)A0 | (uintptr_t)W0 | (uintptr_t)A1 | (uintptr_t)W1 | (uintptr_t)A2 |
                   (uintptr_t)W2) % 16 == 0, "wc_gemm_f16: operands must be 16-byte aligned");
     WC_CHECK_ARG((C32 || C16) && ldc >= N && batch >= 1 && batch <= 65535, "wc_gemm_f16: bad output");
-    WC_CHECK_ARG(act >= 0 && act <= 3, "wc_gemm_f16: act must be 0..3");
+    WC_CHECK_ARG(act >= 0 && act <= 4, "wc_gemm_f16: act must be 0..4");
+    WC_CHECK_ARG(act != 4 || (aux && rpg > 0 && ldaux >= N), "wc_gemm_f16: act 4 needs aux, rpg, ldaux");
     GemmArgs g;
     g.A[0] = (const __half*)A0; g.A[1] = (const __half*)A1; g.A[2] = (const __half*)A2;
     g.W[0] = (const __half*)W0; g.W[1] = (const __half*)W1; g.W[2] = (const __half*)W2;
@@ -184,6 +198,7 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
     g.sA = sA; g.sW = sW; g.sC = sC; g.sR = sR; g.bias = bias; g.resid = resid; g.ldr = ldr;
     g.C32 = C32; g.C16 = (__half*)C16; g.C16lo = (__half*)C16lo; g.ldc = ldc;
     g.act = act; g.round16 = round16; g.scale = scale; g.scale_cols = scale_cols;
+    g.P32 = P32; g.aux = aux; g.rowmap = rowmap; g.rpg = rpg > 0 ? rpg : 1; g.ldaux = ldaux;
     dim3 grid(wc_cdiv(N, BN), wc_cdiv(M, BM), batch);
     WC_CHECK_ARG(grid.y <= 65535, "wc_gemm_f16: M too large for one launch");
     const size_t lds = 2 * 2 * BM * LDS_ROW;

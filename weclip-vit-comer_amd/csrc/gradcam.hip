@@ -1,0 +1,559 @@
+// GradCAM on the last CLIP block without autograd, for all (image, class) pairs of a batch.
+//
+// Replaces reference pytorch_grad_cam/base_cam.py:62-154 + grad_cam.py:16-23 +
+// activations_and_gradients.py:19-47 driving autograd through CLIP.forward_last_layer
+// (clip/model.py:407-429): one block-12 forward per IMAGE (the reference repeats it per class)
+// and one analytic backward per (image, class) PAIR, batched as P right-hand sides.  The backward
+// is linear in the seed; GradCAM only needs w_c = mean over patch tokens of dp_j/dA[token, c]
+// (A = ln_1 output), and A feeds nothing but the in-projection, so w = colsum(dqkv) W_in / hw.
+// Column sums of dq, dk, dv over the patch tokens reduce to (per head, S = natural scores):
+//   u_l  = sum_q dS[q,l]                 dS = P * (dP - delta),  dP = dO V^T,  delta = rowsum(dO*O)
+//   cq   = sum_l u_l k_l / sqrt(dh)
+//   ck   = - sum_q dS[q,0] q_q / sqrt(dh)            (rows of dS sum to zero)
+//   cv   = sum_q (1 - P[q,0]) dO_q                   (rows of P sum to one)
+// (dO of the CLS query is exactly 0: the class logit pools patch tokens only.)
+// Gradients are carried multiplied by a power of two `gs` wherever they are stored as fp16 hi+lo
+// MFMA operands, and unscaled where the reference itself rounds them to fp16 (backward of the
+// forced-fp16 out-projection, clip/myAtt.py:321).
+#include "common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// (a) partial[b, chunk, :] = sum over tokens l in chunk, l >= 1, of ln_post(x2[b, l, :])
+__global__ __launch_bounds__(256) void lnpost_pool_kernel(const float* __restrict__ x2,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ bb, float eps,
+                                                           float* __restrict__ partial, int L, int E,
+                                                           int nchunk) {
+    extern __shared__ float sm[];   // [4][E]
+    const int b = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* acc = sm + wv * E;
+    for (int e = lane; e < E; e += 64) acc[e] = 0.f;
+    const int l0 = chunk * 64;
+    for (int l = l0 + wv; l < l0 + 64 && l < L; l += 4) {
+        if (l == 0) continue;
+        const float* xr = x2 + ((long)b * L + l) * E;
+        float s = 0.f;
+        for (int e = lane; e < E; e += 64) s += xr[e];
+        const float mean = wave_sum(s) / E;
+        float q = 0.f;
+        for (int e = lane; e < E; e += 64) { const float d = xr[e] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) / E + eps);
+        for (int e = lane; e < E; e += 64) acc[e] += (xr[e] - mean) * rstd * w[e] + bb[e];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += 256)
+        partial[((long)b * nchunk + chunk) * E + e] = sm[e] + sm[E + e] + sm[2 * E + e] + sm[3 * E + e];
+}
+
+// (b) per pair: f = mean token feature, y = f proj, probs = softmax(s * yhat . that), seed -> df
+// text rows are pre-normalised; text_idx[p, t] indexes rows of `text` (T_p = n_text[p] rows in use).
+__global__ __launch_bounds__(512) void cam_head_kernel(const float* __restrict__ partial,
+                                                        const float* __restrict__ proj,
+                                                        const float* __restrict__ text,
+                                                        const int* __restrict__ text_idx,
+                                                        const int* __restrict__ n_text,
+                                                        const int* __restrict__ pair_img,
+                                                        const int* __restrict__ pair_cls, float logit_scale,
+                                                        float* __restrict__ probs, float* __restrict__ df,
+                                                        int L, int E, int Ed, int nchunk, int Tmax) {
+    extern __shared__ float sm[];   // f[E] | y[Ed] | dy[Ed] | logit[Tmax] | red[16]
+    float* f = sm;
+    float* y = f + E;
+    float* dy = y + Ed;
+    float* lg = dy + Ed;
+    float* red = lg + Tmax;
+    const int p = blockIdx.x, img = pair_img[p], cls = pair_cls[p], T = n_text[p], tid = threadIdx.x;
+    for (int e = tid; e < E; e += 512) {
+        float s = 0.f;
+        for (int c = 0; c < nchunk; ++c) s += partial[((long)img * nchunk + c) * E + e];
+        f[e] = s / (L - 1);
+    }
+    __syncthreads();
+    for (int t = tid; t < Ed; t += 512) {
+        float s = 0.f;
+        for (int e = 0; e < E; ++e) s = fmaf(f[e], proj[(long)e * Ed + t], s);
+        y[t] = s;
+    }
+    __syncthreads();
+    float q = 0.f;
+    for (int t = tid; t < Ed; t += 512) q += y[t] * y[t];
+    const float ynorm = sqrtf(block_sum(q, red));
+    __syncthreads();
+    for (int t = tid; t < Ed; t += 512) y[t] /= ynorm;     // yhat
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int t = wv; t < T; t += 8) {
+        const float* tr = text + (long)text_idx[(long)p * Tmax + t] * Ed;
+        float s = 0.f;
+        for (int k = lane; k < Ed; k += 64) s += y[k] * tr[k];
+        s = wave_sum(s);
+        if (lane == 0) lg[t] = logit_scale * s;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = 0; t < T; ++t) mx = fmaxf(mx, lg[t]);
+    float den = 0.f;
+    for (int t = 0; t < T; ++t) den += expf(lg[t] - mx);
+    __syncthreads();
+    if (tid < T) {
+        const float pr = expf(lg[tid] - mx) / den;
+        probs[(long)p * Tmax + tid] = pr;
+        lg[tid] = pr;
+    }
+    __syncthreads();
+    const float pj = lg[cls];
+    // dyhat = s * sum_t dlogit_t that_t,  dlogit_t = pj (delta_jt - p_t)
+    for (int k = tid; k < Ed; k += 512) {
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float dl = pj * ((t == cls ? 1.f : 0.f) - lg[t]);
+            s = fmaf(dl, text[(long)text_idx[(long)p * Tmax + t] * Ed + k], s);
+        }
+        dy[k] = logit_scale * s;
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int k = tid; k < Ed; k += 512) dot += y[k] * dy[k];
+    dot = block_sum(dot, red);
+    __syncthreads();
+    for (int k = tid; k < Ed; k += 512) dy[k] = (dy[k] - y[k] * dot) / ynorm;   // d/dy of y/|y|
+    __syncthreads();
+    for (int e = tid; e < E; e += 512) {
+        const float* pr = proj + (long)e * Ed;
+        float s = 0.f;
+        for (int k = 0; k < Ed; ++k) s = fmaf(pr[k], dy[k], s);
+        df[(long)p * E + e] = s;
+    }
+}
+
+// (c) dx2[p,l,:] = gs * LNpost_bwd(df[p]/(L-1); x2[img,l,:]) for l >= 1, 0 for l = 0.
+//     outputs: fp32 and fp16 hi/lo (GEMM operand).  One wave per row.
+__global__ __launch_bounds__(256) void lnpost_bwd_kernel(const float* __restrict__ df,
+                                                          const float* __restrict__ x2,
+                                                          const float* __restrict__ w, float eps, float gs,
+                                                          const int* __restrict__ pair_img,
+                                                          float* __restrict__ d32, __half* __restrict__ dhi,
+                                                          __half* __restrict__ dlo, int L, int E, long rows) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int p = row / L, l = row % L;
+    const long o = row * E;
+    if (l == 0) {
+        for (int e = lane; e < E; e += 64) {
+            d32[o + e] = 0.f;
+            dhi[o + e] = __float2half(0.f);
+            dlo[o + e] = __float2half(0.f);
+        }
+        return;
+    }
+    const float* xr = x2 + ((long)pair_img[p] * L + l) * E;
+    const float* g0 = df + (long)p * E;
+    const float invn = 1.0f / (L - 1);
+    float s = 0.f;
+    for (int e = lane; e < E; e += 64) s += xr[e];
+    const float mean = wave_sum(s) / E;
+    float q = 0.f;
+    for (int e = lane; e < E; e += 64) { const float d = xr[e] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / E + eps);
+    float sg = 0.f, sgx = 0.f;
+    for (int e = lane; e < E; e += 64) {
+        const float g = g0[e] * invn * w[e];
+        sg += g;
+        sgx += g * (xr[e] - mean) * rstd;
+    }
+    sg = wave_sum(sg) / E;
+    sgx = wave_sum(sgx) / E;
+    for (int e = lane; e < E; e += 64) {
+        const float g = g0[e] * invn * w[e];
+        const float v = gs * rstd * (g - sg - (xr[e] - mean) * rstd * sgx);
+        d32[o + e] = v;
+        const __half h = __float2half(v);
+        dhi[o + e] = h;
+        dlo[o + e] = __float2half(v - __half2float(h));
+    }
+}
+
+// (f) g16[p,l,:] = fp16( (dx2s + LN2_bwd(da2s; x1[img,l,:])) / gs )  -- gradient reaching the fp16
+//     out-projection output, rounded like autograd does for the fp16 tensor (myAtt.py:321).
+__global__ __launch_bounds__(256) void ln2_bwd_add_kernel(const float* __restrict__ da2,
+                                                           const float* __restrict__ dx2,
+                                                           const float* __restrict__ x1,
+                                                           const float* __restrict__ w, float eps,
+                                                           float inv_gs, const int* __restrict__ pair_img,
+                                                           __half* __restrict__ g16, int L, int E, long rows) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int p = row / L, l = row % L;
+    const long o = row * E;
+    const float* xr = x1 + ((long)pair_img[p] * L + l) * E;
+    float s = 0.f;
+    for (int e = lane; e < E; e += 64) s += xr[e];
+    const float mean = wave_sum(s) / E;
+    float q = 0.f;
+    for (int e = lane; e < E; e += 64) { const float d = xr[e] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / E + eps);
+    float sg = 0.f, sgx = 0.f;
+    for (int e = lane; e < E; e += 64) {
+        const float g = da2[o + e] * w[e];
+        sg += g;
+        sgx += g * (xr[e] - mean) * rstd;
+    }
+    sg = wave_sum(sg) / E;
+    sgx = wave_sum(sgx) / E;
+    for (int e = lane; e < E; e += 64) {
+        const float g = da2[o + e] * w[e];
+        const float v = (dx2[o + e] + rstd * (g - sg - (xr[e] - mean) * rstd * sgx)) * inv_gs;
+        g16[o + e] = __float2half(v);
+    }
+}
+
+// (h) delta[p,h,q] = sum_d dO[p,q,h,d] * O[img,q,h,d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const __half* __restrict__ dO,
+                                                          const float* __restrict__ o32,
+                                                          const int* __restrict__ pair_img,
+                                                          float* __restrict__ delta, int L, int H, int DH,
+                                                          long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;   // over (p, q, h)
+    if (i >= total) return;
+    const int h = i % H;
+    const long pq = i / H;
+    const int q = pq % L, p = pq / L;
+    const int E = H * DH;
+    const __half* a = dO + ((long)p * L + q) * E + h * DH;
+    const float* b = o32 + ((long)pair_img[p] * L + q) * E + h * DH;
+    float s = 0.f;
+    for (int d = 0; d < DH; ++d) s = fmaf(__half2float(a[d]), b[d], s);
+    delta[((long)p * H + h) * L + q] = s;
+}
+
+// (i) u[p,h,l] = sum_q dS[q,l];  column 0:  dS0[p,h,q] = dS[q,0], P0[p,h,q] = P[q,0].
+// grid (key tiles of 128, H, P); 4 waves as 2(q) x 2(key), 128-row q tiles streamed through LDS.
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_colsum_kernel(const __half* __restrict__ qkv,
+                                                               const __half* __restrict__ dO,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ delta,
+                                                               const int* __restrict__ pair_img,
+                                                               float* __restrict__ u, float* __restrict__ dS0,
+                                                               float* __restrict__ P0, int L, int H, int E) {
+    constexpr int KS = DH / 16;
+    constexpr int ROW = DH * 2 + 16;
+    constexpr int TB = 128 * ROW;
+    constexpr int CH = DH / 8;
+    constexpr int NC = 128 * CH / 256;
+    constexpr int QBUF = 2 * TB + 1024;   // Q tile | dO tile | lse[128] | delta[128]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // K | V | 2 x QBUF | red[2][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hh = lane >> 5, l31 = lane & 31, wr = wave >> 1, wc = wave & 1;
+    const int k0 = blockIdx.x * 128, h = blockIdx.y, p = blockIdx.z, img = pair_img[p];
+    const long ldq = 3L * E;
+    const __half* qb = qkv + (long)img * L * ldq + (long)h * DH;
+    const __half* dob = dO + (long)p * L * E + (long)h * DH;
+    const float* lseb = lse + ((long)img * H + h) * L;
+    const float* delb = delta + ((long)p * H + h) * L;
+    char* Ks = smem;
+    char* Vs = smem + TB;
+    char* Qs = smem + 2 * TB;
+    float* red = reinterpret_cast<float*>(smem + 2 * TB + 2 * QBUF);
+
+    // K, V tiles of this key block (rows clamped; padded keys are masked by zero dS below)
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = tid + 256 * i;
+        int kr = k0 + c / CH;
+        if (kr > L - 1) kr = L - 1;
+        *reinterpret_cast<uint4*>(Ks + (c / CH) * ROW + (c % CH) * 16) =
+            *reinterpret_cast<const uint4*>(qb + (long)kr * ldq + E + (c % CH) * 8);
+        *reinterpret_cast<uint4*>(Vs + (c / CH) * ROW + (c % CH) * 16) =
+            *reinterpret_cast<const uint4*>(qb + (long)kr * ldq + 2 * E + (c % CH) * 8);
+    }
+    uint4 rq[NC], rd[NC];
+    float rl = 0.f, rdl = 0.f;
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = tid + 256 * i;
+            int qr = t * 128 + c / CH;
+            if (qr > L - 1) qr = L - 1;
+            rq[i] = *reinterpret_cast<const uint4*>(qb + (long)qr * ldq + (c % CH) * 8);
+            rd[i] = *reinterpret_cast<const uint4*>(dob + (long)qr * E + (c % CH) * 8);
+        }
+        if (tid < 128) {
+            const int qr = t * 128 + tid;
+            rl = qr < L ? lseb[qr] : 1.0e30f;    // rows past L: P = exp2(S - 1e30) = 0
+            rdl = qr < L ? delb[qr] : 0.f;
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* base = Qs + buf * QBUF;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = tid + 256 * i;
+            *reinterpret_cast<uint4*>(base + (c / CH) * ROW + (c % CH) * 16) = rq[i];
+            *reinterpret_cast<uint4*>(base + TB + (c / CH) * ROW + (c % CH) * 16) = rd[i];
+        }
+        if (tid < 128) {
+            reinterpret_cast<float*>(base + 2 * TB)[tid] = rl;
+            reinterpret_cast<float*>(base + 2 * TB + 512)[tid] = rdl;
+        }
+    };
+    float usum[2] = {0.f, 0.f};
+    const int nt = (L + 127) / 128;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const bool col0 = (blockIdx.x == 0 && wc == 0 && l31 == 0);
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) gload(t + 1);
+        const char* base = Qs + buf * QBUF;
+        const float* ls = reinterpret_cast<const float*>(base + 2 * TB);
+        const float* dl = reinterpret_cast<const float*>(base + 2 * TB + 512);
+        f32x16 s[2][2], dp[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                s[mi][0][r] = s[mi][1][r] = -ls[rr];
+                dp[mi][0][r] = dp[mi][1][r] = -dl[rr];
+            }
+        const char* Aq = base + (wr * 64 + l31) * ROW + hh * 16;
+        const char* Ad = base + TB + (wr * 64 + l31) * ROW + hh * 16;
+        const char* Bk = Ks + (wc * 64 + l31) * ROW + hh * 16;
+        const char* Bv = Vs + (wc * 64 + l31) * ROW + hh * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 q0 = *reinterpret_cast<const f16x8*>(Aq + ks * 32);
+            const f16x8 q1 = *reinterpret_cast<const f16x8*>(Aq + 32 * ROW + ks * 32);
+            const f16x8 kk0 = *reinterpret_cast<const f16x8*>(Bk + ks * 32);
+            const f16x8 kk1 = *reinterpret_cast<const f16x8*>(Bk + 32 * ROW + ks * 32);
+            s[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q0, kk0, s[0][0], 0, 0, 0);
+            s[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q0, kk1, s[0][1], 0, 0, 0);
+            s[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1, kk0, s[1][0], 0, 0, 0);
+            s[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1, kk1, s[1][1], 0, 0, 0);
+            const f16x8 d0 = *reinterpret_cast<const f16x8*>(Ad + ks * 32);
+            const f16x8 d1 = *reinterpret_cast<const f16x8*>(Ad + 32 * ROW + ks * 32);
+            const f16x8 v0 = *reinterpret_cast<const f16x8*>(Bv + ks * 32);
+            const f16x8 v1 = *reinterpret_cast<const f16x8*>(Bv + 32 * ROW + ks * 32);
+            dp[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d0, v0, dp[0][0], 0, 0, 0);
+            dp[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d0, v1, dp[0][1], 0, 0, 0);
+            dp[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d1, v0, dp[1][0], 0, 0, 0);
+            dp[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d1, v1, dp[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pr = __builtin_amdgcn_exp2f(s[mi][ni][r]);
+                    const float ds = pr * dp[mi][ni][r];
+                    usum[ni] += ds;
+                    if (ni == 0 && col0) {
+                        const int q = t * 128 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        if (q < L) {
+                            dS0[((long)p * H + h) * L + q] = ds;
+                            P0[((long)p * H + h) * L + q] = pr;
+                        }
+                    }
+                }
+        if (t + 1 < nt) lstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        usum[ni] += __shfl_xor(usum[ni], 32, 64);
+        if (hh == 0) red[wr * 128 + wc * 64 + ni * 32 + l31] = usum[ni];
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int key = k0 + tid;
+        if (key < L) u[((long)p * H + h) * L + key] = red[tid] + red[128 + tid];
+    }
+}
+
+// (j) column sums of dq, dk, dv for one (pair, head): c[p, {0,E,2E} + h*DH + d]
+__global__ __launch_bounds__(256) void qkv_colsum_kernel(const __half* __restrict__ qkv,
+                                                          const __half* __restrict__ dO,
+                                                          const float* __restrict__ u,
+                                                          const float* __restrict__ dS0,
+                                                          const float* __restrict__ P0,
+                                                          const int* __restrict__ pair_img,
+                                                          float* __restrict__ c, int L, int H, int DH,
+                                                          float inv_sqrt_dh, float inv_qscale) {
+    __shared__ float red[3][4][64];
+    const int h = blockIdx.x, p = blockIdx.y, img = pair_img[p];
+    const int E = H * DH, d = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const __half* qb = qkv + (long)img * L * 3 * E + (long)h * DH;
+    const __half* dob = dO + (long)p * L * E + (long)h * DH;
+    const float* ub = u + ((long)p * H + h) * L;
+    const float* sb = dS0 + ((long)p * H + h) * L;
+    const float* pb = P0 + ((long)p * H + h) * L;
+    float cq = 0.f, ck = 0.f, cv = 0.f;
+    if (d < DH)
+        for (int l = part; l < L; l += 4) {
+            const __half* row = qb + (long)l * 3 * E;
+            cq = fmaf(ub[l], __half2float(row[E + d]), cq);
+            ck = fmaf(sb[l], __half2float(row[d]), ck);
+            cv = fmaf(1.0f - pb[l], __half2float(dob[(long)l * E + d]), cv);
+        }
+    red[0][part][d] = cq;
+    red[1][part][d] = ck;
+    red[2][part][d] = cv;
+    __syncthreads();
+    if (threadIdx.x < 64 && d < DH) {
+        float* out = c + (long)p * 3 * E + h * DH + d;
+        out[0] = (red[0][0][d] + red[0][1][d] + red[0][2][d] + red[0][3][d]) * inv_sqrt_dh;
+        out[E] = -(red[1][0][d] + red[1][1][d] + red[1][2][d] + red[1][3][d]) * inv_qscale;
+        out[2 * E] = red[2][0][d] + red[2][1][d] + red[2][2][d] + red[2][3][d];
+    }
+}
+
+// (l) cam[p, l] = norm(norm(relu(sum_c w[p,c] A[img, l+1, c]))), norm(z) = (z - min z)/(1e-7 + max(z - min z))
+//     base_cam.py:56-60,144-154 + utils/image.py:51-61.  One 1024-thread block per pair.
+__global__ __launch_bounds__(1024) void cam_map_kernel(const float* __restrict__ a32,
+                                                        const float* __restrict__ w,
+                                                        const int* __restrict__ pair_img,
+                                                        float* __restrict__ cam, int L, int E) {
+    extern __shared__ float sm[];   // w[E] | cam[L-1] | red[16]
+    float* ws = sm;
+    float* cs = sm + E;
+    float* red = cs + (L - 1);
+    const int p = blockIdx.x, img = pair_img[p], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int hw = L - 1;
+    for (int e = tid; e < E; e += 1024) ws[e] = w[(long)p * E + e];
+    __syncthreads();
+    for (int l = wv; l < hw; l += 16) {
+        const float* ar = a32 + ((long)img * L + l + 1) * E;
+        float s = 0.f;
+        for (int e = lane; e < E; e += 64) s = fmaf(ws[e], ar[e], s);
+        s = wave_sum(s);
+        if (lane == 0) cs[l] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        float mn = INFINITY;
+        for (int l = tid; l < hw; l += 1024) mn = fminf(mn, cs[l]);
+        mn = block_min(mn, red);
+        float mx = -INFINITY;
+        for (int l = tid; l < hw; l += 1024) mx = fmaxf(mx, cs[l] - mn);
+        mx = block_max(mx, red);
+        __syncthreads();
+        for (int l = tid; l < hw; l += 1024) cs[l] = fmaxf((cs[l] - mn) / (1e-7f + mx), 0.f);
+        __syncthreads();
+    }
+    for (int l = tid; l < hw; l += 1024) cam[(long)p * hw + l] = cs[l];
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int wc_cam_head(const float* x2, const float* lnw, const float* lnb, const float* proj,
+                           const float* text, const int* text_idx, const int* n_text, const int* pair_img,
+                           const int* pair_cls, float logit_scale, float* partial, float* probs, float* df,
+                           int B, int P, int L, int E, int Ed, int Tmax, void* stream) {
+    WC_CHECK_ARG(x2 && lnw && lnb && proj && text && text_idx && n_text && pair_img && pair_cls && partial &&
+                     probs && df && B > 0 && P > 0 && L > 1 && E > 0 && Ed > 0,
+                 "wc_cam_head: bad argument");
+    WC_CHECK_ARG(Tmax > 0 && Tmax <= 512 && E <= 4096 && Ed <= 4096, "wc_cam_head: Tmax <= 512, E, Ed <= 4096");
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = wc_cdiv(L, 64);
+    hipLaunchKernelGGL(lnpost_pool_kernel, dim3(nchunk, B), dim3(256), 4 * E * sizeof(float), st, x2, lnw, lnb,
+                       1e-5f, partial, L, E, nchunk);
+    WC_LAUNCH_CHECK("lnpost_pool_kernel");
+    const size_t sm = (E + 2 * Ed + Tmax + 16) * sizeof(float);
+    hipLaunchKernelGGL(cam_head_kernel, dim3(P), dim3(512), sm, st, partial, proj, text, text_idx, n_text,
+                       pair_img, pair_cls, logit_scale, probs, df, L, E, Ed, nchunk, Tmax);
+    WC_LAUNCH_CHECK("cam_head_kernel");
+    return WC_OK;
+}
+
+extern "C" int wc_lnpost_bwd(const float* df, const float* x2, const float* lnw, float gs,
+                             const int* pair_img, float* d32, void* dhi, void* dlo, int P, int L, int E,
+                             void* stream) {
+    WC_CHECK_ARG(df && x2 && lnw && pair_img && d32 && dhi && dlo && P > 0 && L > 1 && E > 0,
+                 "wc_lnpost_bwd: bad argument");
+    const long rows = (long)P * L;
+    hipLaunchKernelGGL(lnpost_bwd_kernel, dim3(wc_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, df, x2,
+                       lnw, 1e-5f, gs, pair_img, d32, (__half*)dhi, (__half*)dlo, L, E, rows);
+    WC_LAUNCH_CHECK("lnpost_bwd_kernel");
+    return WC_OK;
+}
+
+extern "C" int wc_ln2_bwd_add(const float* da2, const float* dx2, const float* x1, const float* lnw, float gs,
+                              const int* pair_img, void* g16, int P, int L, int E, void* stream) {
+    WC_CHECK_ARG(da2 && dx2 && x1 && lnw && pair_img && g16 && P > 0 && L > 0 && E > 0 && gs > 0,
+                 "wc_ln2_bwd_add: bad argument");
+    const long rows = (long)P * L;
+    hipLaunchKernelGGL(ln2_bwd_add_kernel, dim3(wc_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, da2,
+                       dx2, x1, lnw, 1e-5f, 1.0f / gs, pair_img, (__half*)g16, L, E, rows);
+    WC_LAUNCH_CHECK("ln2_bwd_add_kernel");
+    return WC_OK;
+}
+
+extern "C" int wc_attn_bwd_colsum(const void* qkv, const void* dO, const float* o32, const float* lse,
+                                  const int* pair_img, float* delta, float* u, float* dS0, float* P0,
+                                  float* c, int P, int L, int H, int DH, void* stream) {
+    WC_CHECK_ARG(qkv && dO && o32 && lse && pair_img && delta && u && dS0 && P0 && c && P > 0 && L > 0 && H > 0,
+                 "wc_attn_bwd_colsum: bad argument");
+    WC_CHECK_ARG(DH == 64 || DH == 32, "wc_attn_bwd_colsum: head dim must be 32 or 64");
+    WC_CHECK_ARG(P <= 65535 && H <= 65535, "wc_attn_bwd_colsum: too many pairs/heads for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    const int E = H * DH;
+    const long total = (long)P * L * H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(wc_cdiv(total, 256)), dim3(256), 0, st, (const __half*)dO, o32,
+                       pair_img, delta, L, H, DH, total);
+    WC_LAUNCH_CHECK("attn_delta_kernel");
+    dim3 grid(wc_cdiv(L, 128), H, P);
+    if (DH == 64) {
+        const size_t lds = 2 * 128 * (64 * 2 + 16) + 2 * (2 * 128 * (64 * 2 + 16) + 1024) + 1024;
+        hipLaunchKernelGGL(attn_bwd_colsum_kernel<64>, grid, dim3(256), lds, st, (const __half*)qkv,
+                           (const __half*)dO, lse, delta, pair_img, u, dS0, P0, L, H, E);
+    } else {
+        const size_t lds = 2 * 128 * (32 * 2 + 16) + 2 * (2 * 128 * (32 * 2 + 16) + 1024) + 1024;
+        hipLaunchKernelGGL(attn_bwd_colsum_kernel<32>, grid, dim3(256), lds, st, (const __half*)qkv,
+                           (const __half*)dO, lse, delta, pair_img, u, dS0, P0, L, H, E);
+    }
+    WC_LAUNCH_CHECK("attn_bwd_colsum_kernel");
+    hipLaunchKernelGGL(qkv_colsum_kernel, dim3(H, P), dim3(256), 0, st, (const __half*)qkv, (const __half*)dO, u,
+                       dS0, P0, pair_img, c, L, H, DH, 1.0f / sqrtf((float)DH),
+                       1.0f / 1.4426950408889634f);
+    WC_LAUNCH_CHECK("qkv_colsum_kernel");
+    return WC_OK;
+}
+
+// out[p, e] = scale * sum_n c[p, n] * W[n, e]   (plain fp32 FMA: P is tiny, values span ~1e-9..1e-3)
+__global__ __launch_bounds__(256) void rowvec_matmul_kernel(const float* __restrict__ c,
+                                                             const float* __restrict__ W, float* __restrict__ out,
+                                                             int N, int E, float scale) {
+    const int e = blockIdx.x * 256 + threadIdx.x, p = blockIdx.y;
+    if (e >= E) return;
+    const float* cr = c + (long)p * N;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s = fmaf(cr[n], W[(long)n * E + e], s);
+    out[(long)p * E + e] = s * scale;
+}
+
+extern "C" int wc_rowvec_matmul(const float* c, const float* W, float* out, int P, int N, int E, float scale,
+                                void* stream) {
+    WC_CHECK_ARG(c && W && out && P > 0 && N > 0 && E > 0 && P <= 65535, "wc_rowvec_matmul: bad argument");
+    hipLaunchKernelGGL(rowvec_matmul_kernel, dim3(wc_cdiv(E, 256), P), dim3(256), 0, (hipStream_t)stream, c, W,
+                       out, N, E, scale);
+    WC_LAUNCH_CHECK("rowvec_matmul_kernel");
+    return WC_OK;
+}
+
+extern "C" int wc_cam_map(const float* a32, const float* w, const int* pair_img, float* cam, int P, int L,
+                          int E, void* stream) {
+    WC_CHECK_ARG(a32 && w && pair_img && cam && P > 0 && L > 1 && E > 0, "wc_cam_map: bad argument");
+    const size_t sm = (E + (L - 1) + 16) * sizeof(float);
+    WC_CHECK_ARG(sm <= 160 * 1024, "wc_cam_map: token grid too large for LDS");
+    hipLaunchKernelGGL(cam_map_kernel, dim3(P), dim3(1024), sm, (hipStream_t)stream, a32, w, pair_img, cam, L, E);
+    WC_LAUNCH_CHECK("cam_map_kernel");
+    return WC_OK;
+}

@@ -33,7 +33,8 @@ def split_f16(x, with_lo=False):
 
 def gemm(a, w, M, N, K, *, lda=None, ldw=None, bias=None, resid=None, ldr=None, sR=None,
          out32=None, out16=None, out16lo=None, ldc=None, act=0, round16=False, scale=1.0,
-         scale_cols=0, batch=1, sA=0, sW=0, sC=0):
+         scale_cols=0, batch=1, sA=0, sW=0, sC=0, pre32=None, aux=None, rowmap=None, rpg=0,
+         ldaux=0):
     """C = epilogue(A W^T).  `a`, `w`: Split (or fp16 tensors).  Segments accumulated:
     (a.hi,w.hi) [+ (a.lo,w.hi)] [+ (a.hi,w.lo)]."""
     a = a if isinstance(a, Split) else Split(a)
@@ -54,7 +55,8 @@ def gemm(a, w, M, N, K, *, lda=None, ldw=None, bias=None, resid=None, ldr=None, 
                         batch, sA, sW, sC, L.ptr(bias, F32, "bias"), L.ptr(resid, F32, "resid"),
                         ldr, sR, L.ptr(out32, F32, "out32"), L.ptr(out16, F16, "out16"),
                         L.ptr(out16lo, F16, "out16lo"), ldc, act, 1 if round16 else 0,
-                        float(scale), scale_cols, L.stream())
+                        float(scale), scale_cols, L.ptr(pre32, F32, "pre32"), L.ptr(aux, F32, "aux"),
+                        L.ptr(rowmap, torch.int32, "rowmap"), rpg, ldaux, L.stream())
 
 
 def layernorm(x, weight, bias, *, eps=1e-5, want32=False, want16=True, with_lo=False, rows=None,
@@ -73,7 +75,7 @@ def layernorm(x, weight, bias, *, eps=1e-5, want32=False, want16=True, with_lo=F
     return y32, (Split(hi, lo) if want16 else None)
 
 
-def attention(qkv16, B, Lq, H, DH, want_mean=True):
+def attention(qkv16, B, Lq, H, DH, want_mean=True, want_o32=False):
     """qkv16 (B*L, 3E) fp16 with q pre-scaled by log2(e)/sqrt(DH).
     Returns (o16 (B*L, E) fp16, lse (B,H,L) f32, mean (B,L,L) f32 or None)."""
     E = H * DH
@@ -84,11 +86,15 @@ def attention(qkv16, B, Lq, H, DH, want_mean=True):
     lib.wc_attn_vt(L.ptr(qkv16, F16, "qkv"), L.ptr(vt), B, Lq, Lp, H, DH, L.stream())
     o16 = torch.empty(B * Lq, E, device=dev, dtype=F16)
     lse = torch.empty(B, H, Lq, device=dev, dtype=F32)
-    lib.wc_attn_fwd(L.ptr(qkv16), L.ptr(vt), L.ptr(o16), L.ptr(lse), B, Lq, Lp, H, DH, L.stream())
+    o32 = torch.empty(B * Lq, E, device=dev, dtype=F32) if want_o32 else None
+    lib.wc_attn_fwd(L.ptr(qkv16), L.ptr(vt), L.ptr(o16), L.ptr(o32), L.ptr(lse), B, Lq, Lp, H, DH,
+                    L.stream())
     mean = None
     if want_mean:
         mean = torch.empty(B, Lq, Lq, device=dev, dtype=F32)
         lib.wc_attn_mean(L.ptr(qkv16), L.ptr(lse), L.ptr(mean), B, Lq, H, DH, L.stream())
+    if want_o32:
+        return o16, lse, mean, o32
     return o16, lse, mean
 
 
