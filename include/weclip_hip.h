@@ -145,6 +145,37 @@ int wc_rowvec_matmul(const float* c, const float* W, float* out, int P, int N, i
 int wc_cam_map(const float* a32, const float* w, const int* pair_img, float* cam, int P, int L, int E,
                void* stream);
 
+/* ---- attention-affinity CAM refinement -------------------------------------------------- */
+/* clip/clip_tool.py:152-191, compute_trans_mat :64-80, clip/utils.py:115-142 (scoremap2bbox),
+ * generate_cam_label :202-216, WeCLIP_model/model_attn_aff_voc.py:158-163.  hw = L-1 patch tokens.
+ * wc_aff_weight:      W (B,hw,hw) = sum_l wgt[b,l] * maps[l][b,1:,1:] (* seg[b] if seg != NULL);
+ *                     h_maps: HOST array of nmaps (<=12) device pointers to (B,L,L) head-mean maps.
+ * wc_aff_seg_weights: seg-trans layer selection (:158-167): diff (B,nmaps) workspace,
+ *                     wgt[b,l] = [diff <= mean diff] / (count + 1e-5).
+ * wc_matvec:          out (B,hw,K) = f(W x) (transpose=0) or f(W^T x) (transpose=1),
+ *                     x = X * sin[:,None]; f = 1/v if recip else alpha*v*sout[:,None] + add.
+ *                     Sinkhorn (:64-75) as scale vectors: c = 1/(W^T r), r = 1/(W c), 3 rounds;
+ *                     T_sym x = (r*(W(c*x)) + c*(W^T(r*x)))/2; refined = T_sym(T_sym(mask*cam)).
+ * wc_tsym:            materialise T_sym (B,hw,hw) (public compute_trans_mat only).
+ * wc_box_mask:        per pair p (cam (P,h*w) in [0,1]): u8 quantise, > int(thr*max), 8-connected
+ *                     components, boxes [x0,y0,min(x1+1,w-1),min(y1+1,h-1)], half-open fill;
+ *                     V[pair_img[p], :, pair_slot[p]] = mask*cam (V is (B,hw,K));
+ *                     optional mask_out (P,hw) f32, boxes (P,maxbox,4) i32 + nbox (P).
+ * wc_cam_upsample:    R (B,hw,K) refined maps -> cams (B,C,H,W): channel 1+k = bilinear(half-pixel)
+ *                     of min-max(R_k) for k < nk[b] (0 beyond), channel 0 = 1 - max_k.
+ *                     stats: workspace B*K*2 f32. */
+int wc_aff_weight(const float* const* h_maps, int nmaps, const float* wgt, const float* seg, float* W,
+                  int B, int L, void* stream);
+int wc_aff_seg_weights(const float* const* h_maps, int nmaps, const float* seg, float* diff, float* wgt,
+                       int B, int L, void* stream);
+int wc_matvec(const float* W, const float* X, const float* sin, const float* sout, const float* add,
+              float* out, int B, int hw, int K, int transpose, int recip, float alpha, void* stream);
+int wc_tsym(const float* W, const float* r, const float* c, float* T, int B, int hw, void* stream);
+int wc_box_mask(const float* cam, const int* pair_img, const int* pair_slot, float* V, float* mask_out,
+                int* boxes, int* nbox, int maxbox, int P, int h, int w, int K, double thr, void* stream);
+int wc_cam_upsample(const float* R, const int* nk, float* stats, float* cams, int B, int h, int w, int K,
+                    int C, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

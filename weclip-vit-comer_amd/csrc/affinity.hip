@@ -1,0 +1,366 @@
+// Attention-affinity CAM refinement for gfx950 (HBM/L2-bound, fp32).
+//
+// Replaces reference clip/clip_tool.py:152-191 + compute_trans_mat :64-80 + clip/utils.py:115-142
+// (scoremap2bbox, cv2 on the CPU) + generate_cam_label :202-216 and the bg/concat glue of
+// WeCLIP_model/model_attn_aff_voc.py:158-163:
+//   aff_weight_kernel : W = mean of the selected head-mean maps [1:,1:] (optionally the seg-trans
+//                       masked mean times the predicted affinity)           -> (B, hw, hw)
+//   Sinkhorn as scale vectors: 3 x (column-normalise, row-normalise) of W only rescales rows and
+//                       columns, so T = diag(r) W diag(c) with c = 1/(W^T r), r = 1/(W c); T is never
+//                       written.  matvec_cols / matvec_rows are the two passes over W.
+//   refinement        : (T_sym^2 * mask) @ cam = T_sym (T_sym (mask * cam)),
+//                       T_sym x = (r*(W(c*x)) + c*(W^T(r*x)))/2 : four mat-vec passes, all classes of
+//                       an image at once (the reference materialises T_sym, T_sym^2 and T*mask).
+//   box_mask_kernel   : u8 quantise, threshold, 8-connected components, bounding boxes, half-open
+//                       box fill -- on the device, one workgroup per (image, class) pair.
+//   cam_upsample_kernel: per-map min-max, bilinear (half-pixel) resize to H x W, bg = 1 - max_k.
+#include "common.h"
+
+#define MAXK 4   // classes per pass in the mat-vec kernels
+
+struct MapPtrs {
+    const float* p[12];
+};
+
+// W[b,i,j] = sum_l wgt[b,l] * maps[l][b, i+1, j+1]  (* seg[b,i,j] if seg)
+__global__ __launch_bounds__(256) void aff_weight_kernel(MapPtrs maps, int nmaps, const float* __restrict__ wgt,
+                                                          const float* __restrict__ seg, float* __restrict__ W,
+                                                          int L) {
+    const int hw = L - 1;
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
+    if (j >= hw) return;
+    const long src = (long)b * L * L + (long)(i + 1) * L + (j + 1);
+    float s = 0.f;
+    for (int l = 0; l < nmaps; ++l) s = fmaf(wgt[b * nmaps + l], maps.p[l][src], s);
+    const long dst = ((long)b * hw + i) * hw + j;
+    if (seg) s *= seg[dst];
+    W[dst] = s;
+}
+
+// diff[b,l] = sum_ij (seg[b,i,j] - maps[l][b,i+1,j+1])   (clip_tool.py:158-159)
+__global__ __launch_bounds__(256) void aff_diff_kernel(MapPtrs maps, int nmaps, const float* __restrict__ seg,
+                                                        float* __restrict__ diff, int L) {
+    __shared__ float red[16];
+    const int hw = L - 1, i = blockIdx.x, l = blockIdx.y, b = blockIdx.z;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < hw; j += 256)
+        s += seg[((long)b * hw + i) * hw + j] - maps.p[l][(long)b * L * L + (long)(i + 1) * L + (j + 1)];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(&diff[b * nmaps + l], s);
+}
+
+// wgt[b,l] = keep / (nkeep + 1e-5), keep = diff[b,l] <= mean_l diff[b,:]   (clip_tool.py:160-167)
+__global__ void aff_keep_kernel(const float* __restrict__ diff, float* __restrict__ wgt, int nmaps) {
+    const int b = blockIdx.x;
+    float m = 0.f;
+    for (int l = 0; l < nmaps; ++l) m += diff[b * nmaps + l];
+    m /= nmaps;
+    float n = 0.f;
+    for (int l = 0; l < nmaps; ++l) n += (diff[b * nmaps + l] <= m) ? 1.f : 0.f;
+    for (int l = 0; l < nmaps; ++l) wgt[b * nmaps + l] = ((diff[b * nmaps + l] <= m) ? 1.f : 0.f) / (n + 1e-5f);
+}
+
+// out[b,j,k] = f( sum_i W[b,i,j] * X[b,i,k] * (sin ? sin[b,i] : 1) )      (W^T x)
+// f(v) = recip ? 1/v : alpha * v * (sout ? sout[b,j] : 1) + (add ? add[b,j,k] : 0)
+// block = 64 columns x 4 row-slices; X/out are (B, hw, K) with K <= MAXK per launch slice.
+__global__ __launch_bounds__(256) void matvec_cols_kernel(const float* __restrict__ W, const float* __restrict__ X,
+                                                           const float* __restrict__ sin, const float* __restrict__ sout,
+                                                           const float* __restrict__ add, float* __restrict__ out,
+                                                           int hw, int K, int k0, int recip, float alpha) {
+    __shared__ float red[4][64][MAXK];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane, b = blockIdx.y;
+    const int kn = (K - k0 < MAXK) ? K - k0 : MAXK;
+    float acc[MAXK] = {0.f, 0.f, 0.f, 0.f};
+    if (j < hw) {
+        const float* Wb = W + (long)b * hw * hw + j;
+        for (int i = wv; i < hw; i += 4) {
+            const float wv_ = Wb[(long)i * hw] * (sin ? sin[(long)b * hw + i] : 1.f);
+            const float* xr = X + ((long)b * hw + i) * K + k0;
+#pragma unroll
+            for (int k = 0; k < MAXK; ++k)
+                if (k < kn) acc[k] = fmaf(wv_, xr[k], acc[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) red[wv][lane][k] = acc[k];
+    __syncthreads();
+    if (wv == 0 && j < hw) {
+        for (int k = 0; k < kn; ++k) {
+            float v = red[0][lane][k] + red[1][lane][k] + red[2][lane][k] + red[3][lane][k];
+            const long o = ((long)b * hw + j) * K + k0 + k;
+            if (recip) v = 1.0f / v;
+            else {
+                v *= alpha * (sout ? sout[(long)b * hw + j] : 1.f);
+                if (add) v += add[o];
+            }
+            out[o] = v;
+        }
+    }
+}
+
+// out[b,i,k] = f( sum_j W[b,i,j] * X[b,j,k] * (sin ? sin[b,j] : 1) )      (W x), one wave per row
+__global__ __launch_bounds__(256) void matvec_rows_kernel(const float* __restrict__ W, const float* __restrict__ X,
+                                                           const float* __restrict__ sin, const float* __restrict__ sout,
+                                                           const float* __restrict__ add, float* __restrict__ out,
+                                                           int hw, int K, int k0, int recip, float alpha) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (i >= hw) return;
+    const int kn = (K - k0 < MAXK) ? K - k0 : MAXK;
+    float acc[MAXK] = {0.f, 0.f, 0.f, 0.f};
+    const float* Wr = W + ((long)b * hw + i) * hw;
+    for (int j = lane; j < hw; j += 64) {
+        const float wv_ = Wr[j] * (sin ? sin[(long)b * hw + j] : 1.f);
+        const float* xr = X + ((long)b * hw + j) * K + k0;
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+            if (k < kn) acc[k] = fmaf(wv_, xr[k], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane == 0)
+        for (int k = 0; k < kn; ++k) {
+            float v = acc[k];
+            const long o = ((long)b * hw + i) * K + k0 + k;
+            if (recip) v = 1.0f / v;
+            else {
+                v *= alpha * (sout ? sout[(long)b * hw + i] : 1.f);
+                if (add) v += add[o];
+            }
+            out[o] = v;
+        }
+}
+
+// T_sym[b,i,j] = (r_i W_ij c_j + c_i W_ji r_j) / 2   (materialised only for the public compute_trans_mat)
+__global__ __launch_bounds__(256) void tsym_kernel(const float* __restrict__ W, const float* __restrict__ r,
+                                                    const float* __restrict__ c, float* __restrict__ T, int hw) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
+    if (j >= hw) return;
+    const float* Wb = W + (long)b * hw * hw;
+    const float* rb = r + (long)b * hw;
+    const float* cb = c + (long)b * hw;
+    T[((long)b * hw + i) * hw + j] = 0.5f * (rb[i] * Wb[(long)i * hw + j] * cb[j] + cb[i] * Wb[(long)j * hw + i] * rb[j]);
+}
+
+// One workgroup per pair: box mask of the CAM and V[img, l, slot] = mask ? cam : 0.
+// clip/utils.py:115-142 (scoremap2bbox) + clip/clip_tool.py:179-190.
+__global__ __launch_bounds__(256) void box_mask_kernel(const float* __restrict__ cam, const int* __restrict__ pair_img,
+                                                        const int* __restrict__ pair_slot, float* __restrict__ V,
+                                                        float* __restrict__ mask_out, int* __restrict__ boxes,
+                                                        int* __restrict__ nbox, int maxbox, int h, int w, int K,
+                                                        double thr) {
+    extern __shared__ int smi[];   // lab[hw] | xmin[hw] | xmax[hw] | ymin[hw] | ymax[hw] | roots[hw] | misc[4]
+    const int hw = h * w, p = blockIdx.x, tid = threadIdx.x;
+    int* lab = smi;
+    int* xmin = lab + hw;
+    int* xmax = xmin + hw;
+    int* ymin = xmax + hw;
+    int* ymax = ymin + hw;
+    int* roots = ymax + hw;
+    int* misc = roots + hw;   // [0] max u8, [1] changed flag, [2] root count
+    const float* cp = cam + (long)p * hw;
+    if (tid == 0) { misc[0] = 0; misc[2] = 0; }
+    __syncthreads();
+    int mx = 0;
+    for (int i = tid; i < hw; i += 256) {
+        const int u = (int)(unsigned char)(cp[i] * 255.0f);
+        mx = u > mx ? u : mx;
+    }
+    atomicMax(&misc[0], mx);
+    __syncthreads();
+    const int theta = (int)(thr * (double)misc[0]);
+    for (int i = tid; i < hw; i += 256) {
+        const int u = (int)(unsigned char)(cp[i] * 255.0f);
+        lab[i] = (u > theta) ? i : -1;
+        xmin[i] = w; xmax[i] = -1; ymin[i] = h; ymax[i] = -1;
+    }
+    __syncthreads();
+    // min-label propagation over 8-neighbourhoods until stable
+    for (int it = 0; it < hw + 2; ++it) {
+        if (tid == 0) misc[1] = 0;
+        __syncthreads();
+        int changed = 0;
+        for (int i = tid; i < hw; i += 256) {
+            int l = lab[i];
+            if (l < 0) continue;
+            const int y = i / w, x = i - y * w;
+            int best = l;
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = y + dy, xx = x + dx;
+                    if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+                    const int nl = lab[yy * w + xx];
+                    if (nl >= 0 && nl < best) best = nl;
+                }
+            if (best < l) { lab[i] = best; changed = 1; }
+        }
+        if (changed) misc[1] = 1;
+        __syncthreads();
+        if (misc[1] == 0) break;
+        __syncthreads();
+    }
+    // labels may still be chains l -> lab[l] -> ... ; resolve to the root (fixed point lab[r] == r)
+    for (int i = tid; i < hw; i += 256) {
+        int l = lab[i];
+        if (l < 0) continue;
+        while (lab[l] != l) l = lab[l];
+        const int y = i / w, x = i - y * w;
+        atomicMin(&xmin[l], x); atomicMax(&xmax[l], x);
+        atomicMin(&ymin[l], y); atomicMax(&ymax[l], y);
+    }
+    __syncthreads();
+    for (int i = tid; i < hw; i += 256)
+        if (lab[i] == i) roots[atomicAdd(&misc[2], 1)] = i;
+    __syncthreads();
+    const int nroot = misc[2];
+    if (boxes) {   // estimated_boxes of scoremap2bbox: [x0, y0, min(x0+w, W-1), min(y0+h, H-1)]
+        if (tid == 0) nbox[p] = nroot;
+        for (int k = tid; k < nroot && k < maxbox; k += 256) {
+            const int r = roots[k];
+            int* bx = boxes + ((long)p * maxbox + k) * 4;
+            bx[0] = xmin[r]; bx[1] = ymin[r];
+            bx[2] = (xmax[r] + 1 < w - 1) ? xmax[r] + 1 : w - 1;
+            bx[3] = (ymax[r] + 1 < h - 1) ? ymax[r] + 1 : h - 1;
+        }
+    }
+    const int img = pair_img[p], slot = pair_slot[p];
+    for (int i = tid; i < hw; i += 256) {
+        const int y = i / w, x = i - y * w;
+        int inside = 0;
+        for (int k = 0; k < nroot && !inside; ++k) {
+            const int r = roots[k];
+            const int x0 = xmin[r], y0 = ymin[r];
+            int x1 = xmax[r] + 1, y1 = ymax[r] + 1;
+            x1 = x1 < w - 1 ? x1 : w - 1;
+            y1 = y1 < h - 1 ? y1 : h - 1;
+            inside = (x >= x0 && x < x1 && y >= y0 && y < y1);
+        }
+        if (mask_out) mask_out[(long)p * hw + i] = inside ? 1.f : 0.f;
+        V[((long)img * hw + i) * K + slot] = inside ? cp[i] : 0.f;
+    }
+}
+
+// stats[b,k] = (min, max(z - min)) of refined map k of image b;  R is (B, hw, K)
+__global__ __launch_bounds__(256) void refined_minmax_kernel(const float* __restrict__ R, float* __restrict__ stats,
+                                                              int hw, int K) {
+    __shared__ float red[16];
+    const int k = blockIdx.x, b = blockIdx.y;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = threadIdx.x; i < hw; i += 256) {
+        const float v = R[((long)b * hw + i) * K + k];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    mn = block_min(mn, red);
+    mx = block_max(mx, red);
+    if (threadIdx.x == 0) {
+        stats[((long)b * K + k) * 2] = mn;
+        stats[((long)b * K + k) * 2 + 1] = mx - mn;
+    }
+}
+
+// cams[b, 1+k, y, x] = bilinear((R_k - min)/(1e-7 + max)), cams[b, 0] = 1 - max_k   (k < nk[b])
+__global__ __launch_bounds__(256) void cam_upsample_kernel(const float* __restrict__ R, const float* __restrict__ stats,
+                                                            const int* __restrict__ nk, float* __restrict__ cams,
+                                                            int h, int w, int K, int C, int H, int W, float sy, float sx) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (x >= W || y >= H) return;
+    float fy = fmaxf(sy * (y + 0.5f) - 0.5f, 0.f), fx = fmaxf(sx * (x + 0.5f) - 0.5f, 0.f);
+    int y0 = (int)fy, x0 = (int)fx;
+    if (y0 > h - 1) y0 = h - 1;
+    if (x0 > w - 1) x0 = w - 1;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const long HW = (long)H * W;
+    const int n = nk[b];
+    float best = -INFINITY;
+    const float* Rb = R + (long)b * h * w * K;
+    for (int k = 0; k < n; ++k) {
+        const float mn = stats[((long)b * K + k) * 2], den = 1e-7f + stats[((long)b * K + k) * 2 + 1];
+        const float v00 = (Rb[((long)y0 * w + x0) * K + k] - mn) / den, v01 = (Rb[((long)y0 * w + x1) * K + k] - mn) / den;
+        const float v10 = (Rb[((long)y1 * w + x0) * K + k] - mn) / den, v11 = (Rb[((long)y1 * w + x1) * K + k] - mn) / den;
+        const float v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+        cams[((long)b * C + 1 + k) * HW + (long)y * W + x] = v;
+        best = fmaxf(best, v);
+    }
+    for (int k = n; k < C - 1; ++k) cams[((long)b * C + 1 + k) * HW + (long)y * W + x] = 0.f;
+    cams[(long)b * C * HW + (long)y * W + x] = 1.0f - best;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int wc_aff_weight(const float* const* h_maps, int nmaps, const float* wgt, const float* seg, float* W,
+                             int B, int L, void* stream) {
+    WC_CHECK_ARG(h_maps && nmaps >= 1 && nmaps <= 12 && wgt && W && B > 0 && L > 1, "wc_aff_weight: bad argument");
+    MapPtrs mp;
+    for (int i = 0; i < 12; ++i) mp.p[i] = i < nmaps ? h_maps[i] : nullptr;
+    const int hw = L - 1;
+    hipLaunchKernelGGL(aff_weight_kernel, dim3(wc_cdiv(hw, 256), hw, B), dim3(256), 0, (hipStream_t)stream, mp, nmaps,
+                       wgt, seg, W, L);
+    WC_LAUNCH_CHECK("aff_weight_kernel");
+    return WC_OK;
+}
+
+extern "C" int wc_aff_seg_weights(const float* const* h_maps, int nmaps, const float* seg, float* diff, float* wgt,
+                                  int B, int L, void* stream) {
+    WC_CHECK_ARG(h_maps && nmaps >= 1 && nmaps <= 12 && seg && diff && wgt && B > 0 && L > 1,
+                 "wc_aff_seg_weights: bad argument");
+    MapPtrs mp;
+    for (int i = 0; i < 12; ++i) mp.p[i] = i < nmaps ? h_maps[i] : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(diff, 0, sizeof(float) * B * nmaps, st);
+    hipLaunchKernelGGL(aff_diff_kernel, dim3(L - 1, nmaps, B), dim3(256), 0, st, mp, nmaps, seg, diff, L);
+    WC_LAUNCH_CHECK("aff_diff_kernel");
+    hipLaunchKernelGGL(aff_keep_kernel, dim3(B), dim3(1), 0, st, diff, wgt, nmaps);
+    WC_LAUNCH_CHECK("aff_keep_kernel");
+    return WC_OK;
+}
+
+extern "C" int wc_matvec(const float* W, const float* X, const float* sin, const float* sout, const float* add,
+                         float* out, int B, int hw, int K, int transpose, int recip, float alpha, void* stream) {
+    WC_CHECK_ARG(W && X && out && B > 0 && hw > 0 && K > 0 && B <= 65535, "wc_matvec: bad argument");
+    WC_CHECK_ARG(out != X && out != sin, "wc_matvec: out must not alias an input vector");
+    hipStream_t st = (hipStream_t)stream;
+    for (int k0 = 0; k0 < K; k0 += MAXK) {
+        if (transpose)
+            hipLaunchKernelGGL(matvec_cols_kernel, dim3(wc_cdiv(hw, 64), B), dim3(256), 0, st, W, X, sin, sout, add,
+                               out, hw, K, k0, recip, alpha);
+        else
+            hipLaunchKernelGGL(matvec_rows_kernel, dim3(wc_cdiv(hw, 4), B), dim3(256), 0, st, W, X, sin, sout, add,
+                               out, hw, K, k0, recip, alpha);
+        WC_LAUNCH_CHECK("matvec kernel");
+    }
+    return WC_OK;
+}
+
+extern "C" int wc_tsym(const float* W, const float* r, const float* c, float* T, int B, int hw, void* stream) {
+    WC_CHECK_ARG(W && r && c && T && B > 0 && hw > 0, "wc_tsym: bad argument");
+    hipLaunchKernelGGL(tsym_kernel, dim3(wc_cdiv(hw, 256), hw, B), dim3(256), 0, (hipStream_t)stream, W, r, c, T, hw);
+    WC_LAUNCH_CHECK("tsym_kernel");
+    return WC_OK;
+}
+
+extern "C" int wc_box_mask(const float* cam, const int* pair_img, const int* pair_slot, float* V, float* mask_out,
+                           int* boxes, int* nbox, int maxbox, int P, int h, int w, int K, double thr, void* stream) {
+    WC_CHECK_ARG(cam && pair_img && pair_slot && V && P > 0 && h > 0 && w > 0 && K > 0, "wc_box_mask: bad argument");
+    WC_CHECK_ARG(!boxes || (nbox && maxbox > 0), "wc_box_mask: boxes needs nbox and maxbox");
+    const size_t sm = ((size_t)6 * h * w + 4) * sizeof(int);
+    WC_CHECK_ARG(sm <= 160 * 1024, "wc_box_mask: CAM grid too large (h*w <= 6800)");
+    hipLaunchKernelGGL(box_mask_kernel, dim3(P), dim3(256), sm, (hipStream_t)stream, cam, pair_img, pair_slot, V,
+                       mask_out, boxes, nbox, maxbox, h, w, K, thr);
+    WC_LAUNCH_CHECK("box_mask_kernel");
+    return WC_OK;
+}
+
+extern "C" int wc_cam_upsample(const float* R, const int* nk, float* stats, float* cams, int B, int h, int w, int K,
+                               int C, int H, int W, void* stream) {
+    WC_CHECK_ARG(R && nk && stats && cams && B > 0 && h > 0 && w > 0 && K > 0 && C >= 2 && C <= K + 1 && H > 0 && W > 0,
+                 "wc_cam_upsample: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(refined_minmax_kernel, dim3(K, B), dim3(256), 0, st, R, stats, h * w, K);
+    WC_LAUNCH_CHECK("refined_minmax_kernel");
+    hipLaunchKernelGGL(cam_upsample_kernel, dim3(wc_cdiv(W, 64), wc_cdiv(H, 4), B), dim3(256), 0, st, R, stats, nk,
+                       cams, h, w, K, C, H, W, (float)h / H, (float)w / W);
+    WC_LAUNCH_CHECK("cam_upsample_kernel");
+    return WC_OK;
+}
