@@ -1,0 +1,142 @@
+"""`WeCLIP` (VOC) with the reference's constructor / forward / state-dict contract
+(WeCLIP_model/model_attn_aff_voc.py:60-175): frozen CLIP ViT encoder -> adapters -> decoder ->
+attn_pred = sigmoid(F^T F) -> per image GradCAM + affinity refinement + PAR -> pseudo labels.
+The per-image Python loop with its numpy/cv2/PIL round trips is replaced by one batched,
+device-resident pipeline (all images x classes at once)."""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import cam_pipeline as CP
+from ..clip import clip_tool as CT
+from ..clip import vit_engine as VE
+from ..clip.clip import load as clip_load
+from ..pytorch_grad_cam import GradCAM
+from .Decoder.TransDecoder import DecoderTransformer
+from .PAR import PAR, refine_labels
+from .segformer_head import SegFormerHead
+
+
+def reshape_transform(tensor, height=28, width=28):
+    """(L, N, D) tokens -> (N, D, h, w) patch grid (reference :23-30); kept for API parity."""
+    t = tensor.permute(1, 0, 2)[:, 1:, :]
+    return t.reshape(t.size(0), height, width, t.size(2)).permute(0, 3, 1, 2)
+
+
+class WeCLIP(nn.Module):
+    cam_threshold = 0.4      # scoremap2bbox threshold (clip_tool.py:179)
+    seg_trans_last = 6       # maps used in the seg-trans branch (clip_tool.py:155)
+    seg_trans_after = 15000  # iteration after which the seg-trans branch is used (:146)
+    val_runs_cam = True      # the VOC model runs the CAM/PAR path in 'val' too (:146-155)
+
+    def __init__(self, num_classes=None, clip_model=None, embedding_dim=256, in_channels=512,
+                 dataset_root_path=None, device="cuda", text_features=None):
+        """`text_features=(bg (n_bg, Ed), fg (n_fg, Ed))`: the zero-shot text rows.  The reference
+        computes them at construction with the CLIP text tower + tokenizer (:34-46,81-82); that
+        init-time step is outside this package, so they are passed in (or assigned later to
+        `bg_text_features` / `fg_text_features`)."""
+        super().__init__()
+        self.num_classes, self.embedding_dim, self.in_channels = num_classes, embedding_dim, in_channels
+        self.encoder, _ = clip_load(clip_model, device=device)
+        for name, p in self.encoder.named_parameters():
+            p.requires_grad = "11" in name                      # reference :68-70
+        self.decoder_fts_fuse = SegFormerHead(in_channels=in_channels, embedding_dim=embedding_dim,
+                                              num_classes=num_classes, index=11)
+        self.decoder = DecoderTransformer(width=embedding_dim, layers=3, heads=8, output_dim=num_classes)
+        self.bg_text_features, self.fg_text_features = (None, None) if text_features is None else text_features
+        self.target_layers = [self.encoder.visual.transformer.resblocks[-1].ln_1]
+        self.grad_cam = GradCAM(model=self.encoder, target_layers=self.target_layers,
+                                reshape_transform=reshape_transform)
+        self.root_path = os.path.join(dataset_root_path, "SegmentationClassAug") if dataset_root_path else None
+        self.cam_bg_thres = 1
+        self.encoder.eval()
+        self.par = PAR(num_iter=20, dilations=[1, 2, 4, 8, 12, 24])
+        self.iter_num = 0
+        self.require_all_fts = True
+        self.to(device)
+
+    def get_param_groups(self):
+        groups = [[], [], [], []]   # backbone; backbone_norm; cls_head; seg_head
+        groups[3].extend(self.decoder.parameters())
+        groups[3].extend(self.decoder_fts_fuse.parameters())
+        return groups
+
+    # ------------------------------------------------------------------------------------------
+    def _labels_for(self, img_names, labels, shape):
+        if labels is not None:
+            return [list(l) for l in labels], [tuple(shape)] * len(labels)
+        if self.root_path is None:
+            raise RuntimeError("pass labels=[[class ids]...] or construct WeCLIP with dataset_root_path")
+        out, sizes = [], []
+        for name in img_names:
+            ids, osz = CT.read_image_labels(os.path.join(self.root_path, str(name) + ".png"))
+            out.append(ids)
+            sizes.append(osz)
+        return out, sizes
+
+    def _maps_needed(self, seg_trans):
+        n = self.seg_trans_last if seg_trans else 8
+        first = 12 - n                      # index into the 12 maps (11 encoder + last block)
+        return [i >= first for i in range(11)]
+
+    def encode(self, img, seg_trans):
+        """Frozen encoder: token rows of blocks 1..11 and the head-mean maps the affinity needs."""
+        vis = self.encoder.visual
+        rows, B, Lq = vis.embed(img)
+        need = self._maps_needed(seg_trans)
+        xs, maps = [], []
+        for i in range(vis.transformer.layers - 1):
+            rows, m = VE.run_block(vis.transformer.resblocks[i].pack(), rows, B, Lq, want_mean=need[i])
+            xs.append(rows)
+            maps.append(m)
+        return xs, maps, B, Lq
+
+    def forward(self, img, img_names="2007_000032", mode="train", labels=None):
+        """-> (seg (B,nc,h,w), cam_labels (B,H,W) int64 [list of per-image maps in 'val' when the
+        original sizes differ], attn_pred (B,hw,hw))."""
+        B, _, H, W = img.shape
+        h, w = H // 16, W // 16
+        self.encoder.eval()
+        self.iter_num += 1
+        seg_trans = self.iter_num > self.seg_trans_after or mode == "val"
+        img = img.cuda().float().contiguous()
+        with torch.no_grad():
+            xs, maps, _, Lq = self.encode(img, seg_trans)
+        fts = self.decoder_fts_fuse.forward_rows(xs, B, Lq, h, w)
+        seg, _ = self.decoder(fts, need_weights=False)
+        f = fts.reshape(B, fts.shape[1], h * w)
+        attn_pred = torch.sigmoid(f.transpose(2, 1).bmm(f))
+        if mode == "val" and not self.val_runs_cam:
+            return seg, None, attn_pred
+        with torch.no_grad():
+            cam_labels = self.cam_labels(img, xs[-1], maps, attn_pred.detach(), img_names, labels, mode,
+                                         seg_trans, h, w)
+        return seg, cam_labels, attn_pred
+
+    def cam_labels(self, img, last_rows, maps, attn_pred, img_names, labels, mode, seg_trans, h, w):
+        if self.bg_text_features is None or self.fg_text_features is None:
+            raise RuntimeError("WeCLIP needs text_features=(bg, fg) (see __init__)")
+        B, _, H, W = img.shape
+        if isinstance(img_names, str):
+            img_names = [img_names]
+        label_lists, sizes = self._labels_for(img_names, labels, (H, W))
+        dev = img.device
+        plan = CT.PairPlan(label_lists, self.fg_text_features.shape[0], self.bg_text_features.shape[0], dev)
+        text_hat = CT.normalised_text(self.fg_text_features, self.bg_text_features, dev)
+        R, _, _, _ = CT.batch_refined_cams(self.encoder, last_rows, maps, attn_pred if seg_trans else None,
+                                           plan, text_hat, h, w, self.cam_threshold, seg_trans,
+                                           self.seg_trans_last)
+        C = plan.K + 1
+        if mode == "train" or all(tuple(s) == (H, W) for s in sizes):
+            cams = CP.upsample_with_bg(R, plan.nk, h, w, H, W, C)          # cam_bg_thres = 1: pow is identity
+            refined = self.par(img, cams)
+            return refine_labels(refined, plan.valid_key, plan.nch)
+        out = []                                                            # 'val': original image sizes
+        for i, (oh, ow) in enumerate(sizes):
+            cams = CP.upsample_with_bg(R[i:i + 1].contiguous(), plan.nk[i:i + 1].contiguous(), h, w, oh, ow, C)
+            refined = self.par(img[i:i + 1], cams)
+            out.append(refine_labels(refined, plan.valid_key[i:i + 1].contiguous(),
+                                     plan.nch[i:i + 1].contiguous())[0])
+        return out

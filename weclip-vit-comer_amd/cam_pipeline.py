@@ -20,19 +20,18 @@ def affinity_weight(maps, seg=None, seg_trans=False, n_last=6):
     """maps: list of head-mean attention maps (B,L,L) f32 in layer order (11 encoder + last block).
     Normal branch (clip_tool.py:169-173): mean of the last 8 [1:,1:].  Seg-trans branch
     (:152-168, n_last 6 VOC / 10 COCO): masked mean of the last n_last times seg (B,hw,hw)."""
-    B, Lq, _ = maps[0].shape
+    sel = maps[-n_last:] if seg_trans else maps[-8:]      # entries outside the selection may be None
+    B, Lq, _ = sel[0].shape
     hw = Lq - 1
-    dev = maps[0].device
-    for m in maps:
+    dev = sel[0].device
+    for m in sel:
         L.ptr(m, F32, "attention map")
     lib = L.lib()
     W = torch.empty(B, hw, hw, device=dev, dtype=F32)
     if not seg_trans:
-        sel = maps[-8:]
         wgt = torch.full((B, len(sel)), 1.0 / len(sel), device=dev, dtype=F32)
         lib.wc_aff_weight(_map_array(sel), len(sel), L.ptr(wgt), None, L.ptr(W), B, Lq, L.stream())
         return W
-    sel = maps[-n_last:]
     seg = seg.detach().float().contiguous()
     diff = torch.empty(B, len(sel), device=dev, dtype=F32)
     wgt = torch.empty(B, len(sel), device=dev, dtype=F32)

@@ -1,0 +1,136 @@
+"""Per-image CAM driver API of reference clip/clip_tool.py, executed by the batched device
+pipeline (gradcam_engine + cam_pipeline): nothing leaves the GPU between GradCAM, the affinity
+refinement and the label map."""
+import numpy as np
+import torch
+
+from .. import cam_pipeline as CP
+from ..gradcam_engine import last_layer_forward
+from . import vit_engine as VE
+
+I32 = torch.int32
+
+
+class ClipOutputTarget:
+    def __init__(self, category):
+        self.category = category
+
+    def __call__(self, model_output):
+        return model_output[self.category] if model_output.dim() == 1 else model_output[:, self.category]
+
+
+def generate_clip_fts(image, model, require_all_fts=True):
+    if image.dim() == 3:
+        image = image.unsqueeze(0)
+    h, w = image.shape[-2:]
+    return model.encode_image(image.cuda(), h, w, require_all_fts=require_all_fts)
+
+
+def compute_trans_mat(attn_weight):
+    """(hw, hw) affinity -> Sinkhorn x3, symmetrise, square (reference clip_tool.py:64-80)."""
+    return CP.trans_mat(attn_weight.detach().float().contiguous()[None].cuda())[0]
+
+
+def read_image_labels(img_path):
+    """Image-level class ids from the GT mask PNG (reference clip_tool.py:111-124): unique pixel
+    values minus one (uint8 arithmetic, so background 0 -> 255), 255/254 dropped.
+    Returns (ids, (orig_h, orig_w))."""
+    from PIL import Image
+    arr = np.asarray(Image.open(img_path))
+    ids = (np.unique(arr) - 1).tolist()
+    ids = [int(i) for i in ids if i not in (255, 254)]
+    return ids, arr.shape[:2]
+
+
+class PairPlan:
+    """Flattened (image, class) pairs of a batch and the index tensors the kernels consume."""
+
+    def __init__(self, label_lists, n_fg, n_bg, device):
+        self.label_lists = [list(map(int, l)) for l in label_lists]
+        if any(len(l) == 0 for l in self.label_lists):
+            raise RuntimeError("every image needs at least one foreground class id")
+        self.B = len(self.label_lists)
+        self.K = max(len(l) for l in self.label_lists)
+        self.Tmax = self.K + n_bg
+        pi, pc, ps, ti, nt = [], [], [], [], []
+        for i, ids in enumerate(self.label_lists):
+            rows = ids + [n_fg + r for r in range(n_bg)]
+            for j in range(len(ids)):
+                pi.append(i); pc.append(j); ps.append(j)
+                ti.append(rows + [0] * (self.Tmax - len(rows)))
+                nt.append(len(rows))
+        t = lambda v: torch.tensor(v, dtype=I32, device=device)
+        self.pair_img, self.pair_cls, self.pair_slot = t(pi), t(pc), t(ps)
+        self.text_idx, self.n_text = t(ti).contiguous(), t(nt)
+        self.nk = t([len(l) for l in self.label_lists])
+        self.P = len(pi)
+        vk = torch.zeros(self.B, self.K + 1, dtype=torch.int64)
+        for i, ids in enumerate(self.label_lists):
+            vk[i, 1:1 + len(ids)] = torch.tensor(ids) + 1
+        self.valid_key = vk.to(device)
+        self.nch = t([len(l) + 1 for l in self.label_lists])
+
+
+def normalised_text(fg_text, bg_text, device):
+    t = torch.cat([fg_text.detach().float(), bg_text.detach().float()], 0).to(device)
+    return (t / t.norm(dim=1, keepdim=True)).contiguous()
+
+
+def batch_refined_cams(clip_model, last_rows, maps11, seg_attn, plan, text_hat, h, w, thr,
+                       seg_trans, n_last):
+    """GradCAM for every pair + affinity refinement.  last_rows (B*L, E): block layers-1 output;
+    maps11: list of that many head-mean maps (entries may be None where unused).
+    Returns (R (B, hw, K) refined CAMs, cams (P, hw), probs (P, Tmax), state)."""
+    B, Lq = plan.B, h * w + 1
+    st = last_layer_forward(clip_model, last_rows, B, Lq)
+    cams, probs, _ = st.grad_cam(text_hat, plan.text_idx, plan.n_text, plan.pair_img, plan.pair_cls, plan.Tmax)
+    maps = list(maps11) + [st.mean]
+    need = maps[-n_last:] if seg_trans else maps[-8:]
+    if any(m is None for m in need):
+        raise RuntimeError("attention maps needed by the affinity were not computed")
+    W = CP.affinity_weight(maps, seg_attn, seg_trans, n_last)
+    R = CP.refine(W, cams, plan.pair_img, plan.pair_slot, plan.K, h, w, thr)
+    return R, cams, probs, st
+
+
+def _single(img_path, image, image_features, attn_weight_list, seg_attn, bg_text_features, fg_text_features,
+            cam, mode, require_seg_trans, thr, n_last, labels=None):
+    if labels is None:
+        ids, (oh, ow) = read_image_labels(img_path)
+    else:
+        ids, (oh, ow) = list(labels), image.shape[-2:]
+    H, W = image.shape[-2:]
+    h, w = H // 16, W // 16
+    dev = image_features.device
+    rows, N, Lq = VE.to_rows(image_features)
+    plan = PairPlan([ids], fg_text_features.shape[0], bg_text_features.shape[0], dev)
+    text_hat = normalised_text(fg_text_features, bg_text_features, dev)
+    maps = [m[None].float().contiguous() for m in attn_weight_list]
+    seg = seg_attn.reshape(1, h * w, h * w) if seg_attn is not None else None
+    R, _, _, _ = batch_refined_cams(cam.model, rows, maps, seg, plan, text_hat, h, w, thr, require_seg_trans, n_last)
+    refined = [R[0, :, k].reshape(h, w) for k in range(len(ids))]
+    return (refined, ids, W, H) if mode == "train" else (refined, ids, ow, oh)
+
+
+def perform_single_voc_cam(img_path, image, image_features, attn_weight_list, seg_attn, bg_text_features,
+                           fg_text_features, cam, mode="train", require_seg_trans=False, labels=None):
+    """Reference clip_tool.py:106-197.  `cam` is this package's GradCAM (its .model is used)."""
+    return _single(img_path, image, image_features, attn_weight_list, seg_attn, bg_text_features,
+                   fg_text_features, cam, mode, require_seg_trans, 0.4, 6, labels)
+
+
+def perform_single_coco_cam(img_path, image, image_features, attn_weight_list, seg_attn, bg_text_features,
+                            fg_text_features, cam, mode="train", require_all_fts=True, require_seg_trans=False,
+                            labels=None):
+    """Reference clip_tool.py:221-319 (threshold 0.7, last 10 maps in the seg-trans branch)."""
+    return _single(img_path, image, image_features, attn_weight_list, seg_attn, bg_text_features,
+                   fg_text_features, cam, mode, require_seg_trans, 0.7, 10, labels)
+
+
+def generate_cam_label(cam_refined_list, keys, w, h):
+    """Reference clip_tool.py:202-216: min-max + bilinear to (h, w) of every refined CAM."""
+    R = torch.stack([c.reshape(-1) for c in cam_refined_list], dim=1)[None].float().contiguous().cuda()
+    hh, ww = cam_refined_list[0].shape
+    nk = torch.tensor([len(cam_refined_list)], dtype=I32, device="cuda")
+    cams = CP.upsample_with_bg(R, nk, hh, ww, h, w)
+    return {"keys": np.asarray(keys), "refined_cam": cams[0, 1:]}

@@ -1,0 +1,86 @@
+"""The training step around `WeCLIP.forward` (what reference scripts/dist_clip_voc.py:238-267 does
+per iteration) and its data-parallel form: one process per GPU, image batch sharded over ranks,
+one RCCL all-reduce of the adapter+decoder gradients (5,985,045 fp32 = 23.9 MB in ONE flat bucket;
+the frozen CLIP encoder is replicated and never reduced).  The reference itself is single-GPU
+(SURVEY.md §0-3); this is the DP launcher the build adds beside it.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .utils.camutils import cams_to_affinity_label, get_mask_by_radius
+from .utils.losses import get_aff_loss, get_seg_loss
+from .utils.optimizer import PolyWarmupAdamW
+
+
+def make_optimizer(model, lr=2e-4, weight_decay=0.01, betas=(0.9, 0.999), warmup_iter=50, max_iter=30000,
+                   warmup_ratio=1e-6, power=1.0):
+    """configs/voc_attn_reg.yaml:29-38 + scripts/dist_clip_voc.py:196-234: only group 3 is non-empty
+    and runs at 10x the base lr."""
+    g = model.get_param_groups()
+    groups = [
+        {"params": g[0], "lr": lr, "weight_decay": weight_decay},
+        {"params": g[1], "lr": 0.0, "weight_decay": 0.0},
+        {"params": g[2], "lr": lr * 10, "weight_decay": weight_decay},
+        {"params": g[3], "lr": lr * 10, "weight_decay": weight_decay},
+    ]
+    return PolyWarmupAdamW(groups, lr=lr, weight_decay=weight_decay, betas=list(betas),
+                           warmup_iter=warmup_iter, max_iter=max_iter, warmup_ratio=warmup_ratio, power=power)
+
+
+class GradBucket:
+    """Flat fp32 bucket aliasing every trainable gradient, so the DP exchange is one collective."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, device=self.params[0].device, dtype=torch.float32)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, group=None):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.div_(dist.get_world_size(group))
+
+
+class TrainStep:
+    def __init__(self, model, optimizer=None, radius=8, ignore_index=255, bucket=True):
+        self.model = model
+        self.opt = optimizer or make_optimizer(model)
+        self.radius, self.ignore = radius, ignore_index
+        self._mask = {}
+        self.bucket = GradBucket(model.get_param_groups()[3]) if bucket else None
+
+    def mask(self, h, w, device):
+        key = (h, w, str(device))
+        if key not in self._mask:
+            self._mask[key] = get_mask_by_radius(h, w, self.radius, device=device)
+        return self._mask[key]
+
+    def losses(self, seg, cam, attn_pred):
+        segs = F.interpolate(seg, size=cam.shape[1:], mode="bilinear", align_corners=False)
+        h, w = cam.shape[1] // 16, cam.shape[2] // 16
+        aff_label = cams_to_affinity_label(cam, mask=self.mask(h, w, cam.device), ignore_index=self.ignore)
+        attn_loss, _, _ = get_aff_loss(attn_pred, aff_label)
+        seg_loss = get_seg_loss(segs, cam.long(), ignore_index=self.ignore)
+        return seg_loss + 0.1 * attn_loss, seg_loss, attn_loss
+
+    def __call__(self, img, names=None, labels=None):
+        """forward -> losses -> backward -> (DP: gradient all-reduce) -> AdamW step."""
+        seg, cam, attn_pred = self.model(img, names if names is not None else [""] * img.shape[0], labels=labels)
+        loss, seg_loss, attn_loss = self.losses(seg, cam, attn_pred)
+        if self.bucket is not None:
+            self.bucket.zero()
+        else:
+            self.opt.zero_grad()
+        loss.backward()
+        if self.bucket is not None:
+            self.bucket.all_reduce_mean()
+        self.opt.step()
+        return loss.detach(), seg_loss.detach(), attn_loss.detach()
