@@ -12,6 +12,43 @@ F32 = torch.float32
 LOG2E = 1.4426950408889634
 
 
+class KernelTimer:
+    """Optional HIP-event timing of kernel families on the current stream (bench.py roofline leg).
+    `work` is the algorithmic work (flops or bytes) of the bracketed launch(es)."""
+    enabled = False
+    records = {}
+
+    @classmethod
+    def reset(cls):
+        cls.records = {}
+
+    @classmethod
+    def start(cls):
+        if not cls.enabled:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    @classmethod
+    def stop(cls, name, e0, work, launches=1):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        cls.records.setdefault(name, []).append((e0, e1, work, launches))
+
+    @classmethod
+    def summary(cls):
+        """name -> dict(ms total, launches, work) after a device sync."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in cls.records.items():
+            out[name] = dict(ms=sum(a.elapsed_time(b) for a, b, _, _ in recs),
+                             launches=sum(n for _, _, _, n in recs), work=sum(w for _, _, w, _ in recs))
+        return out
+
+
 class Split:
     """An fp32 tensor represented for the MFMA GEMM as fp16 `hi` (+ optional fp16 `lo` with
     x ~= hi + lo).  `lo is None` means single-pass fp16 precision."""
@@ -51,12 +88,14 @@ def gemm(a, w, M, N, K, *, lda=None, ldw=None, bias=None, resid=None, ldr=None, 
     wp = [L.ptr(s[1], F16, "W") for s in segs] + [None] * (3 - len(segs))
     ldr = ldc if ldr is None else ldr
     sR = sC if sR is None else sR
+    t0 = KernelTimer.start()
     L.lib().wc_gemm_f16(ap[0], ap[1], ap[2], wp[0], wp[1], wp[2], len(segs), M, N, K, lda, ldw,
                         batch, sA, sW, sC, L.ptr(bias, F32, "bias"), L.ptr(resid, F32, "resid"),
                         ldr, sR, L.ptr(out32, F32, "out32"), L.ptr(out16, F16, "out16"),
                         L.ptr(out16lo, F16, "out16lo"), ldc, act, 1 if round16 else 0,
                         float(scale), scale_cols, L.ptr(pre32, F32, "pre32"), L.ptr(aux, F32, "aux"),
                         L.ptr(rowmap, torch.int32, "rowmap"), rpg, ldaux, L.stream())
+    KernelTimer.stop("gemm_f16_kernel", t0, 2.0 * M * N * K * batch)   # algorithmic flops (1 pass)
 
 
 def layernorm(x, weight, bias, *, eps=1e-5, want32=False, want16=True, with_lo=False, rows=None,
@@ -87,12 +126,16 @@ def attention(qkv16, B, Lq, H, DH, want_mean=True, want_o32=False):
     o16 = torch.empty(B * Lq, E, device=dev, dtype=F16)
     lse = torch.empty(B, H, Lq, device=dev, dtype=F32)
     o32 = torch.empty(B * Lq, E, device=dev, dtype=F32) if want_o32 else None
+    t0 = KernelTimer.start()
     lib.wc_attn_fwd(L.ptr(qkv16), L.ptr(vt), L.ptr(o16), L.ptr(o32), L.ptr(lse), B, Lq, Lp, H, DH,
                     L.stream())
+    KernelTimer.stop("attn_fwd_kernel", t0, 4.0 * B * H * Lq * Lq * DH)
     mean = None
     if want_mean:
         mean = torch.empty(B, Lq, Lq, device=dev, dtype=F32)
+        t0 = KernelTimer.start()
         lib.wc_attn_mean(L.ptr(qkv16), L.ptr(lse), L.ptr(mean), B, Lq, H, DH, L.stream())
+        KernelTimer.stop("attn_mean_kernel", t0, 2.0 * B * H * Lq * Lq * DH)
     if want_o32:
         return o16, lse, mean, o32
     return o16, lse, mean
