@@ -81,37 +81,43 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __half* __restrict_
     for (int s = 0; s < KS; ++s)
         qf[s] = *reinterpret_cast<const f16x8*>(base + (long)qr * ldq + 16 * s + 8 * hh);
 
-    uint4 rk[NKC], rv[NVC];
-    auto gload = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < NKC; ++i) {
-            const int c = tid + 256 * i;
-            int key = t * 64 + c / KCH;
-            if (key > L - 1) key = L - 1;
-            rk[i] = *reinterpret_cast<const uint4*>(base + E + (long)key * ldq + (c % KCH) * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < NVC; ++i) {
-            const int c = tid + 256 * i;
-            rv[i] = *reinterpret_cast<const uint4*>(vbase + (long)(c >> 3) * Lp + t * 64 + (c & 7) * 8);
-        }
-    };
-    auto lstore = [&](int buf) {
-        char* kb = smem + buf * (KBUF + VBUF);
-        char* vb = kb + KBUF;
-#pragma unroll
-        for (int i = 0; i < NKC; ++i) {
-            const int c = tid + 256 * i;
-            *reinterpret_cast<uint4*>(kb + (c / KCH) * KROW + (c % KCH) * 16) = rk[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NVC; ++i) {
-            const int c = tid + 256 * i;
-            uint2* p = reinterpret_cast<uint2*>(vb + (c >> 3) * VROW + (c & 7) * 16);
-            p[0] = make_uint2(rv[i].x, rv[i].y);
-            p[1] = make_uint2(rv[i].z, rv[i].w);
-        }
-    };
+    u32x4 rk[NKC], rv[NVC];
+#undef GLOAD
+#define GLOAD(t_) \
+    { \
+        const int t__ = (t_); \
+        _Pragma("unroll") \
+        for (int i = 0; i < NKC; ++i) { \
+            const int c = tid + 256 * i; \
+            int key = t__ * 64 + c / KCH; \
+            if (key > L - 1) key = L - 1; \
+            rk[i] = *reinterpret_cast<const u32x4*>(base + E + (long)key * ldq + (c % KCH) * 8); \
+        } \
+        _Pragma("unroll") \
+        for (int i = 0; i < NVC; ++i) { \
+            const int c = tid + 256 * i; \
+            rv[i] = *reinterpret_cast<const u32x4*>(vbase + (long)(c >> 3) * Lp + t__ * 64 + (c & 7) * 8); \
+        } \
+    }
+#undef LSTORE
+#define LSTORE(buf_) \
+    { \
+        const int buf__ = (buf_); \
+        char* kb = smem + buf__ * (KBUF + VBUF); \
+        char* vb = kb + KBUF; \
+        _Pragma("unroll") \
+        for (int i = 0; i < NKC; ++i) { \
+            const int c = tid + 256 * i; \
+            *reinterpret_cast<u32x4*>(kb + (c / KCH) * KROW + (c % KCH) * 16) = rk[i]; \
+        } \
+        _Pragma("unroll") \
+        for (int i = 0; i < NVC; ++i) { \
+            const int c = tid + 256 * i; \
+            u32x2* p = reinterpret_cast<u32x2*>(vb + (c >> 3) * VROW + (c & 7) * 16); \
+            p[0] = rv[i].xy; \
+            p[1] = rv[i].zw; \
+        } \
+    }
 
     f32x16 o[DT];
 #pragma unroll
@@ -121,12 +127,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __half* __restrict_
     float m = NEG_BIG, lsum = 0.f;
 
     const int nt = (L + 63) / 64;
-    gload(0);
-    lstore(0);
+    GLOAD(0);
+    LSTORE(0);
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nt) gload(t + 1);
+        if (t + 1 < nt) GLOAD(t + 1);
         const char* kb = smem + buf * (KBUF + VBUF);
         const char* vb = kb + KBUF;
         f32x16 s[2];
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __half* __restrict_
                 o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb, o[d], 0, 0, 0);
             }
         }
-        if (t + 1 < nt) lstore(buf ^ 1);
+        if (t + 1 < nt) LSTORE(buf ^ 1);
         __syncthreads();
     }
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
@@ -232,34 +238,40 @@ __global__ __launch_bounds__(256) void attn_mean_kernel(const __half* __restrict
     const long ldq = 3L * E;
     const __half* base = qkv + (long)b * L * ldq;
 
-    uint4 rq[NC], rk[NC];
+    u32x4 rq[NC], rk[NC];
     float rl = 0.f;
-    auto gload = [&](int h) {
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const int c = tid + 256 * i;
-            int qr = q0 + c / CH, kr = k0 + c / CH;
-            if (qr > L - 1) qr = L - 1;
-            if (kr > L - 1) kr = L - 1;
-            rq[i] = *reinterpret_cast<const uint4*>(base + (long)qr * ldq + h * DH + (c % CH) * 8);
-            rk[i] = *reinterpret_cast<const uint4*>(base + (long)kr * ldq + E + h * DH + (c % CH) * 8);
-        }
-        if (tid < 128) {
-            int qr = q0 + tid;
-            if (qr > L - 1) qr = L - 1;
-            rl = lse[((long)b * H + h) * L + qr];
-        }
-    };
-    auto lstore = [&](int buf) {
-        char* qb = smem + buf * BUF;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const int c = tid + 256 * i;
-            *reinterpret_cast<uint4*>(qb + (c / CH) * ROW + (c % CH) * 16) = rq[i];
-            *reinterpret_cast<uint4*>(qb + TB + (c / CH) * ROW + (c % CH) * 16) = rk[i];
-        }
-        if (tid < 128) reinterpret_cast<float*>(qb + 2 * TB)[tid] = rl;
-    };
+#undef GLOAD
+#define GLOAD(h_) \
+    { \
+        const int h__ = (h_); \
+        _Pragma("unroll") \
+        for (int i = 0; i < NC; ++i) { \
+            const int c = tid + 256 * i; \
+            int qr = q0 + c / CH, kr = k0 + c / CH; \
+            if (qr > L - 1) qr = L - 1; \
+            if (kr > L - 1) kr = L - 1; \
+            rq[i] = *reinterpret_cast<const u32x4*>(base + (long)qr * ldq + h__ * DH + (c % CH) * 8); \
+            rk[i] = *reinterpret_cast<const u32x4*>(base + (long)kr * ldq + E + h__ * DH + (c % CH) * 8); \
+        } \
+        if (tid < 128) { \
+            int qr = q0 + tid; \
+            if (qr > L - 1) qr = L - 1; \
+            rl = lse[((long)b * H + h__) * L + qr]; \
+        } \
+    }
+#undef LSTORE
+#define LSTORE(buf_) \
+    { \
+        const int buf__ = (buf_); \
+        char* qb = smem + buf__ * BUF; \
+        _Pragma("unroll") \
+        for (int i = 0; i < NC; ++i) { \
+            const int c = tid + 256 * i; \
+            *reinterpret_cast<u32x4*>(qb + (c / CH) * ROW + (c % CH) * 16) = rq[i]; \
+            *reinterpret_cast<u32x4*>(qb + TB + (c / CH) * ROW + (c % CH) * 16) = rk[i]; \
+        } \
+        if (tid < 128) reinterpret_cast<float*>(qb + 2 * TB)[tid] = rl; \
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -269,12 +281,12 @@ __global__ __launch_bounds__(256) void attn_mean_kernel(const __half* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    gload(0);
-    lstore(0);
+    GLOAD(0);
+    LSTORE(0);
     __syncthreads();
     for (int h = 0; h < H; ++h) {
         const int buf = h & 1;
-        if (h + 1 < H) gload(h + 1);
+        if (h + 1 < H) GLOAD(h + 1);
         const char* qb = smem + buf * BUF;
         const float* ls = reinterpret_cast<const float*>(qb + 2 * TB);
         f32x16 s[2][2];
@@ -305,7 +317,7 @@ __global__ __launch_bounds__(256) void attn_mean_kernel(const __half* __restrict
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] += __builtin_amdgcn_exp2f(s[mi][ni][r]);
-        if (h + 1 < H) lstore(buf ^ 1);
+        if (h + 1 < H) LSTORE(buf ^ 1);
         __syncthreads();
     }
     const float invh = 1.0f / H;

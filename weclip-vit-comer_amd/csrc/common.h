@@ -5,6 +5,10 @@
 #include <stdint.h>
 #include <stdio.h>
 
+// native vector types (arrays of HIP's struct uint4 are not promoted to registers by SROA)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
 #define WC_OK 0
 #define WC_ERR_ARG 1
 #define WC_ERR_HIP 2

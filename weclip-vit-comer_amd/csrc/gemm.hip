@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
     const long zb = blockIdx.z;
 
     // per-thread staging coordinates: 4 chunks of 16 B for A and 4 for W per K-tile
-    int srow[4], scol[4];
+    int srow[4], scol[4], soff[4];
     long aoff[4], woff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -77,32 +77,42 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
         if (ar > g.M - 1) ar = g.M - 1;
         int wrow = n0 + srow[i];
         if (wrow > g.N - 1) wrow = g.N - 1;
+        soff[i] = srow[i] * LDS_ROW + scol[i] * 16;
         aoff[i] = zb * g.sA + (long)ar * g.lda + scol[i] * 8;
         woff[i] = zb * g.sW + (long)wrow * g.ldw + scol[i] * 8;
     }
     const int ktiles = g.K / BK;
     const int nt = ktiles * g.nseg;
 
-    uint4 ra[4], rw[4];
-    auto gload = [&](int t) {
-        const int seg = t / ktiles;
-        const long k0 = (long)(t - seg * ktiles) * BK;
-        const __half* Ap = g.A[seg];
-        const __half* Wp = g.W[seg];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const uint4*>(Ap + aoff[i] + k0);
-            rw[i] = *reinterpret_cast<const uint4*>(Wp + woff[i] + k0);
-        }
-    };
-    auto lstore = [&](int buf) {
-        char* base = smem + buf * (2 * BM * LDS_ROW);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4*>(base + srow[i] * LDS_ROW + scol[i] * 16) = ra[i];
-            *reinterpret_cast<uint4*>(base + (BM + srow[i]) * LDS_ROW + scol[i] * 16) = rw[i];
-        }
-    };
+    // staging registers as scalars + macros (arrays captured by lambdas ended up in scratch)
+    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+#define GLOAD(t)                                                                         \
+    {                                                                                    \
+        const int seg_ = (t) / ktiles;                                                   \
+        const long k0_ = (long)((t) - seg_ * ktiles) * BK;                               \
+        const __half* Ap_ = seg_ == 0 ? g.A[0] : (seg_ == 1 ? g.A[1] : g.A[2]);          \
+        const __half* Wp_ = seg_ == 0 ? g.W[0] : (seg_ == 1 ? g.W[1] : g.W[2]);          \
+        ra0 = *reinterpret_cast<const uint4*>(Ap_ + aoff[0] + k0_);                      \
+        ra1 = *reinterpret_cast<const uint4*>(Ap_ + aoff[1] + k0_);                      \
+        ra2 = *reinterpret_cast<const uint4*>(Ap_ + aoff[2] + k0_);                      \
+        ra3 = *reinterpret_cast<const uint4*>(Ap_ + aoff[3] + k0_);                      \
+        rw0 = *reinterpret_cast<const uint4*>(Wp_ + woff[0] + k0_);                      \
+        rw1 = *reinterpret_cast<const uint4*>(Wp_ + woff[1] + k0_);                      \
+        rw2 = *reinterpret_cast<const uint4*>(Wp_ + woff[2] + k0_);                      \
+        rw3 = *reinterpret_cast<const uint4*>(Wp_ + woff[3] + k0_);                      \
+    }
+#define LSTORE(buf)                                                                      \
+    {                                                                                    \
+        char* base_ = smem + (buf) * (2 * BM * LDS_ROW);                                 \
+        *reinterpret_cast<uint4*>(base_ + soff[0]) = ra0;                                \
+        *reinterpret_cast<uint4*>(base_ + soff[1]) = ra1;                                \
+        *reinterpret_cast<uint4*>(base_ + soff[2]) = ra2;                                \
+        *reinterpret_cast<uint4*>(base_ + soff[3]) = ra3;                                \
+        *reinterpret_cast<uint4*>(base_ + BM * LDS_ROW + soff[0]) = rw0;                 \
+        *reinterpret_cast<uint4*>(base_ + BM * LDS_ROW + soff[1]) = rw1;                 \
+        *reinterpret_cast<uint4*>(base_ + BM * LDS_ROW + soff[2]) = rw2;                 \
+        *reinterpret_cast<uint4*>(base_ + BM * LDS_ROW + soff[3]) = rw3;                 \
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -112,14 +122,14 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    gload(0);
-    lstore(0);
+    GLOAD(0);
+    LSTORE(0);
     __syncthreads();
 
     const int frow = lane & 31, fk = (lane >> 5) * 16;   // fragment row / byte offset of k-half
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nt) gload(t + 1);
+        if (t + 1 < nt) GLOAD(t + 1);
         const char* As = smem + buf * (2 * BM * LDS_ROW) + (wr * 64 + frow) * LDS_ROW + fk;
         const char* Ws = smem + buf * (2 * BM * LDS_ROW) + (BM + wc * 64 + frow) * LDS_ROW + fk;
 #pragma unroll
@@ -133,42 +143,60 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (t + 1 < nt) lstore(buf ^ 1);
+        if (t + 1 < nt) LSTORE(buf ^ 1);
         __syncthreads();
     }
 
-    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Side inputs (residual / aux) are fetched for all 16 rows of a tile before any use so the
+    // loads overlap; out-of-range rows/cols read a clamped address and are not stored.
     const long cb = zb * g.sC;
+    const int act = g.act;
+    const bool has_res = g.resid != nullptr, has_aux = (act == 4);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int col = n0 + wc * 64 + ni * 32 + (lane & 31);
-            if (col >= g.N) continue;
-            const float bv = g.bias ? g.bias[col] : 0.f;
+            const bool colok = col < g.N;
+            const int colc = colok ? col : g.N - 1;
+            const float bv = g.bias ? g.bias[colc] : 0.f;
             const float sc = (col < g.scale_cols) ? g.scale : 1.0f;
+            const int rbase = m0 + wr * 64 + mi * 32 + 4 * (lane >> 5);
+            float rv[16], uv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= g.M) continue;
+                int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row > g.M - 1) row = g.M - 1;
+                rv[r] = has_res ? g.resid[zb * g.sR + (long)row * g.ldr + colc] : 0.f;
+                if (has_aux) {
+                    const long arow = g.rowmap ? (long)g.rowmap[row / g.rpg] * g.rpg + row % g.rpg : row;
+                    uv[r] = g.aux[arow * g.ldaux + colc];
+                } else
+                    uv[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
                 float v = acc[mi][ni][r] + bv;
                 if (g.round16) v = __half2float(__float2half(v));
                 v *= sc;
-                if (g.P32) g.P32[cb + (long)row * g.ldc + col] = v;
-                if (g.act == 4) {
-                    const long arow = g.rowmap ? (long)g.rowmap[row / g.rpg] * g.rpg + row % g.rpg : row;
-                    const float u = g.aux[arow * g.ldaux + col];
-                    const float sg = 1.0f / (1.0f + __expf(-1.702f * u));
-                    v *= sg * (1.0f + 1.702f * u * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
+                const float pre = v;
+                if (has_aux) {
+                    const float sg = 1.0f / (1.0f + __expf(-1.702f * uv[r]));
+                    v *= sg * (1.0f + 1.702f * uv[r] * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
                 } else
-                    v = apply_act(v, g.act);
-                const long o = cb + (long)row * g.ldc + col;
-                if (g.resid) v += g.resid[zb * g.sR + (long)row * g.ldr + col];
-                if (g.C32) g.C32[o] = v;
-                if (g.C16) {
-                    const __half h = __float2half(v);
-                    g.C16[o] = h;
-                    if (g.C16lo) g.C16lo[o] = __float2half(v - __half2float(h));
+                    v = apply_act(v, act);
+                v += rv[r];
+                if (colok && row < g.M) {
+                    const long o = cb + (long)row * g.ldc + col;
+                    if (g.P32) g.P32[o] = pre;
+                    if (g.C32) g.C32[o] = v;
+                    if (g.C16) {
+                        const __half h = __float2half(v);
+                        g.C16[o] = h;
+                        if (g.C16lo) g.C16lo[o] = __float2half(v - __half2float(h));
+                    }
                 }
             }
         }

@@ -267,50 +267,56 @@ __global__ __launch_bounds__(256) void attn_bwd_colsum_kernel(const __half* __re
         const int c = tid + 256 * i;
         int kr = k0 + c / CH;
         if (kr > L - 1) kr = L - 1;
-        *reinterpret_cast<uint4*>(Ks + (c / CH) * ROW + (c % CH) * 16) =
-            *reinterpret_cast<const uint4*>(qb + (long)kr * ldq + E + (c % CH) * 8);
-        *reinterpret_cast<uint4*>(Vs + (c / CH) * ROW + (c % CH) * 16) =
-            *reinterpret_cast<const uint4*>(qb + (long)kr * ldq + 2 * E + (c % CH) * 8);
+        *reinterpret_cast<u32x4*>(Ks + (c / CH) * ROW + (c % CH) * 16) =
+            *reinterpret_cast<const u32x4*>(qb + (long)kr * ldq + E + (c % CH) * 8);
+        *reinterpret_cast<u32x4*>(Vs + (c / CH) * ROW + (c % CH) * 16) =
+            *reinterpret_cast<const u32x4*>(qb + (long)kr * ldq + 2 * E + (c % CH) * 8);
     }
-    uint4 rq[NC], rd[NC];
+    u32x4 rq[NC], rd[NC];
     float rl = 0.f, rdl = 0.f;
-    auto gload = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const int c = tid + 256 * i;
-            int qr = t * 128 + c / CH;
-            if (qr > L - 1) qr = L - 1;
-            rq[i] = *reinterpret_cast<const uint4*>(qb + (long)qr * ldq + (c % CH) * 8);
-            rd[i] = *reinterpret_cast<const uint4*>(dob + (long)qr * E + (c % CH) * 8);
-        }
-        if (tid < 128) {
-            const int qr = t * 128 + tid;
-            rl = qr < L ? lseb[qr] : 1.0e30f;    // rows past L: P = exp2(S - 1e30) = 0
-            rdl = qr < L ? delb[qr] : 0.f;
-        }
-    };
-    auto lstore = [&](int buf) {
-        char* base = Qs + buf * QBUF;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const int c = tid + 256 * i;
-            *reinterpret_cast<uint4*>(base + (c / CH) * ROW + (c % CH) * 16) = rq[i];
-            *reinterpret_cast<uint4*>(base + TB + (c / CH) * ROW + (c % CH) * 16) = rd[i];
-        }
-        if (tid < 128) {
-            reinterpret_cast<float*>(base + 2 * TB)[tid] = rl;
-            reinterpret_cast<float*>(base + 2 * TB + 512)[tid] = rdl;
-        }
-    };
+#undef GLOAD
+#define GLOAD(t_) \
+    { \
+        const int t__ = (t_); \
+        _Pragma("unroll") \
+        for (int i = 0; i < NC; ++i) { \
+            const int c = tid + 256 * i; \
+            int qr = t__ * 128 + c / CH; \
+            if (qr > L - 1) qr = L - 1; \
+            rq[i] = *reinterpret_cast<const u32x4*>(qb + (long)qr * ldq + (c % CH) * 8); \
+            rd[i] = *reinterpret_cast<const u32x4*>(dob + (long)qr * E + (c % CH) * 8); \
+        } \
+        if (tid < 128) { \
+            const int qr = t__ * 128 + tid; \
+            rl = qr < L ? lseb[qr] : 1.0e30f; \
+            rdl = qr < L ? delb[qr] : 0.f; \
+        } \
+    }
+#undef LSTORE
+#define LSTORE(buf_) \
+    { \
+        const int buf__ = (buf_); \
+        char* base = Qs + buf__ * QBUF; \
+        _Pragma("unroll") \
+        for (int i = 0; i < NC; ++i) { \
+            const int c = tid + 256 * i; \
+            *reinterpret_cast<u32x4*>(base + (c / CH) * ROW + (c % CH) * 16) = rq[i]; \
+            *reinterpret_cast<u32x4*>(base + TB + (c / CH) * ROW + (c % CH) * 16) = rd[i]; \
+        } \
+        if (tid < 128) { \
+            reinterpret_cast<float*>(base + 2 * TB)[tid] = rl; \
+            reinterpret_cast<float*>(base + 2 * TB + 512)[tid] = rdl; \
+        } \
+    }
     float usum[2] = {0.f, 0.f};
     const int nt = (L + 127) / 128;
-    gload(0);
-    lstore(0);
+    GLOAD(0);
+    LSTORE(0);
     __syncthreads();
     const bool col0 = (blockIdx.x == 0 && wc == 0 && l31 == 0);
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nt) gload(t + 1);
+        if (t + 1 < nt) GLOAD(t + 1);
         const char* base = Qs + buf * QBUF;
         const float* ls = reinterpret_cast<const float*>(base + 2 * TB);
         const float* dl = reinterpret_cast<const float*>(base + 2 * TB + 512);
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(256) void attn_bwd_colsum_kernel(const __half* __re
                         }
                     }
                 }
-        if (t + 1 < nt) lstore(buf ^ 1);
+        if (t + 1 < nt) LSTORE(buf ^ 1);
         __syncthreads();
     }
 #pragma unroll
