@@ -94,5 +94,7 @@ class DecoderTransformer(nn.Module):
         b, c, h, w = x.shape
         t = x.reshape(b, c, h * w).permute(2, 0, 1)
         t, ws = self.transformer(t, need_weights)
-        t = t.permute(1, 2, 0).reshape(b, c, h, w)
-        return self.linear_pred(t), ws
+        # 1x1 conv as a token GEMM (MIOpen has no tuned 1x1 kernel for this shape and falls back to
+        # a naive convolution that costs more than the whole decoder)
+        logit = F.linear(t, self.linear_pred.weight.flatten(1), self.linear_pred.bias)   # (hw, b, nc)
+        return logit.permute(1, 2, 0).reshape(b, -1, h, w), ws

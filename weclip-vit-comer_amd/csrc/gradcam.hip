@@ -534,22 +534,37 @@ extern "C" int wc_attn_bwd_colsum(const void* qkv, const void* dO, const float* 
 }
 
 // out[p, e] = scale * sum_n c[p, n] * W[n, e]   (plain fp32 FMA: P is tiny, values span ~1e-9..1e-3)
+// block = 64 columns x 4 row-slices of n (LDS reduce), all pairs of a PB-chunk share each W read.
+#define RVM_PB 8
 __global__ __launch_bounds__(256) void rowvec_matmul_kernel(const float* __restrict__ c,
                                                              const float* __restrict__ W, float* __restrict__ out,
-                                                             int N, int E, float scale) {
-    const int e = blockIdx.x * 256 + threadIdx.x, p = blockIdx.y;
-    if (e >= E) return;
-    const float* cr = c + (long)p * N;
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s = fmaf(cr[n], W[(long)n * E + e], s);
-    out[(long)p * E + e] = s * scale;
+                                                             int P, int N, int E, float scale) {
+    __shared__ float red[4][RVM_PB][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane, p0 = blockIdx.y * RVM_PB;
+    float acc[RVM_PB];
+#pragma unroll
+    for (int k = 0; k < RVM_PB; ++k) acc[k] = 0.f;
+    if (e < E)
+        for (int n = wv; n < N; n += 4) {
+            const float w = W[(long)n * E + e];
+#pragma unroll
+            for (int k = 0; k < RVM_PB; ++k)
+                if (p0 + k < P) acc[k] = fmaf(c[(long)(p0 + k) * N + n], w, acc[k]);
+        }
+#pragma unroll
+    for (int k = 0; k < RVM_PB; ++k) red[wv][k][lane] = acc[k];
+    __syncthreads();
+    if (wv == 0 && e < E)
+        for (int k = 0; k < RVM_PB && p0 + k < P; ++k)
+            out[(long)(p0 + k) * E + e] = (red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane]) * scale;
 }
 
 extern "C" int wc_rowvec_matmul(const float* c, const float* W, float* out, int P, int N, int E, float scale,
                                 void* stream) {
-    WC_CHECK_ARG(c && W && out && P > 0 && N > 0 && E > 0 && P <= 65535, "wc_rowvec_matmul: bad argument");
-    hipLaunchKernelGGL(rowvec_matmul_kernel, dim3(wc_cdiv(E, 256), P), dim3(256), 0, (hipStream_t)stream, c, W,
-                       out, N, E, scale);
+    WC_CHECK_ARG(c && W && out && P > 0 && N > 0 && E > 0 && P <= 65535 * RVM_PB, "wc_rowvec_matmul: bad argument");
+    hipLaunchKernelGGL(rowvec_matmul_kernel, dim3(wc_cdiv(E, 64), wc_cdiv(P, RVM_PB)), dim3(256), 0,
+                       (hipStream_t)stream, c, W, out, P, N, E, scale);
     WC_LAUNCH_CHECK("rowvec_matmul_kernel");
     return WC_OK;
 }
