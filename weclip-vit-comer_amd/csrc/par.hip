@@ -68,6 +68,66 @@ __global__ __launch_bounds__(256) void par_affinity_kernel(const float* __restri
     }
 }
 
+// Register-resident variant for a compile-time tap count (ND dilations, T = 8*ND taps): the 3*T
+// neighbour values are fetched once and kept in VGPRs (one pass over the image instead of four).
+template <int ND>
+__global__ __launch_bounds__(256) void par_affinity_reg_kernel(const float* __restrict__ img,
+                                                                float* __restrict__ aff, int H, int W,
+                                                                float w1, ParTaps taps) {
+    constexpr int T = 8 * ND;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const long HW = (long)H * W;
+    const float* I = img + (long)blockIdx.z * 3 * HW;
+    const long p = (long)y * W + x;
+    const float c0 = I[p], c1 = I[HW + p], c2 = I[2 * HW + p];
+    float v0[T], v1[T], v2[T];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const long o = (long)clampi(y + taps.dy[t], H - 1) * W + clampi(x + taps.dx[t], W - 1);
+        v0[t] = I[o]; v1[t] = I[HW + o]; v2[t] = I[2 * HW + o];
+        s0 += v0[t]; s1 += v1[t]; s2 += v2[t];
+    }
+    const float m0 = s0 / T, m1 = s1 / T, m2 = s2 / T;
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const float a = v0[t] - m0, b = v1[t] - m1, c = v2[t] - m2;
+        q0 += a * a; q1 += b * b; q2 += c * c;
+    }
+    const float d0 = sqrtf(q0 / (T - 1)) + 1e-8f, d1 = sqrtf(q1 / (T - 1)) + 1e-8f,
+                d2 = sqrtf(q2 / (T - 1)) + 1e-8f;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const float a = fabsf(v0[t] - c0) / d0 / w1, b = fabsf(v1[t] - c1) / d1 / w1,
+                    c = fabsf(v2[t] - c2) / d2 / w1;
+        v0[t] = -(a * a + b * b + c * c) / 3.0f;
+        mx = fmaxf(mx, v0[t]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        v0[t] = __expf(v0[t] - mx);
+        sum += v0[t];
+    }
+    const float inv = 1.0f / sum;
+    float* A = aff + (long)blockIdx.z * T * HW + p;
+#pragma unroll
+    for (int t = 0; t < T; ++t) A[(long)t * HW] = v0[t] * inv + taps.pi[t];
+}
+
+static void launch_affinity(const float* img, float* aff, int nb, int H, int W, const ParTaps& tp,
+                            hipStream_t st) {
+    dim3 grid(wc_cdiv(W, 64), wc_cdiv(H, 4), nb);
+    if (tp.n == 48)
+        hipLaunchKernelGGL(par_affinity_reg_kernel<6>, grid, dim3(256), 0, st, img, aff, H, W, 0.3f, tp);
+    else
+        hipLaunchKernelGGL(par_affinity_kernel, grid, dim3(256), 0, st, img, aff, H, W, 0.3f, tp);
+}
+
 // One PAR iteration.  Thread = one pixel, CG channels at a time (aff value reused across the
 // channel group).  HBM traffic per launch: T*H*W*4 (aff) + 2*C*H*W*4 (masks in/out); the
 // neighbour gathers of `min` hit L1/L2 (C planes of H*W floats).
@@ -161,9 +221,7 @@ extern "C" int wc_par_affinity(const float* img, float* aff, int B, int H, int W
     WC_CHECK_ARG(img && aff && B > 0 && H > 0 && W > 0, "wc_par_affinity: bad argument");
     ParTaps tp;
     WC_CHECK_ARG(build_taps(&tp, dilations, n_dil, 0.3f, 0.01f) == 0, "wc_par_affinity: 1..8 dilations");
-    dim3 grid(wc_cdiv(W, 64), wc_cdiv(H, 4), B);
-    hipLaunchKernelGGL(par_affinity_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, aff, H, W,
-                       0.3f, tp);
+    launch_affinity(img, aff, B, H, W, tp, (hipStream_t)stream);
     WC_LAUNCH_CHECK("par_affinity_kernel");
     return WC_OK;
 }
@@ -207,9 +265,7 @@ extern "C" int wc_par_forward(const float* img, const float* masks, float* out, 
     const long HW = (long)H * W;
     for (int b0 = 0; b0 < B; b0 += group) {
         const int nb = (B - b0 < group) ? B - b0 : group;
-        dim3 grid(wc_cdiv(W, 64), wc_cdiv(H, 4), nb);
-        hipLaunchKernelGGL(par_affinity_kernel, grid, dim3(256), 0, st, img + (long)b0 * 3 * HW, aff_ws,
-                           H, W, 0.3f, tp);
+        launch_affinity(img + (long)b0 * 3 * HW, aff_ws, nb, H, W, tp, st);
         WC_LAUNCH_CHECK("par_affinity_kernel");
         const float* src = masks + (long)b0 * C * HW;
         for (int i = 0; i < num_iter; ++i) {
