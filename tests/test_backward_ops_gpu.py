@@ -1,0 +1,119 @@
+"""Backward building blocks of the trainable path (attention backward, LN backward, transposes,
+column sums, sigmoid-Gram backward) vs torch autograd on the CPU in fp64."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from weclip_vit_comer_amd import ops
+    return ops
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return ((a - b).abs().max() / b.abs().max()).item()
+
+
+@pytest.mark.parametrize("B,L,H,DH", [(2, 24, 8, 32), (1, 197, 12, 64), (2, 1024, 8, 32), (1, 130, 1, 64)])
+def test_attention_backward_matches_autograd(ops, B, L, H, DH):
+    E = H * DH
+    g = torch.Generator().manual_seed(L + DH)
+    qkv = torch.randn(B * L, 3 * E, generator=g)
+    qs = (qkv[:, :E] * ops.q_scale(DH)).half()
+    k, v = qkv[:, E:2 * E].half(), qkv[:, 2 * E:].half()
+    packed = torch.cat([qs, k, v], 1).contiguous().cuda()
+    do = (torch.randn(B * L, E, generator=g) * 0.1).half()
+    o16, lse, _, o32 = ops.attention(packed, B, L, H, DH, want_mean=False, want_o32=True)
+    d = ops.attention_bwd(packed, do.cuda(), o32, lse, B, L, H, DH)
+    got = (d.hi.float() + d.lo.float()).cpu().double()
+    # reference: unscaled q = qs / (log2e/sqrt(dh)) (exactly what the kernel differentiates w.r.t.)
+    q0 = (qs.double() / ops.q_scale(DH)).requires_grad_(True)
+    k0, v0 = k.double().requires_grad_(True), v.double().requires_grad_(True)
+    sh = lambda t: t.view(B, L, H, DH).permute(0, 2, 1, 3)
+    s = sh(q0) @ sh(k0).transpose(-1, -2) / DH ** 0.5
+    o = (torch.softmax(s, -1) @ sh(v0)).permute(0, 2, 1, 3).reshape(B * L, E)
+    (o * do.double()).sum().backward()
+    ref = torch.cat([q0.grad, k0.grad, v0.grad], 1)
+    for name, sl in (("dq", slice(0, E)), ("dk", slice(E, 2 * E)), ("dv", slice(2 * E, 3 * E))):
+        e = _rel(got[:, sl], ref[:, sl])
+        assert e < 6e-3, f"{name} rel err {e:.2e}"      # P, dS are rounded to fp16 before the second MFMA
+
+
+@pytest.mark.parametrize("D", [64, 256, 768])
+def test_layernorm_backward(ops, D):
+    g = torch.Generator().manual_seed(D)
+    rows = 333
+    x = (torch.randn(rows, D, generator=g) * 2 + 0.5)
+    w = torch.randn(D, generator=g)
+    dy = torch.randn(rows, D, generator=g)
+    add = torch.randn(rows, D, generator=g)
+    dx32, dx16, dgb = ops.layernorm_bwd(dy.cuda(), x.cuda(), w.cuda(), add=add.cuda(), want16=True, out_scale=0.5,
+                                        alpha=2.0)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    br = torch.zeros(D, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.layer_norm(xr, (D,), wr, br, 1e-5)
+    (y * dy.double()).sum().backward()
+    assert _rel(dx32.cpu(), xr.grad + add.double()) < 1e-5
+    assert _rel(dx16.float().cpu(), 0.5 * (xr.grad + add.double())) < 2e-3
+    assert _rel(dgb[0].cpu(), 2 * wr.grad) < 1e-5 and _rel(dgb[1].cpu(), 2 * br.grad) < 1e-5
+
+
+def test_transpose_colsum_and_wgrad(ops):
+    """dW = dY^T X through transposes + the TN GEMM, db = colsum(dY)."""
+    g = torch.Generator().manual_seed(0)
+    Bn, R, Cy, Cx = 2, 75, 96, 130     # rows per batch not a multiple of 64 -> zero padded K
+    dy = torch.randn(Bn * R, Cy, generator=g)
+    xfull = torch.randn(Bn, R + 1, Cx, generator=g).half()      # x with a CLS row per batch to skip
+    dyT, Kp = ops.transpose_f16(dy.cuda(), Bn * R, Cy, with_lo=True)
+    xsrc = xfull.cuda()
+    xT, Kp2 = ops.transpose_f16(xsrc.view(-1)[Cx:], R, Cx, ld=Cx, batch=Bn, sSrc=(R + 1) * Cx)
+    assert Kp == Kp2 == 192
+    out = torch.empty(Cy, Cx, device="cuda")
+    ops.gemm(dyT, xT, Cy, Cx, Kp, out32=out, scale=0.25, scale_cols=Cx)
+    ref = 0.25 * dy.double().t() @ xfull[:, 1:].reshape(Bn * R, Cx).double()
+    assert _rel(out.cpu(), ref) < 1e-5
+    b = ops.colsum(dy.cuda(), Bn * R, Cy, alpha=0.5)
+    assert _rel(b.cpu(), 0.5 * dy.double().sum(0)) < 1e-5
+    bh = ops.colsum(dy.half().cuda(), Bn * R, Cy, round16=True)
+    assert _rel(bh.cpu(), dy.half().double().sum(0)) < 2e-3
+
+
+def test_sigmoid_gram_backward_and_colscale(ops):
+    g = torch.Generator().manual_seed(3)
+    B, n, c = 2, 40, 64
+    F = torch.randn(B, n, c, generator=g, dtype=torch.float64, requires_grad=True)
+    AP = torch.sigmoid(F @ F.transpose(1, 2))
+    dAP = torch.randn(B, n, n, generator=g, dtype=torch.float64)
+    (AP * dAP).sum().backward()
+    S = ops.sigmoid_gram_bwd(dAP.float().cuda(), AP.detach().float().cuda())
+    Sf = (S.hi.float() + S.lo.float()).cpu().double()
+    assert _rel(Sf @ F.detach(), F.grad) < 1e-4
+    x = torch.randn(B * n, c, generator=g)
+    cs = torch.rand(B, c, generator=g)
+    y32, ys = ops.colscale_split(x.cuda(), cs.cuda(), n)
+    ref = x.view(B, n, c) * cs[:, None, :]
+    assert _rel(y32.cpu(), ref.reshape(B * n, c)) < 1e-6
+    assert _rel((ys.hi.float() + ys.lo.float()).cpu(), ref.reshape(B * n, c)) < 1e-6
+
+
+def test_gemm_relu_grad_and_colscale_epilogues(ops):
+    g = torch.Generator().manual_seed(4)
+    Bn, M, N, K = 2, 70, 64, 64
+    a = torch.randn(Bn * M, K, generator=g).half()
+    w = torch.randn(N, K, generator=g).half()
+    t1 = torch.randn(Bn * M, N, generator=g).half()
+    out = torch.empty(Bn * M, N, device="cuda")
+    ops.gemm(a.cuda(), w.cuda(), Bn * M, N, K, out32=out, act=5, auxh=t1.cuda(), ldaux=N)
+    ref = (a.double() @ w.double().t()) * (t1.double() > 0)
+    assert _rel(out.cpu(), ref) < 1e-5
+    cs = torch.rand(Bn, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    ops.gemm(a.cuda(), w.cuda(), M, N, K, bias=bias.cuda(), out32=out, batch=Bn, sA=M * K, sW=0, sC=M * N,
+             cscale=cs.cuda(), sCS=N)
+    ref2 = ((a.double() @ w.double().t() + bias.double()).view(Bn, M, N) * cs.double()[:, None, :]).reshape(Bn * M, N)
+    assert _rel(out.cpu(), ref2) < 1e-5

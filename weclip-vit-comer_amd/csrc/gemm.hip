@@ -48,6 +48,9 @@ struct GemmArgs {
     const int* rowmap;
     int rpg;
     long ldaux;
+    const __half* auxh;   // act 5: v *= (auxh[m*ldaux + n] > 0)  (ReLU backward from the saved fp16 output)
+    const float* cscale;  // optional per-batch column scale after bias: v *= cscale[z*sCS + n] (Dropout2d)
+    long sCS;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
     // loads overlap; out-of-range rows/cols read a clamped address and are not stored.
     const long cb = zb * g.sC;
     const int act = g.act;
-    const bool has_res = g.resid != nullptr, has_aux = (act == 4);
+    const bool has_res = g.resid != nullptr, has_aux = (act == 4), has_auxh = (act == 5);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -161,7 +164,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
             const bool colok = col < g.N;
             const int colc = colok ? col : g.N - 1;
             const float bv = g.bias ? g.bias[colc] : 0.f;
-            const float sc = (col < g.scale_cols) ? g.scale : 1.0f;
+            float sc = (col < g.scale_cols) ? g.scale : 1.0f;
+            if (g.cscale) sc *= g.cscale[zb * g.sCS + colc];
             const int rbase = m0 + wr * 64 + mi * 32 + 4 * (lane >> 5);
             float rv[16], uv[16];
 #pragma unroll
@@ -172,7 +176,9 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
                 if (has_aux) {
                     const long arow = g.rowmap ? (long)g.rowmap[row / g.rpg] * g.rpg + row % g.rpg : row;
                     uv[r] = g.aux[arow * g.ldaux + colc];
-                } else
+                } else if (has_auxh)
+                    uv[r] = __half2float(g.auxh[(long)row * g.ldaux + colc]) > 0.f ? 1.f : 0.f;
+                else
                     uv[r] = 0.f;
             }
 #pragma unroll
@@ -185,7 +191,9 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
                 if (has_aux) {
                     const float sg = 1.0f / (1.0f + __expf(-1.702f * uv[r]));
                     v *= sg * (1.0f + 1.702f * uv[r] * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
-                } else
+                } else if (has_auxh)
+                    v *= uv[r];
+                else
                     v = apply_act(v, act);
                 v += rv[r];
                 if (colok && row < g.M) {
@@ -207,7 +215,8 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
                            long ldw, int batch, long sA, long sW, long sC, const float* bias,
                            const float* resid, long ldr, long sR, float* C32, void* C16, void* C16lo, long ldc, int act,
                            int round16, float scale, int scale_cols, float* P32, const float* aux,
-                           const int* rowmap, int rpg, long ldaux, void* stream) {
+                           const int* rowmap, int rpg, long ldaux, const void* auxh, const float* cscale,
+                           long sCS, void* stream) {
     WC_CHECK_ARG(nseg >= 1 && nseg <= 3, "wc_gemm_f16: nseg must be 1..3");
     WC_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % BK == 0, "wc_gemm_f16: need M,N>0 and K %% 64 == 0 (got M=%d N=%d K=%d)", M, N, K);
     WC_CHECK_ARG(A0 && W0 && (nseg < 2 || (A1 && W1)) && (nseg < 3 || (A2 && W2)),
@@ -217,7 +226,8 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
     WC_CHECK_ARG(((uintptr_t)A0 | (uintptr_t)W0 | (uintptr_t)A1 | (uintptr_t)W1 | (uintptr_t)A2 |
                   (uintptr_t)W2) % 16 == 0, "wc_gemm_f16: operands must be 16-byte aligned");
     WC_CHECK_ARG((C32 || C16) && ldc >= N && batch >= 1 && batch <= 65535, "wc_gemm_f16: bad output");
-    WC_CHECK_ARG(act >= 0 && act <= 4, "wc_gemm_f16: act must be 0..4");
+    WC_CHECK_ARG(act >= 0 && act <= 5, "wc_gemm_f16: act must be 0..5");
+    WC_CHECK_ARG(act != 5 || (auxh && ldaux >= N), "wc_gemm_f16: act 5 needs auxh, ldaux");
     WC_CHECK_ARG(act != 4 || (aux && rpg > 0 && ldaux >= N), "wc_gemm_f16: act 4 needs aux, rpg, ldaux");
     GemmArgs g;
     g.A[0] = (const __half*)A0; g.A[1] = (const __half*)A1; g.A[2] = (const __half*)A2;
@@ -227,6 +237,7 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
     g.C32 = C32; g.C16 = (__half*)C16; g.C16lo = (__half*)C16lo; g.ldc = ldc;
     g.act = act; g.round16 = round16; g.scale = scale; g.scale_cols = scale_cols;
     g.P32 = P32; g.aux = aux; g.rowmap = rowmap; g.rpg = rpg > 0 ? rpg : 1; g.ldaux = ldaux;
+    g.auxh = (const __half*)auxh; g.cscale = cscale; g.sCS = sCS;
     dim3 grid(wc_cdiv(N, BN), wc_cdiv(M, BM), batch);
     WC_CHECK_ARG(grid.y <= 65535, "wc_gemm_f16: M too large for one launch");
     const size_t lds = 2 * 2 * BM * LDS_ROW;

@@ -1,0 +1,236 @@
+// Backward-pass helpers for the trainable adapters / decoder (reference autograd through
+// WeCLIP_model/segformer_head.py:69-80, WeCLIP_model/Decoder/TransDecoder.py:63-125 and
+// model_attn_aff_voc.py:134-137): operand transposes for weight-gradient GEMMs, bias-gradient
+// column sums, LayerNorm backward with parameter gradients, and the sigmoid-Gram backward.
+#include "common.h"
+
+// dst[b? .. ] : out[c, coff_b + r] = fp16(scale * src[b, r, c]);  src rows r < R of batch b start at
+// src + b*sSrc with row stride ld; out row stride ldo (>= batch*R, zero padded by the caller).
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_f16_kernel(const T* __restrict__ src, long ld, long sSrc,
+                                                             __half* __restrict__ hi, __half* __restrict__ lo,
+                                                             long ldo, int R, int C, float scale) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+    const T* s = src + (long)b * sSrc;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        tile[r][c] = (r0 + r < R && c0 + c < C) ? (float)s[(long)(r0 + r) * ld + c0 + c] * scale : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (c0 + c < C && r0 + r < R) {
+            const float v = tile[r][c];
+            const __half h = __float2half(v);
+            const long o = (long)(c0 + c) * ldo + (long)b * R + r0 + r;
+            hi[o] = h;
+            if (lo) lo[o] = __float2half(v - __half2float(h));
+        }
+    }
+}
+
+// out[c] = alpha * sum_r src[r, c]  (optionally rounded through fp16); two-stage via partial sums.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ src, long ld, float* __restrict__ part,
+                                                              long R, int C, int rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > R) r1 = R;
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += (float)src[r * ld + c];
+    part[(long)blockIdx.y * C + c] = s;
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                            int nblk, int C, float alpha, int round16) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(long)b * C + c];
+    s *= alpha;
+    out[c] = round16 ? __half2float(__float2half(s)) : s;
+}
+
+// LayerNorm backward.  dx = add + rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*w.
+// Outputs: dx32 (optional), dx16 = fp16(dx * out_scale) (optional); per-block partial sums of
+// dgamma = sum dy*xhat and dbeta = sum dy in part (nblk, 2, D).  One wave per row, 16 rows per wave.
+template <int NV>   // D <= 64*NV
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ w, const float* __restrict__ add,
+                                                      float eps, float* __restrict__ dx32, __half* __restrict__ dx16,
+                                                      float out_scale, float* __restrict__ part, long rows, int D) {
+    extern __shared__ float sm[];   // [4][2][D]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float ag[NV], ab[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) ag[i] = ab[i] = 0.f;
+    const long r0 = ((long)blockIdx.x * 4 + wv) * 16;
+    for (long row = r0; row < r0 + 16 && row < rows; ++row) {
+        const float* xr = x + row * D;
+        const float* dr = dy + row * D;
+        float xv[NV], dv[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = lane + 64 * i;
+            xv[i] = e < D ? xr[e] : 0.f;
+            dv[i] = e < D ? dr[e] : 0.f;
+            s += xv[i];
+        }
+        const float mean = wave_sum(s) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = lane + 64 * i;
+            const float d = e < D ? xv[i] - mean : 0.f;
+            q += d * d;
+        }
+        const float rstd = rsqrtf(wave_sum(q) / D + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = lane + 64 * i;
+            if (e < D) {
+                const float xh = (xv[i] - mean) * rstd;
+                const float g = dv[i] * w[e];
+                sg += g;
+                sgx += g * xh;
+                ag[i] += dv[i] * xh;
+                ab[i] += dv[i];
+            }
+        }
+        sg = wave_sum(sg) / D;
+        sgx = wave_sum(sgx) / D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = lane + 64 * i;
+            if (e < D) {
+                const float xh = (xv[i] - mean) * rstd;
+                float v = rstd * (dv[i] * w[e] - sg - xh * sgx);
+                if (add) v += add[row * D + e];
+                if (dx32) dx32[row * D + e] = v;
+                if (dx16) dx16[row * D + e] = __float2half(v * out_scale);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = lane + 64 * i;
+        if (e < D) {
+            sm[(wv * 2 + 0) * D + e] = ag[i];
+            sm[(wv * 2 + 1) * D + e] = ab[i];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * D; e += 256) {
+        const int which = e / D, k = e - which * D;
+        part[((long)blockIdx.x * 2 + which) * D + k] = sm[(0 * 2 + which) * D + k] + sm[(1 * 2 + which) * D + k] +
+                                                        sm[(2 * 2 + which) * D + k] + sm[(3 * 2 + which) * D + k];
+    }
+}
+
+// S[b,i,j] = z(i,j) + z(j,i),  z = dAP * AP * (1 - AP)   (backward of sigmoid(F^T F) w.r.t. the Gram matrix,
+// symmetrised so that dF = S F); fp16 hi/lo operands for the GEMM.
+__global__ __launch_bounds__(256) void sigmoid_gram_bwd_kernel(const float* __restrict__ dAP, const float* __restrict__ AP,
+                                                                __half* __restrict__ hi, __half* __restrict__ lo, int n,
+                                                                float scale) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
+    if (j >= n) return;
+    const long base = (long)b * n * n;
+    const long o = base + (long)i * n + j, ot = base + (long)j * n + i;
+    const float a = AP[o], at = AP[ot];
+    const float v = scale * (dAP[o] * a * (1.f - a) + dAP[ot] * at * (1.f - at));
+    const __half h = __float2half(v);
+    hi[o] = h;
+    if (lo) lo[o] = __float2half(v - __half2float(h));
+}
+
+// out32[r,c] = x[r,c] * cs[(r / rpb), c];  hi/lo = fp16 split of it   (dropout-mask backward + operand split)
+__global__ __launch_bounds__(256) void colscale_split_kernel(const float* __restrict__ x, const float* __restrict__ cs,
+                                                              float* __restrict__ out32, __half* __restrict__ hi,
+                                                              __half* __restrict__ lo, long rows, int C, int rpb) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * C) return;
+    const long r = i / C;
+    const int c = i - r * C;
+    const float v = x[i] * (cs ? cs[(r / rpb) * C + c] : 1.f);
+    if (out32) out32[i] = v;
+    const __half h = __float2half(v);
+    hi[i] = h;
+    if (lo) lo[i] = __float2half(v - __half2float(h));
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int wc_transpose_f16(const void* src, int src_f32, long ld, long sSrc, void* hi, void* lo, long ldo,
+                                int batch, int R, int C, float scale, void* stream) {
+    WC_CHECK_ARG(src && hi && batch > 0 && R > 0 && C > 0 && ld >= C && ldo >= (long)batch * R && batch <= 65535,
+                 "wc_transpose_f16: bad argument");
+    dim3 grid(wc_cdiv(R, 64), wc_cdiv(C, 64), batch);
+    if (src_f32)
+        hipLaunchKernelGGL(transpose_f16_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, ld,
+                           sSrc, (__half*)hi, (__half*)lo, ldo, R, C, scale);
+    else
+        hipLaunchKernelGGL(transpose_f16_kernel<__half>, grid, dim3(256), 0, (hipStream_t)stream, (const __half*)src,
+                           ld, sSrc, (__half*)hi, (__half*)lo, ldo, R, C, scale);
+    WC_LAUNCH_CHECK("transpose_f16_kernel");
+    return WC_OK;
+}
+
+extern "C" int wc_colsum(const void* src, int src_f32, long ld, float* part, float* out, long R, int C, float alpha,
+                         int round16, void* stream) {
+    WC_CHECK_ARG(src && part && out && R > 0 && C > 0 && ld >= C, "wc_colsum: bad argument");
+    const int rpb = 256;
+    const int nblk = wc_cdiv(R, rpb);
+    WC_CHECK_ARG(nblk <= 65535, "wc_colsum: too many rows");
+    dim3 grid(wc_cdiv(C, 256), nblk);
+    hipStream_t st = (hipStream_t)stream;
+    if (src_f32)
+        hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)src, ld, part, R, C, rpb);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<__half>, grid, dim3(256), 0, st, (const __half*)src, ld, part, R, C, rpb);
+    WC_LAUNCH_CHECK("colsum_partial_kernel");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(wc_cdiv(C, 256)), dim3(256), 0, st, part, out, nblk, C, alpha, round16);
+    WC_LAUNCH_CHECK("colsum_final_kernel");
+    return WC_OK;
+}
+
+// part: workspace ceil(rows/64)*2*D floats; dgb (2,D) = alpha * [dgamma ; dbeta].
+extern "C" int wc_layernorm_bwd(const float* dy, const float* x, const float* w, const float* add, float eps,
+                                float* dx32, void* dx16, float out_scale, float* part, float* dgb, float alpha,
+                                long rows, int D, void* stream) {
+    WC_CHECK_ARG(dy && x && w && part && dgb && rows > 0 && D > 0 && D <= 1024 && (dx32 || dx16),
+                 "wc_layernorm_bwd: bad argument (D <= 1024)");
+    const int nblk = wc_cdiv(rows, 64);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t sm = 8 * (size_t)D * sizeof(float);
+    if (D <= 256)
+        hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nblk), dim3(256), sm, st, dy, x, w, add, eps, dx32, (__half*)dx16,
+                           out_scale, part, rows, D);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<16>, dim3(nblk), dim3(256), sm, st, dy, x, w, add, eps, dx32, (__half*)dx16,
+                           out_scale, part, rows, D);
+    WC_LAUNCH_CHECK("ln_bwd_kernel");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(wc_cdiv(2 * D, 256)), dim3(256), 0, st, part, dgb, nblk, 2 * D, alpha, 0);
+    WC_LAUNCH_CHECK("colsum_final_kernel");
+    return WC_OK;
+}
+
+extern "C" int wc_sigmoid_gram_bwd(const float* dAP, const float* AP, void* hi, void* lo, int B, int n, float scale,
+                                   void* stream) {
+    WC_CHECK_ARG(dAP && AP && hi && B > 0 && n > 0 && n <= 65535, "wc_sigmoid_gram_bwd: bad argument");
+    hipLaunchKernelGGL(sigmoid_gram_bwd_kernel, dim3(wc_cdiv(n, 256), n, B), dim3(256), 0, (hipStream_t)stream, dAP, AP,
+                       (__half*)hi, (__half*)lo, n, scale);
+    WC_LAUNCH_CHECK("sigmoid_gram_bwd_kernel");
+    return WC_OK;
+}
+
+extern "C" int wc_colscale_split(const float* x, const float* cs, float* out32, void* hi, void* lo, long rows, int C,
+                                 int rows_per_batch, void* stream) {
+    WC_CHECK_ARG(x && hi && rows > 0 && C > 0 && rows_per_batch > 0, "wc_colscale_split: bad argument");
+    hipLaunchKernelGGL(colscale_split_kernel, dim3(wc_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, x, cs,
+                       out32, (__half*)hi, (__half*)lo, rows, C, rows_per_batch);
+    WC_LAUNCH_CHECK("colscale_split_kernel");
+    return WC_OK;
+}

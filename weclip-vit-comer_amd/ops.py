@@ -71,7 +71,7 @@ def split_f16(x, with_lo=False):
 def gemm(a, w, M, N, K, *, lda=None, ldw=None, bias=None, resid=None, ldr=None, sR=None,
          out32=None, out16=None, out16lo=None, ldc=None, act=0, round16=False, scale=1.0,
          scale_cols=0, batch=1, sA=0, sW=0, sC=0, pre32=None, aux=None, rowmap=None, rpg=0,
-         ldaux=0):
+         ldaux=0, auxh=None, cscale=None, sCS=0):
     """C = epilogue(A W^T).  `a`, `w`: Split (or fp16 tensors).  Segments accumulated:
     (a.hi,w.hi) [+ (a.lo,w.hi)] [+ (a.hi,w.lo)]."""
     a = a if isinstance(a, Split) else Split(a)
@@ -94,7 +94,8 @@ def gemm(a, w, M, N, K, *, lda=None, ldw=None, bias=None, resid=None, ldr=None, 
                         ldr, sR, L.ptr(out32, F32, "out32"), L.ptr(out16, F16, "out16"),
                         L.ptr(out16lo, F16, "out16lo"), ldc, act, 1 if round16 else 0,
                         float(scale), scale_cols, L.ptr(pre32, F32, "pre32"), L.ptr(aux, F32, "aux"),
-                        L.ptr(rowmap, torch.int32, "rowmap"), rpg, ldaux, L.stream())
+                        L.ptr(rowmap, torch.int32, "rowmap"), rpg, ldaux, L.ptr(auxh, F16, "auxh"),
+                        L.ptr(cscale, F32, "cscale"), sCS, L.stream())
     KernelTimer.stop("gemm_f16_kernel", t0, 2.0 * M * N * K * batch)   # algorithmic flops (1 pass)
 
 
@@ -143,3 +144,81 @@ def attention(qkv16, B, Lq, H, DH, want_mean=True, want_o32=False):
 
 def q_scale(DH):
     return LOG2E / math.sqrt(DH)
+
+
+# ------------------------------------------------------------------------------------------------
+# backward helpers (csrc/train_ops.hip, csrc/attention_bwd.hip)
+
+def attention_bwd(qkv16, do16, o32, lse, B, Lq, H, DH, with_lo=True):
+    """-> dqkv Split (B*L, 3E): gradient w.r.t. the unscaled in-projection output."""
+    E = H * DH
+    dev = qkv16.device
+    Lp = (Lq + 63) // 64 * 64
+    ws = torch.empty(3, B * H * DH * Lp, device=dev, dtype=F16)
+    delta = torch.empty(B * H * Lq, device=dev, dtype=F32)
+    d = Split(torch.empty(B * Lq, 3 * E, device=dev, dtype=F16),
+              torch.empty(B * Lq, 3 * E, device=dev, dtype=F16) if with_lo else None)
+    L.lib().wc_attn_bwd(L.ptr(qkv16, F16, "qkv"), L.ptr(do16, F16, "dO"), L.ptr(o32, F32, "o32"), L.ptr(lse, F32, "lse"),
+                        L.ptr(ws[0]), L.ptr(ws[1]), L.ptr(ws[2]), L.ptr(delta), L.ptr(d.hi), L.ptr(d.lo), B, Lq, Lp,
+                        H, DH, L.stream())
+    return d
+
+
+def transpose_f16(src, R, C, *, ld=None, batch=1, sSrc=0, with_lo=False, scale=1.0):
+    """out (C, Kp) fp16 with out[c, b*R + r] = scale*src[b, r, c]; Kp = batch*R rounded up to 64
+    (zero padded) so it can be the K dimension of a weight-gradient GEMM."""
+    ld = C if ld is None else ld
+    K = batch * R
+    Kp = (K + 63) // 64 * 64
+    dev = src.device
+    alloc = torch.zeros if Kp != K else torch.empty
+    hi = alloc(C, Kp, device=dev, dtype=F16)
+    lo = alloc(C, Kp, device=dev, dtype=F16) if with_lo else None
+    f32 = src.dtype == F32
+    L.lib().wc_transpose_f16(L.ptr(src, F32 if f32 else F16, "src"), 1 if f32 else 0, ld, sSrc, L.ptr(hi), L.ptr(lo),
+                             Kp, batch, R, C, float(scale), L.stream())
+    return Split(hi, lo), Kp
+
+
+def colsum(src, R, C, *, ld=None, alpha=1.0, round16=False, out=None):
+    ld = C if ld is None else ld
+    dev = src.device
+    part = torch.empty(((R + 255) // 256) * C, device=dev, dtype=F32)
+    out = torch.empty(C, device=dev, dtype=F32) if out is None else out
+    f32 = src.dtype == F32
+    L.lib().wc_colsum(L.ptr(src, F32 if f32 else F16, "src"), 1 if f32 else 0, ld, L.ptr(part), L.ptr(out, F32), R, C,
+                      float(alpha), 1 if round16 else 0, L.stream())
+    return out
+
+
+def layernorm_bwd(dy, x, w, *, add=None, want32=True, want16=False, out_scale=1.0, alpha=1.0, eps=1e-5):
+    """-> (dx32 or None, dx16 or None, dgb (2, D) = alpha*[dgamma; dbeta])."""
+    rows, D = x.shape
+    dev = x.device
+    dx32 = torch.empty(rows, D, device=dev, dtype=F32) if want32 else None
+    dx16 = torch.empty(rows, D, device=dev, dtype=F16) if want16 else None
+    part = torch.empty(((rows + 63) // 64) * 2 * D, device=dev, dtype=F32)
+    dgb = torch.empty(2, D, device=dev, dtype=F32)
+    L.lib().wc_layernorm_bwd(L.ptr(dy, F32, "dy"), L.ptr(x, F32, "x"), L.ptr(w, F32, "w"), L.ptr(add, F32, "add"), eps,
+                             L.ptr(dx32), L.ptr(dx16), float(out_scale), L.ptr(part), L.ptr(dgb), float(alpha), rows,
+                             D, L.stream())
+    return dx32, dx16, dgb
+
+
+def sigmoid_gram_bwd(dAP, AP, scale=1.0, with_lo=True):
+    B, n, _ = AP.shape
+    s = Split(torch.empty(B, n, n, device=AP.device, dtype=F16),
+              torch.empty(B, n, n, device=AP.device, dtype=F16) if with_lo else None)
+    L.lib().wc_sigmoid_gram_bwd(L.ptr(dAP, F32, "dAP"), L.ptr(AP, F32, "AP"), L.ptr(s.hi), L.ptr(s.lo), B, n,
+                                float(scale), L.stream())
+    return s
+
+
+def colscale_split(x, cs, rows_per_batch, want32=True, with_lo=True):
+    rows, C = x.shape
+    dev = x.device
+    out32 = torch.empty(rows, C, device=dev, dtype=F32) if want32 else None
+    s = Split(torch.empty(rows, C, device=dev, dtype=F16), torch.empty(rows, C, device=dev, dtype=F16) if with_lo else None)
+    L.lib().wc_colscale_split(L.ptr(x, F32, "x"), L.ptr(cs, F32, "cs"), L.ptr(out32), L.ptr(s.hi), L.ptr(s.lo), rows, C,
+                              rows_per_batch, L.stream())
+    return out32, s
