@@ -80,6 +80,9 @@ int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const void* W0, 
                 void* C16, void* C16lo, long ldc, int act, int round16, float scale,
                 int scale_cols, float* P32, const float* aux, const int* rowmap, int rpg,
                 long ldaux, const void* auxh, const float* cscale, long sCS, void* stream);
+/* out[i] = alpha * sum_s part[s*n + i]: reduction of split-K partial products (the slices are a
+ * batched wc_gemm_f16 over K ranges: sA = sW = K/slices, sC = M*N). */
+int wc_sum_slices(const float* part, float* out, int nslices, long n, float alpha, void* stream);
 /* fp32 -> fp16 hi (+ lo = fp16(x - hi), may be NULL): `.half()` casts of weights/activations
  * (clip/model.py:457-478 convert_weights; clip/myAtt.py:321). */
 int wc_split_f16(const float* x, void* hi, void* lo, long n, void* stream);
@@ -182,13 +185,13 @@ int wc_cam_upsample(const float* R, const int* nk, float* stats, float* cams, in
 /* ---- backward helpers of the trainable adapters / decoder ------------------------------ */
 /* autograd through WeCLIP_model/segformer_head.py:69-80, Decoder/TransDecoder.py:63-125,
  * model_attn_aff_voc.py:134-137 (all run by torch.autograd in the reference).
- * wc_transpose_f16:  out[c, b*R + r] = fp16(scale*src[b,r,c]) (hi[,lo]); src f32 or f16 (src_f32),
+ * wc_transpose_f16:  out[c, b*oR + r] = fp16(scale*src[b,r,c]) (hi[,lo]); src f32 or f16 (src_f32),
  *                    row stride ld, batch stride sSrc; out row stride ldo: operands of dW = dY^T X.
  * wc_colsum:         out[c] = alpha * sum_r src[r,c] (bias gradients); part: ceil(R/256)*C f32.
  * wc_layernorm_bwd:  dx = add + LN_bwd(dy; x, w) as f32 and/or fp16(dx*out_scale);
  *                    dgb (2,D) = alpha*[sum dy*xhat ; sum dy]; part: ceil(rows/64)*2*D f32.
- * wc_sigmoid_gram_bwd: S[b] = Z + Z^T, Z = dAP*AP*(1-AP) (fp16 hi[,lo]) so that dF = S F.
- * wc_colscale_split: y = x * cs[row / rows_per_batch, col] -> f32 (optional) and fp16 hi[,lo]. */
+ * wc_sigmoid_gram_bwd: S[b] = scale*(Z + Z^T), Z = dAP*AP*(1-AP) (fp16 hi[,lo], row stride ldo) so dF = S F.
+ * wc_colscale_split: y = alpha * x * cs[row / rows_per_batch, col] (cs may be NULL) -> f32 (optional), fp16 hi[,lo]. */
 /* wc_attn_bwd: backward of clip/myAtt.py:21-64 without storing L x L tensors: from the packed qkv
  * (q pre-scaled), dO (B*L,E) fp16, o32, lse -> dqkv (B*L,3E) fp16 hi (+lo, may be NULL), gradients
  * w.r.t. the UNSCALED in-projection output.  Workspaces qt, kt, dot: B*H*DH*Lp halves each;
@@ -197,16 +200,16 @@ int wc_attn_bwd(const void* qkv, const void* dO, const float* o32, const float* 
                 void* dot, float* delta, void* dqkv_hi, void* dqkv_lo, int B, int L, int Lp, int H, int DH,
                 void* stream);
 int wc_transpose_f16(const void* src, int src_f32, long ld, long sSrc, void* hi, void* lo, long ldo,
-                     int batch, int R, int C, float scale, void* stream);
+                     long oR, int batch, int R, int C, float scale, void* stream);
 int wc_colsum(const void* src, int src_f32, long ld, float* part, float* out, long R, int C, float alpha,
               int round16, void* stream);
 int wc_layernorm_bwd(const float* dy, const float* x, const float* w, const float* add, float eps,
                      float* dx32, void* dx16, float out_scale, float* part, float* dgb, float alpha,
                      long rows, int D, void* stream);
-int wc_sigmoid_gram_bwd(const float* dAP, const float* AP, void* hi, void* lo, int B, int n, float scale,
-                        void* stream);
+int wc_sigmoid_gram_bwd(const float* dAP, const float* AP, void* hi, void* lo, int B, int n, int ldo,
+                        float scale, void* stream);
 int wc_colscale_split(const float* x, const float* cs, float* out32, void* hi, void* lo, long rows, int C,
-                      int rows_per_batch, void* stream);
+                      int rows_per_batch, float alpha, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@ from .. import cam_pipeline as CP
 from ..clip import clip_tool as CT
 from ..clip import vit_engine as VE
 from ..clip.clip import load as clip_load
+from ..head_engine import HeadEngine, HeadFunction
 from ..pytorch_grad_cam import GradCAM
 from .Decoder.TransDecoder import DecoderTransformer
 from .PAR import PAR, refine_labels
@@ -55,6 +56,8 @@ class WeCLIP(nn.Module):
         self.par = PAR(num_iter=20, dilations=[1, 2, 4, 8, 12, 24])
         self.iter_num = 0
         self.require_all_fts = True
+        self.head_impl = os.environ.get("WECLIP_HEAD", "hip")   # "hip" (head_engine.py) | "torch" (stock autograd)
+        self.head_engine = HeadEngine(self.decoder_fts_fuse, self.decoder)
         self.to(device)
 
     def get_param_groups(self):
@@ -81,14 +84,15 @@ class WeCLIP(nn.Module):
         first = 12 - n                      # index into the 12 maps (11 encoder + last block)
         return [i >= first for i in range(11)]
 
-    def encode(self, img, seg_trans):
-        """Frozen encoder: token rows of blocks 1..11 and the head-mean maps the affinity needs."""
+    def encode(self, img, seg_trans, x16=None):
+        """Frozen encoder: token rows of blocks 1..11 and the head-mean maps the affinity needs.
+        `x16` (a list) additionally receives fp16 copies of the block outputs (adapter operands)."""
         vis = self.encoder.visual
         rows, B, Lq = vis.embed(img)
         need = self._maps_needed(seg_trans)
         xs, maps = [], []
         for i in range(vis.transformer.layers - 1):
-            rows, m = VE.run_block(vis.transformer.resblocks[i].pack(), rows, B, Lq, want_mean=need[i])
+            rows, m = VE.run_block(vis.transformer.resblocks[i].pack(), rows, B, Lq, want_mean=need[i], x16_out=x16)
             xs.append(rows)
             maps.append(m)
         return xs, maps, B, Lq
@@ -102,12 +106,22 @@ class WeCLIP(nn.Module):
         self.iter_num += 1
         seg_trans = self.iter_num > self.seg_trans_after or mode == "val"
         img = img.cuda().float().contiguous()
+        hip_head = self.head_impl == "hip"
+        x16 = [] if hip_head else None
         with torch.no_grad():
-            xs, maps, _, Lq = self.encode(img, seg_trans)
-        fts = self.decoder_fts_fuse.forward_rows(xs, B, Lq, h, w)
-        seg, _ = self.decoder(fts, need_weights=False)
-        f = fts.reshape(B, fts.shape[1], h * w)
-        attn_pred = torch.sigmoid(f.transpose(2, 1).bmm(f))
+            xs, maps, _, Lq = self.encode(img, seg_trans, x16)
+        if hip_head:
+            # adapters + decoder + attn_pred, forward and backward as HIP launches (head_engine.py)
+            drop = None
+            if self.training:
+                p = self.decoder_fts_fuse.dropout.p
+                drop = ((torch.rand(B, self.embedding_dim, device=img.device) >= p).float() / (1.0 - p)).contiguous()
+            seg, attn_pred = HeadFunction.apply(self.head_engine, x16, B, Lq, h, w, drop, *self.head_engine.params())
+        else:
+            fts = self.decoder_fts_fuse.forward_rows(xs, B, Lq, h, w)
+            seg, _ = self.decoder(fts, need_weights=False)
+            f = fts.reshape(B, fts.shape[1], h * w)
+            attn_pred = torch.sigmoid(f.transpose(2, 1).bmm(f))
         if mode == "val" and not self.val_runs_cam:
             return seg, None, attn_pred
         with torch.no_grad():

@@ -37,7 +37,7 @@ class BlockPack:
         self.pj_b = f(blk.mlp.c_proj.bias)
 
 
-def run_block(pk, x, B, L, want_mean=True, keep=None):
+def run_block(pk, x, B, L, want_mean=True, keep=None, x16_out=None):
     """x (B*L, E) fp32 -> (x_out fp32, head-mean map (B,L,L) or None).
     `keep`, if a dict, receives intermediates needed by the analytic backward."""
     M, E, H, DH = B * L, pk.E, pk.H, pk.DH
@@ -59,7 +59,12 @@ def run_block(pk, x, B, L, want_mean=True, keep=None):
     u32 = torch.empty(M, 4 * E, device=dev, dtype=F32) if keep is not None else None
     ops.gemm(a2, pk.fc_w, M, 4 * E, E, bias=pk.fc_b, out16=z.hi, out16lo=z.lo, act=1, pre32=u32)
     x2 = torch.empty(M, E, device=dev, dtype=F32)
-    ops.gemm(z, pk.pj_w, M, E, 4 * E, bias=pk.pj_b, resid=x1, out32=x2)
+    x2h = None
+    if x16_out is not None:     # fp16 copy of the block output for the adapter GEMMs (no extra pass)
+        x2h = Split(torch.empty(M, E, device=dev, dtype=F16), torch.empty(M, E, device=dev, dtype=F16) if ex else None)
+        x16_out.append(x2h)
+    ops.gemm(z, pk.pj_w, M, E, 4 * E, bias=pk.pj_b, resid=x1, out32=x2,
+             out16=x2h.hi if x2h else None, out16lo=x2h.lo if x2h else None)
     if keep is not None:
         keep.update(a32=a32, qkv=qkv, o32=o32, lse=lse, x1=x1, u32=u32)
     return x2, mean

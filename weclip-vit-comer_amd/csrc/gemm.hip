@@ -60,6 +60,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+template <bool AUX>
 __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // layout: buf b (0/1): A rows [0,128) then W rows [0,128), each LDS_ROW bytes
@@ -151,11 +152,12 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // Side inputs (residual / aux) are fetched for all 16 rows of a tile before any use so the
-    // loads overlap; out-of-range rows/cols read a clamped address and are not stored.
+    // Side inputs (residual / aux) of a 32x32 tile are fetched before use so the loads overlap;
+    // out-of-range rows/cols read a clamped address and are not stored.  AUX (act 4/5) is a
+    // separate instantiation so the common epilogue carries no aux registers.
     const long cb = zb * g.sC;
     const int act = g.act;
-    const bool has_res = g.resid != nullptr, has_aux = (act == 4), has_auxh = (act == 5);
+    const bool has_res = g.resid != nullptr;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -167,19 +169,22 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
             float sc = (col < g.scale_cols) ? g.scale : 1.0f;
             if (g.cscale) sc *= g.cscale[zb * g.sCS + colc];
             const int rbase = m0 + wr * 64 + mi * 32 + 4 * (lane >> 5);
-            float rv[16], uv[16];
+            f32x16 rv, uv;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int row = rbase + (r & 3) + 8 * (r >> 2);
                 if (row > g.M - 1) row = g.M - 1;
                 rv[r] = has_res ? g.resid[zb * g.sR + (long)row * g.ldr + colc] : 0.f;
-                if (has_aux) {
-                    const long arow = g.rowmap ? (long)g.rowmap[row / g.rpg] * g.rpg + row % g.rpg : row;
-                    uv[r] = g.aux[arow * g.ldaux + colc];
-                } else if (has_auxh)
-                    uv[r] = __half2float(g.auxh[(long)row * g.ldaux + colc]) > 0.f ? 1.f : 0.f;
-                else
-                    uv[r] = 0.f;
+                if constexpr (AUX) {
+                    if (act == 4) {
+                        const long arow = g.rowmap ? (long)g.rowmap[row / g.rpg] * g.rpg + row % g.rpg : row;
+                        const float u = g.aux[arow * g.ldaux + colc];
+                        const float sg = 1.0f / (1.0f + __expf(-1.702f * u));
+                        uv[r] = sg * (1.0f + 1.702f * u * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
+                    } else {
+                        uv[r] = __half2float(g.auxh[(long)row * g.ldaux + colc]) > 0.f ? 1.f : 0.f;   // ReLU'
+                    }
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -188,10 +193,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
                 if (g.round16) v = __half2float(__float2half(v));
                 v *= sc;
                 const float pre = v;
-                if (has_aux) {
-                    const float sg = 1.0f / (1.0f + __expf(-1.702f * uv[r]));
-                    v *= sg * (1.0f + 1.702f * uv[r] * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
-                } else if (has_auxh)
+                if constexpr (AUX)
                     v *= uv[r];
                 else
                     v = apply_act(v, act);
@@ -208,6 +210,24 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
                 }
             }
         }
+}
+
+// out[i] = alpha * sum_s part[s*n + i]   (split-K reduction: slices are a batched GEMM over K ranges)
+__global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                          int nslices, long n, float alpha) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nslices; ++k) s += part[(long)k * n + i];
+    out[i] = s * alpha;
+}
+
+extern "C" int wc_sum_slices(const float* part, float* out, int nslices, long n, float alpha, void* stream) {
+    WC_CHECK_ARG(part && out && nslices > 0 && n > 0, "wc_sum_slices: bad argument");
+    hipLaunchKernelGGL(sum_slices_kernel, dim3(wc_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, part, out, nslices,
+                       n, alpha);
+    WC_LAUNCH_CHECK("sum_slices_kernel");
+    return WC_OK;
 }
 
 extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const void* W0,
@@ -241,7 +261,10 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
     dim3 grid(wc_cdiv(N, BN), wc_cdiv(M, BM), batch);
     WC_CHECK_ARG(grid.y <= 65535, "wc_gemm_f16: M too large for one launch");
     const size_t lds = 2 * 2 * BM * LDS_ROW;
-    hipLaunchKernelGGL(gemm_f16_kernel, grid, dim3(256), lds, (hipStream_t)stream, g);
+    if (act >= 4)
+        hipLaunchKernelGGL(gemm_f16_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, g);
+    else
+        hipLaunchKernelGGL(gemm_f16_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, g);
     WC_LAUNCH_CHECK("gemm_f16_kernel");
     return WC_OK;
 }

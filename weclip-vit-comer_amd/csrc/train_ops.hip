@@ -9,7 +9,7 @@
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_f16_kernel(const T* __restrict__ src, long ld, long sSrc,
                                                              __half* __restrict__ hi, __half* __restrict__ lo,
-                                                             long ldo, int R, int C, float scale) {
+                                                             long ldo, long oR, int R, int C, float scale) {
     __shared__ float tile[64][65];
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
     const T* s = src + (long)b * sSrc;
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void transpose_f16_kernel(const T* __restrict_
         if (c0 + c < C && r0 + r < R) {
             const float v = tile[r][c];
             const __half h = __float2half(v);
-            const long o = (long)(c0 + c) * ldo + (long)b * R + r0 + r;
+            const long o = (long)(c0 + c) * ldo + (long)b * oR + r0 + r;
             hi[o] = h;
             if (lo) lo[o] = __float2half(v - __half2float(h));
         }
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 // symmetrised so that dF = S F); fp16 hi/lo operands for the GEMM.
 __global__ __launch_bounds__(256) void sigmoid_gram_bwd_kernel(const float* __restrict__ dAP, const float* __restrict__ AP,
                                                                 __half* __restrict__ hi, __half* __restrict__ lo, int n,
-                                                                float scale) {
+                                                                int ldo, float scale) {
     const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
     if (j >= n) return;
     const long base = (long)b * n * n;
@@ -143,19 +143,21 @@ __global__ __launch_bounds__(256) void sigmoid_gram_bwd_kernel(const float* __re
     const float a = AP[o], at = AP[ot];
     const float v = scale * (dAP[o] * a * (1.f - a) + dAP[ot] * at * (1.f - at));
     const __half h = __float2half(v);
-    hi[o] = h;
-    if (lo) lo[o] = __float2half(v - __half2float(h));
+    const long oo = (long)b * n * ldo + (long)i * ldo + j;
+    hi[oo] = h;
+    if (lo) lo[oo] = __float2half(v - __half2float(h));
 }
 
 // out32[r,c] = x[r,c] * cs[(r / rpb), c];  hi/lo = fp16 split of it   (dropout-mask backward + operand split)
 __global__ __launch_bounds__(256) void colscale_split_kernel(const float* __restrict__ x, const float* __restrict__ cs,
                                                               float* __restrict__ out32, __half* __restrict__ hi,
-                                                              __half* __restrict__ lo, long rows, int C, int rpb) {
+                                                              __half* __restrict__ lo, long rows, int C, int rpb,
+                                                              float alpha) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * C) return;
     const long r = i / C;
     const int c = i - r * C;
-    const float v = x[i] * (cs ? cs[(r / rpb) * C + c] : 1.f);
+    const float v = alpha * x[i] * (cs ? cs[(r / rpb) * C + c] : 1.f);
     if (out32) out32[i] = v;
     const __half h = __float2half(v);
     hi[i] = h;
@@ -164,16 +166,17 @@ __global__ __launch_bounds__(256) void colscale_split_kernel(const float* __rest
 
 // ---------------------------------------------------------------------------------------------
 extern "C" int wc_transpose_f16(const void* src, int src_f32, long ld, long sSrc, void* hi, void* lo, long ldo,
-                                int batch, int R, int C, float scale, void* stream) {
-    WC_CHECK_ARG(src && hi && batch > 0 && R > 0 && C > 0 && ld >= C && ldo >= (long)batch * R && batch <= 65535,
+                                long oR, int batch, int R, int C, float scale, void* stream) {
+    WC_CHECK_ARG(src && hi && batch > 0 && R > 0 && C > 0 && ld >= C && oR >= R && ldo >= (long)(batch - 1) * oR + R &&
+                     batch <= 65535,
                  "wc_transpose_f16: bad argument");
     dim3 grid(wc_cdiv(R, 64), wc_cdiv(C, 64), batch);
     if (src_f32)
         hipLaunchKernelGGL(transpose_f16_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, ld,
-                           sSrc, (__half*)hi, (__half*)lo, ldo, R, C, scale);
+                           sSrc, (__half*)hi, (__half*)lo, ldo, oR, R, C, scale);
     else
         hipLaunchKernelGGL(transpose_f16_kernel<__half>, grid, dim3(256), 0, (hipStream_t)stream, (const __half*)src,
-                           ld, sSrc, (__half*)hi, (__half*)lo, ldo, R, C, scale);
+                           ld, sSrc, (__half*)hi, (__half*)lo, ldo, oR, R, C, scale);
     WC_LAUNCH_CHECK("transpose_f16_kernel");
     return WC_OK;
 }
@@ -217,20 +220,20 @@ extern "C" int wc_layernorm_bwd(const float* dy, const float* x, const float* w,
     return WC_OK;
 }
 
-extern "C" int wc_sigmoid_gram_bwd(const float* dAP, const float* AP, void* hi, void* lo, int B, int n, float scale,
-                                   void* stream) {
-    WC_CHECK_ARG(dAP && AP && hi && B > 0 && n > 0 && n <= 65535, "wc_sigmoid_gram_bwd: bad argument");
+extern "C" int wc_sigmoid_gram_bwd(const float* dAP, const float* AP, void* hi, void* lo, int B, int n, int ldo,
+                                   float scale, void* stream) {
+    WC_CHECK_ARG(dAP && AP && hi && B > 0 && n > 0 && n <= 65535 && ldo >= n, "wc_sigmoid_gram_bwd: bad argument");
     hipLaunchKernelGGL(sigmoid_gram_bwd_kernel, dim3(wc_cdiv(n, 256), n, B), dim3(256), 0, (hipStream_t)stream, dAP, AP,
-                       (__half*)hi, (__half*)lo, n, scale);
+                       (__half*)hi, (__half*)lo, n, ldo, scale);
     WC_LAUNCH_CHECK("sigmoid_gram_bwd_kernel");
     return WC_OK;
 }
 
 extern "C" int wc_colscale_split(const float* x, const float* cs, float* out32, void* hi, void* lo, long rows, int C,
-                                 int rows_per_batch, void* stream) {
+                                 int rows_per_batch, float alpha, void* stream) {
     WC_CHECK_ARG(x && hi && rows > 0 && C > 0 && rows_per_batch > 0, "wc_colscale_split: bad argument");
     hipLaunchKernelGGL(colscale_split_kernel, dim3(wc_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, x, cs,
-                       out32, (__half*)hi, (__half*)lo, rows, C, rows_per_batch);
+                       out32, (__half*)hi, (__half*)lo, rows, C, rows_per_batch, alpha);
     WC_LAUNCH_CHECK("colscale_split_kernel");
     return WC_OK;
 }

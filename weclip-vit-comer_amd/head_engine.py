@@ -1,0 +1,262 @@
+"""Adapters + decoder + attn_pred on the HIP path, forward AND backward.
+
+reference forward: WeCLIP_model/segformer_head.py:69-80, WeCLIP_model/Decoder/TransDecoder.py:113-125,
+WeCLIP_model/model_attn_aff_voc.py:134-137; the reference backward is torch.autograd over those.
+Here both directions are explicit launches of the MFMA GEMM (csrc/gemm.hip), LayerNorm
+(norm.hip / train_ops.hip), flash attention forward/backward (attention.hip / attention_bwd.hip)
+and small reductions; `HeadFunction` exposes the pair to autograd so `loss.backward()` fills
+`.grad` of the unchanged nn.Module parameters.
+
+Gradients travel multiplied by GRAD_SCALE (a power of two) because they are MFMA operands in
+fp16 (hi[+lo]); parameter gradients are unscaled in the last epilogue.
+Weight gradients dW = dY^T X use the same TN GEMM on transposed fp16 copies of dY and X
+(tokens become the K dimension, zero padded to a multiple of 64).
+"""
+import torch
+
+from . import config, ops
+from .clip import vit_engine as VE
+from .ops import F16, F32, Split
+
+GRAD_SCALE = 4096.0
+
+
+def _f(p):
+    return p.detach().float().contiguous()
+
+
+def _wT(w, with_lo):
+    """fp16 operand of W^T (K-contiguous for dX = dY W)."""
+    return ops.split_f16(w.detach().float().t().contiguous(), with_lo=with_lo)
+
+
+class HeadEngine:
+    def __init__(self, fuse, dec):
+        self.fuse, self.dec = fuse, dec
+        self.E = dec.linear_pred.weight.shape[1]
+        self.nc = dec.linear_pred.weight.shape[0]
+        self.index = fuse.indexes
+
+    def params(self):
+        return list(self.fuse.parameters()) + list(self.dec.parameters())
+
+    def param_names(self):
+        return ["fuse." + n for n, _ in self.fuse.named_parameters()] + \
+               ["dec." + n for n, _ in self.dec.named_parameters()]
+
+    # ------------------------------------------------------------------------------ forward
+    def forward(self, xs, B, Lq, h, w, drop_scale=None):
+        """xs: `index` Splits of the encoder block outputs (B*L, C) fp16 (CLS row first per image).
+        drop_scale (B, E) f32 = Dropout2d mask / (1 - p) or None.  Returns (seg, attn_pred, ctx)."""
+        ex = config.exact()
+        E, hw, M = self.E, h * w, B * h * w
+        C = xs[0].hi.shape[1]
+        dev = xs[0].hi.device
+        n = self.index
+        ctx = dict(B=B, L=Lq, h=h, w=w, xs=xs, drop=drop_scale, ex=ex)
+        # adapters: t1 = relu(X W1^T + b1); cat[:, l] = t1 W2^T + b2
+        cat = Split(torch.empty(M, n * E, device=dev, dtype=F16), torch.empty(M, n * E, device=dev, dtype=F16) if ex else None)
+        t1s = []
+        for l, mlp in enumerate(self.fuse.linears_modulelist):
+            a = Split(xs[l].hi.view(-1)[C:], xs[l].lo.view(-1)[C:] if (ex and xs[l].lo is not None) else None)
+            t1 = Split(torch.empty(M, E, device=dev, dtype=F16), torch.empty(M, E, device=dev, dtype=F16) if ex else None)
+            ops.gemm(a, ops.split_f16(mlp.proj.weight, ex), hw, E, C, bias=_f(mlp.proj.bias), out16=t1.hi, out16lo=t1.lo,
+                     act=2, batch=B, sA=Lq * C, sW=0, sC=hw * E)
+            ops.gemm(t1, ops.split_f16(mlp.proj_2.weight, ex), M, E, E, bias=_f(mlp.proj_2.bias),
+                     out16=cat.hi.view(-1)[l * E:], out16lo=cat.lo.view(-1)[l * E:] if ex else None, ldc=n * E)
+            t1s.append(t1)
+        # fuse (1x1 conv) + Dropout2d
+        F32_ = torch.empty(M, E, device=dev, dtype=F32)
+        Fh = Split(torch.empty(M, E, device=dev, dtype=F16), torch.empty(M, E, device=dev, dtype=F16) if ex else None)
+        wf = ops.split_f16(self.fuse.linear_fuse.weight.detach().flatten(1), ex)
+        ops.gemm(cat, wf, hw, E, n * E, bias=_f(self.fuse.linear_fuse.bias), out32=F32_, out16=Fh.hi, out16lo=Fh.lo,
+                 batch=B, sA=hw * n * E, sW=0, sC=hw * E, cscale=drop_scale, sCS=E)
+        ctx.update(cat=cat, t1s=t1s, F32=F32_, Fh=Fh)
+        # decoder blocks
+        x = F32_
+        blocks = []
+        for blk in self.dec.transformer.resblocks:
+            pk = VE.BlockPack(blk, exact=ex)
+            x, bc = self._block_fwd(pk, x, B, hw)
+            bc["pk"], bc["blk"] = pk, blk
+            blocks.append(bc)
+        ctx["blocks"] = blocks
+        # linear_pred (1x1 conv) on the fp16 copy of the last block output
+        x3 = blocks[-1]["x2h"]
+        seg_rows = torch.empty(M, self.nc, device=dev, dtype=F32)
+        ops.gemm(x3, ops.split_f16(self.dec.linear_pred.weight.detach().flatten(1), ex), M, self.nc, E,
+                 bias=_f(self.dec.linear_pred.bias), out32=seg_rows)
+        seg = seg_rows.view(B, h, w, self.nc).permute(0, 3, 1, 2).contiguous()
+        # attn_pred = sigmoid(F^T F) per image
+        ap = torch.empty(B, hw, hw, device=dev, dtype=F32)
+        ops.gemm(Fh, Fh, hw, hw, E, out32=ap, act=3, batch=B, sA=hw * E, sW=hw * E, sC=hw * hw)
+        ctx["ap"] = ap
+        return seg, ap, ctx
+
+    def _block_fwd(self, pk, x, B, Lq):
+        M, E, H, DH = B * Lq, pk.E, pk.H, pk.DH
+        dev = x.device
+        ex = pk.exact
+        _, a = ops.layernorm(x, pk.ln1_w, pk.ln1_b, with_lo=ex)
+        qkv = torch.empty(M, 3 * E, device=dev, dtype=F16)
+        ops.gemm(a, pk.in_w, M, 3 * E, E, bias=pk.in_b, out16=qkv, scale=ops.q_scale(DH), scale_cols=E)
+        o16, lse, _, o32 = ops.attention(qkv, B, Lq, H, DH, want_mean=False, want_o32=True)
+        x1 = torch.empty(M, E, device=dev, dtype=F32)
+        ops.gemm(o16, pk.out_w, M, E, E, bias=pk.out_b, resid=x, out32=x1, round16=True)
+        _, a2 = ops.layernorm(x1, pk.ln2_w, pk.ln2_b, with_lo=ex)
+        z = Split(torch.empty(M, 4 * E, device=dev, dtype=F16), torch.empty(M, 4 * E, device=dev, dtype=F16) if ex else None)
+        u32 = torch.empty(M, 4 * E, device=dev, dtype=F32)
+        ops.gemm(a2, pk.fc_w, M, 4 * E, E, bias=pk.fc_b, out16=z.hi, out16lo=z.lo, act=1, pre32=u32)
+        x2 = torch.empty(M, E, device=dev, dtype=F32)
+        x2h = Split(torch.empty(M, E, device=dev, dtype=F16), torch.empty(M, E, device=dev, dtype=F16) if ex else None)
+        ops.gemm(z, pk.pj_w, M, E, 4 * E, bias=pk.pj_b, resid=x1, out32=x2, out16=x2h.hi, out16lo=x2h.lo)
+        return x2, dict(x=x, a=a, qkv=qkv, o16=o16, o32=o32, lse=lse, x1=x1, a2=a2, u32=u32, z=z, x2h=x2h)
+
+    # ------------------------------------------------------------------------------ backward
+    def backward(self, ctx, dseg, dap):
+        """dseg (B,nc,h,w) / dap (B,hw,hw) fp32 (either may be None).  Returns {param name: grad}."""
+        B, h, w, ex = ctx["B"], ctx["h"], ctx["w"], ctx["ex"]
+        E, hw, M, nc, n = self.E, h * w, B * h * w, self.nc, self.index
+        dev = ctx["F32"].device
+        GS, inv = GRAD_SCALE, 1.0 / GRAD_SCALE
+        grads = {}
+        wg = lambda dyT, xT, N_, K_, Kp: self._wgrad(dyT, xT, N_, K_, Kp, inv)
+        # ---- linear_pred
+        x3h = ctx["blocks"][-1]["x2h"]
+        if dseg is not None:
+            d = torch.zeros(M, 64, device=dev, dtype=F32)
+            d[:, :nc] = dseg.permute(0, 2, 3, 1).reshape(M, nc)
+            d32, dS = ops.colscale_split(d, None, M, alpha=GS)
+            wpT = torch.zeros(E, 64, device=dev, dtype=F32)
+            wpT[:, :nc] = self.dec.linear_pred.weight.detach().flatten(1).t()
+            dx = torch.empty(M, E, device=dev, dtype=F32)
+            ops.gemm(dS, ops.split_f16(wpT, ex), M, E, 64, out32=dx)
+            dT, Kp = ops.transpose_f16(d32, M, 64)
+            xT, _ = ops.transpose_f16(x3h.hi, M, E)
+            grads["dec.linear_pred.weight"] = wg(dT, xT, nc, E, Kp).view(nc, E, 1, 1)
+            grads["dec.linear_pred.bias"] = ops.colsum(d32, M, nc, ld=64, alpha=inv)
+        else:
+            dx = torch.zeros(M, E, device=dev, dtype=F32)
+            grads["dec.linear_pred.weight"] = torch.zeros(nc, E, 1, 1, device=dev)
+            grads["dec.linear_pred.bias"] = torch.zeros(nc, device=dev)
+        # ---- decoder blocks, last to first
+        for i in reversed(range(len(ctx["blocks"]))):
+            dx = self._block_bwd(ctx["blocks"][i], dx, B, hw, f"dec.transformer.resblocks.{i}.", grads, inv)
+        # ---- attn_pred = sigmoid(F^T F):  dF += (Z + Z^T) F
+        if dap is not None:
+            S = ops.sigmoid_gram_bwd(dap.contiguous(), ctx["ap"], scale=GS, with_lo=True)
+            hwp = S.hi.shape[-1]
+            FT, Kp = ops.transpose_f16(ctx["F32"], hw, E, batch=B, sSrc=hw * E, oR=hwp)   # (E, B*hwp)
+            dF = torch.empty(M, E, device=dev, dtype=F32)
+            ops.gemm(S, FT, hw, E, hwp, lda=hwp, ldw=Kp, out32=dF, resid=dx, batch=B, sA=hw * hwp, sW=hwp, sC=hw * E)
+        else:
+            dF = dx
+        # ---- Dropout2d backward + fuse
+        dFp32, dFp = ops.colscale_split(dF, ctx["drop"], hw)
+        cat = ctx["cat"]
+        dcat = Split(torch.empty(M, n * E, device=dev, dtype=F16), torch.empty(M, n * E, device=dev, dtype=F16))
+        ops.gemm(dFp, _wT(self.fuse.linear_fuse.weight.detach().flatten(1), ex), M, n * E, E, out16=dcat.hi, out16lo=dcat.lo)
+        dFT, Kp = ops.transpose_f16(dFp32, M, E)
+        catT, _ = ops.transpose_f16(cat.hi, M, n * E)
+        grads["fuse.linear_fuse.weight"] = wg(dFT, catT, E, n * E, Kp).view(E, n * E, 1, 1)
+        grads["fuse.linear_fuse.bias"] = ops.colsum(dFp32, M, E, alpha=inv)
+        # ---- adapters
+        xs, Lq = ctx["xs"], ctx["L"]
+        C = xs[0].hi.shape[1]
+        for l, mlp in enumerate(self.fuse.linears_modulelist):
+            p = f"fuse.linears_modulelist.{l}."
+            dt2 = Split(dcat.hi.view(-1)[l * E:], dcat.lo.view(-1)[l * E:])
+            t1 = ctx["t1s"][l]
+            dt1_32 = torch.empty(M, E, device=dev, dtype=F32)
+            ops.gemm(dt2, _wT(mlp.proj_2.weight, ex), M, E, E, lda=n * E, out32=dt1_32, act=5, auxh=t1.hi, ldaux=E)
+            dt2T, Kp = ops.transpose_f16(dt2.hi, M, E, ld=n * E)
+            t1T, _ = ops.transpose_f16(t1.hi, M, E)
+            grads[p + "proj_2.weight"] = wg(dt2T, t1T, E, E, Kp)
+            grads[p + "proj_2.bias"] = ops.colsum(dt2.hi, M, E, ld=n * E, alpha=inv)
+            dt1T, _ = ops.transpose_f16(dt1_32, M, E)
+            xT, _ = ops.transpose_f16(xs[l].hi.view(-1)[C:], hw, C, ld=C, batch=B, sSrc=Lq * C)
+            grads[p + "proj.weight"] = wg(dt1T, xT, E, C, Kp)
+            grads[p + "proj.bias"] = ops.colsum(dt1_32, M, E, alpha=inv)
+        return grads
+
+    @staticmethod
+    def _wgrad(dyT, xT, N_, K_, Kp, inv):
+        """dW (N_, K_) = inv * dY^T X from transposed operands (N_, Kp), (K_, Kp).
+        The output has few 128x128 tiles and a long K (all tokens), so K is split over `ns` slices
+        run as one batched GEMM (slice = z) and summed by wc_sum_slices."""
+        dev = dyT.hi.device
+        out = torch.empty(N_, K_, device=dev, dtype=F32)
+        tiles = ((N_ + 127) // 128) * ((K_ + 127) // 128)
+        ns = 1
+        while ns * 2 * tiles <= 1024 and Kp % (ns * 2 * 64) == 0 and Kp // (ns * 2) >= 256:
+            ns *= 2
+        if ns == 1:
+            ops.gemm(dyT, xT, N_, K_, Kp, out32=out, scale=inv, scale_cols=K_)
+            return out
+        part = torch.empty(ns, N_, K_, device=dev, dtype=F32)
+        ks = Kp // ns
+        ops.gemm(dyT, xT, N_, K_, ks, lda=Kp, ldw=Kp, out32=part, batch=ns, sA=ks, sW=ks, sC=N_ * K_)
+        from . import _lib as L
+        L.lib().wc_sum_slices(L.ptr(part, F32), L.ptr(out, F32), ns, N_ * K_, inv, L.stream())
+        return out
+
+    def _block_bwd(self, c, dx2, B, Lq, prefix, grads, inv):
+        pk, blk = c["pk"], c["blk"]
+        M, E, H, DH = B * Lq, pk.E, pk.H, pk.DH
+        dev = dx2.device
+        ex = pk.exact
+        wg = lambda dyT, xT, N_, K_, Kp: self._wgrad(dyT, xT, N_, K_, Kp, inv)
+        # MLP
+        _, dx2s = ops.colscale_split(dx2, None, M, want32=False)
+        du = Split(torch.empty(M, 4 * E, device=dev, dtype=F16), torch.empty(M, 4 * E, device=dev, dtype=F16))
+        ops.gemm(dx2s, _wT(blk.mlp.c_proj.weight, ex), M, 4 * E, E, out16=du.hi, out16lo=du.lo, act=4, aux=c["u32"],
+                 ldaux=4 * E, rpg=1)
+        dx2T, Kp = ops.transpose_f16(dx2, M, E)
+        zT, _ = ops.transpose_f16(c["z"].hi, M, 4 * E)
+        grads[prefix + "mlp.c_proj.weight"] = wg(dx2T, zT, E, 4 * E, Kp)
+        grads[prefix + "mlp.c_proj.bias"] = ops.colsum(dx2, M, E, alpha=inv)
+        da2 = torch.empty(M, E, device=dev, dtype=F32)
+        ops.gemm(du, _wT(blk.mlp.c_fc.weight, ex), M, E, 4 * E, out32=da2)
+        duT, _ = ops.transpose_f16(du.hi, M, 4 * E)
+        a2T, _ = ops.transpose_f16(c["a2"].hi, M, E)
+        grads[prefix + "mlp.c_fc.weight"] = wg(duT, a2T, 4 * E, E, Kp)
+        grads[prefix + "mlp.c_fc.bias"] = ops.colsum(du.hi, M, 4 * E, alpha=inv)
+        dx1, g16, dgb2 = ops.layernorm_bwd(da2, c["x1"], pk.ln2_w, add=dx2, want32=True, want16=True, alpha=inv)
+        grads[prefix + "ln_2.weight"], grads[prefix + "ln_2.bias"] = dgb2[0], dgb2[1]
+        # forced-fp16 out-projection (clip/myAtt.py:321): gradient rounded to fp16 on both sides
+        do16 = torch.empty(M, E, device=dev, dtype=F16)
+        ops.gemm(g16, _wT(blk.attn.out_proj.weight, False), M, E, E, out16=do16)
+        g16T, _ = ops.transpose_f16(g16, M, E)
+        o16T, _ = ops.transpose_f16(c["o16"], M, E)
+        grads[prefix + "attn.out_proj.weight"] = wg(g16T, o16T, E, E, Kp)
+        grads[prefix + "attn.out_proj.bias"] = ops.colsum(g16, M, E, alpha=inv)
+        # attention + in-projection
+        dqkv = ops.attention_bwd(c["qkv"], do16, c["o32"], c["lse"], B, Lq, H, DH, with_lo=True)
+        da = torch.empty(M, E, device=dev, dtype=F32)
+        ops.gemm(dqkv, _wT(blk.attn.in_proj_weight, ex), M, E, 3 * E, out32=da)
+        dqT, _ = ops.transpose_f16(dqkv.hi, M, 3 * E)
+        aT, _ = ops.transpose_f16(c["a"].hi, M, E)
+        grads[prefix + "attn.in_proj_weight"] = wg(dqT, aT, 3 * E, E, Kp)
+        grads[prefix + "attn.in_proj_bias"] = ops.colsum(dqkv.hi, M, 3 * E, alpha=inv)
+        dx, _, dgb1 = ops.layernorm_bwd(da, c["x"], pk.ln1_w, add=dx1, want32=True, alpha=inv)
+        grads[prefix + "ln_1.weight"], grads[prefix + "ln_1.bias"] = dgb1[0], dgb1[1]
+        return dx
+
+
+class HeadFunction(torch.autograd.Function):
+    """autograd bridge: (params...) -> (seg, attn_pred); backward = HeadEngine.backward."""
+
+    @staticmethod
+    def forward(ctx, engine, xs, B, Lq, h, w, drop_scale, *params):
+        seg, ap, c = engine.forward(xs, B, Lq, h, w, drop_scale)
+        ctx.engine, ctx.c = engine, c
+        return seg, ap
+
+    @staticmethod
+    def backward(ctx, dseg, dap):
+        eng = ctx.engine
+        g = eng.backward(ctx.c, dseg.contiguous() if dseg is not None else None,
+                         dap.contiguous() if dap is not None else None)
+        out = [g[n].reshape(p.shape) for n, p in zip(eng.param_names(), eng.params())]
+        ctx.c = None
+        return (None,) * 7 + tuple(out)

@@ -164,19 +164,20 @@ def attention_bwd(qkv16, do16, o32, lse, B, Lq, H, DH, with_lo=True):
     return d
 
 
-def transpose_f16(src, R, C, *, ld=None, batch=1, sSrc=0, with_lo=False, scale=1.0):
+def transpose_f16(src, R, C, *, ld=None, batch=1, sSrc=0, with_lo=False, scale=1.0, oR=None):
     """out (C, Kp) fp16 with out[c, b*R + r] = scale*src[b, r, c]; Kp = batch*R rounded up to 64
     (zero padded) so it can be the K dimension of a weight-gradient GEMM."""
     ld = C if ld is None else ld
-    K = batch * R
-    Kp = (K + 63) // 64 * 64
+    oR = R if oR is None else oR          # output column stride between batches (>= R, zero padded)
+    K = (batch - 1) * oR + R
+    Kp = (batch * oR + 63) // 64 * 64
     dev = src.device
     alloc = torch.zeros if Kp != K else torch.empty
     hi = alloc(C, Kp, device=dev, dtype=F16)
     lo = alloc(C, Kp, device=dev, dtype=F16) if with_lo else None
     f32 = src.dtype == F32
     L.lib().wc_transpose_f16(L.ptr(src, F32 if f32 else F16, "src"), 1 if f32 else 0, ld, sSrc, L.ptr(hi), L.ptr(lo),
-                             Kp, batch, R, C, float(scale), L.stream())
+                             Kp, oR, batch, R, C, float(scale), L.stream())
     return Split(hi, lo), Kp
 
 
@@ -206,19 +207,22 @@ def layernorm_bwd(dy, x, w, *, add=None, want32=True, want16=False, out_scale=1.
 
 
 def sigmoid_gram_bwd(dAP, AP, scale=1.0, with_lo=True):
+    """-> Split (B, n, np): rows zero padded to np = ceil64(n) so n can be a GEMM K dimension."""
     B, n, _ = AP.shape
-    s = Split(torch.empty(B, n, n, device=AP.device, dtype=F16),
-              torch.empty(B, n, n, device=AP.device, dtype=F16) if with_lo else None)
-    L.lib().wc_sigmoid_gram_bwd(L.ptr(dAP, F32, "dAP"), L.ptr(AP, F32, "AP"), L.ptr(s.hi), L.ptr(s.lo), B, n,
+    np_ = (n + 63) // 64 * 64
+    alloc = torch.zeros if np_ != n else torch.empty
+    s = Split(alloc(B, n, np_, device=AP.device, dtype=F16),
+              alloc(B, n, np_, device=AP.device, dtype=F16) if with_lo else None)
+    L.lib().wc_sigmoid_gram_bwd(L.ptr(dAP, F32, "dAP"), L.ptr(AP, F32, "AP"), L.ptr(s.hi), L.ptr(s.lo), B, n, np_,
                                 float(scale), L.stream())
     return s
 
 
-def colscale_split(x, cs, rows_per_batch, want32=True, with_lo=True):
+def colscale_split(x, cs, rows_per_batch, want32=True, with_lo=True, alpha=1.0):
     rows, C = x.shape
     dev = x.device
     out32 = torch.empty(rows, C, device=dev, dtype=F32) if want32 else None
     s = Split(torch.empty(rows, C, device=dev, dtype=F16), torch.empty(rows, C, device=dev, dtype=F16) if with_lo else None)
     L.lib().wc_colscale_split(L.ptr(x, F32, "x"), L.ptr(cs, F32, "cs"), L.ptr(out32), L.ptr(s.hi), L.ptr(s.lo), rows, C,
-                              rows_per_batch, L.stream())
+                              rows_per_batch, float(alpha), L.stream())
     return out32, s
