@@ -55,6 +55,11 @@ int wc_par_labels(const float* masks, const int64_t* valid_key, const int* nch, 
  * src (planes,Hs,Ws) f32 -> dst (planes,Hd,Wd) f32. */
 int wc_bilinear_resize(const float* src, float* dst, int planes, int Hs, int Ws, int Hd, int Wd,
                        int align_corners, void* stream);
+/* backward of the same (up-sampling): gsrc (planes,Hs,Ws) = sum over destination pixels of their
+ * gradient gdst (planes,Hd,Wd) times the interpolation weight; gather form, no atomics
+ * (autograd of F.interpolate at scripts/dist_clip_voc.py:250). */
+int wc_bilinear_resize_bwd(const float* gdst, float* gsrc, int planes, int Hs, int Ws, int Hd, int Wd,
+                           int align_corners, void* stream);
 
 /* ---- MFMA GEMM ------------------------------------------------------------------------ */
 /* C[M,N] = epilogue(sum_{s<nseg} A_s[M,K] * W_s[N,K]^T), fp16 operands (K contiguous), fp32

@@ -132,9 +132,10 @@ class HeadEngine:
             dx = torch.empty(M, E, device=dev, dtype=F32)
             ops.gemm(dS, ops.split_f16(wpT, ex), M, E, 64, out32=dx)
             dT, Kp = ops.transpose_f16(d32, M, 64)
-            xT, _ = ops.transpose_f16(x3h.hi, M, E)
-            grads["dec.linear_pred.weight"] = wg(dT, xT, nc, E, Kp).view(nc, E, 1, 1)
-            grads["dec.linear_pred.bias"] = ops.colsum(d32, M, nc, ld=64, alpha=inv)
+            xT, _ = ops.transpose_f16(x3h.hi, M, E, ones_row=True)
+            g = wg(dT, xT, nc, E, Kp)
+            grads["dec.linear_pred.weight"] = g[:, :E].reshape(nc, E, 1, 1)
+            grads["dec.linear_pred.bias"] = g[:, E]
         else:
             dx = torch.zeros(M, E, device=dev, dtype=F32)
             grads["dec.linear_pred.weight"] = torch.zeros(nc, E, 1, 1, device=dev)
@@ -157,9 +158,10 @@ class HeadEngine:
         dcat = Split(torch.empty(M, n * E, device=dev, dtype=F16), torch.empty(M, n * E, device=dev, dtype=F16))
         ops.gemm(dFp, _wT(self.fuse.linear_fuse.weight.detach().flatten(1), ex), M, n * E, E, out16=dcat.hi, out16lo=dcat.lo)
         dFT, Kp = ops.transpose_f16(dFp32, M, E)
-        catT, _ = ops.transpose_f16(cat.hi, M, n * E)
-        grads["fuse.linear_fuse.weight"] = wg(dFT, catT, E, n * E, Kp).view(E, n * E, 1, 1)
-        grads["fuse.linear_fuse.bias"] = ops.colsum(dFp32, M, E, alpha=inv)
+        catT, _ = ops.transpose_f16(cat.hi, M, n * E, ones_row=True)
+        g = wg(dFT, catT, E, n * E, Kp)
+        grads["fuse.linear_fuse.weight"] = g[:, :n * E].reshape(E, n * E, 1, 1)
+        grads["fuse.linear_fuse.bias"] = g[:, n * E]
         # ---- adapters
         xs, Lq = ctx["xs"], ctx["L"]
         C = xs[0].hi.shape[1]
@@ -170,13 +172,13 @@ class HeadEngine:
             dt1_32 = torch.empty(M, E, device=dev, dtype=F32)
             ops.gemm(dt2, _wT(mlp.proj_2.weight, ex), M, E, E, lda=n * E, out32=dt1_32, act=5, auxh=t1.hi, ldaux=E)
             dt2T, Kp = ops.transpose_f16(dt2.hi, M, E, ld=n * E)
-            t1T, _ = ops.transpose_f16(t1.hi, M, E)
-            grads[p + "proj_2.weight"] = wg(dt2T, t1T, E, E, Kp)
-            grads[p + "proj_2.bias"] = ops.colsum(dt2.hi, M, E, ld=n * E, alpha=inv)
+            t1T, _ = ops.transpose_f16(t1.hi, M, E, ones_row=True)
+            g = wg(dt2T, t1T, E, E, Kp)
+            grads[p + "proj_2.weight"], grads[p + "proj_2.bias"] = g[:, :E], g[:, E]
             dt1T, _ = ops.transpose_f16(dt1_32, M, E)
-            xT, _ = ops.transpose_f16(xs[l].hi.view(-1)[C:], hw, C, ld=C, batch=B, sSrc=Lq * C)
-            grads[p + "proj.weight"] = wg(dt1T, xT, E, C, Kp)
-            grads[p + "proj.bias"] = ops.colsum(dt1_32, M, E, alpha=inv)
+            xT, _ = ops.transpose_f16(xs[l].hi.view(-1)[C:], hw, C, ld=C, batch=B, sSrc=Lq * C, ones_row=True)
+            g = wg(dt1T, xT, E, C, Kp)
+            grads[p + "proj.weight"], grads[p + "proj.bias"] = g[:, :C], g[:, C]
         return grads
 
     @staticmethod
@@ -185,6 +187,7 @@ class HeadEngine:
         The output has few 128x128 tiles and a long K (all tokens), so K is split over `ns` slices
         run as one batched GEMM (slice = z) and summed by wc_sum_slices."""
         dev = dyT.hi.device
+        K_ = xT.hi.shape[0]                 # K_ + 1 when xT carries the ones row (bias gradient column)
         out = torch.empty(N_, K_, device=dev, dtype=F32)
         tiles = ((N_ + 127) // 128) * ((K_ + 127) // 128)
         ns = 1
@@ -212,32 +215,32 @@ class HeadEngine:
         ops.gemm(dx2s, _wT(blk.mlp.c_proj.weight, ex), M, 4 * E, E, out16=du.hi, out16lo=du.lo, act=4, aux=c["u32"],
                  ldaux=4 * E, rpg=1)
         dx2T, Kp = ops.transpose_f16(dx2, M, E)
-        zT, _ = ops.transpose_f16(c["z"].hi, M, 4 * E)
-        grads[prefix + "mlp.c_proj.weight"] = wg(dx2T, zT, E, 4 * E, Kp)
-        grads[prefix + "mlp.c_proj.bias"] = ops.colsum(dx2, M, E, alpha=inv)
+        zT, _ = ops.transpose_f16(c["z"].hi, M, 4 * E, ones_row=True)
+        g = wg(dx2T, zT, E, 4 * E, Kp)
+        grads[prefix + "mlp.c_proj.weight"], grads[prefix + "mlp.c_proj.bias"] = g[:, :4 * E], g[:, 4 * E]
         da2 = torch.empty(M, E, device=dev, dtype=F32)
         ops.gemm(du, _wT(blk.mlp.c_fc.weight, ex), M, E, 4 * E, out32=da2)
         duT, _ = ops.transpose_f16(du.hi, M, 4 * E)
-        a2T, _ = ops.transpose_f16(c["a2"].hi, M, E)
-        grads[prefix + "mlp.c_fc.weight"] = wg(duT, a2T, 4 * E, E, Kp)
-        grads[prefix + "mlp.c_fc.bias"] = ops.colsum(du.hi, M, 4 * E, alpha=inv)
+        a2T, _ = ops.transpose_f16(c["a2"].hi, M, E, ones_row=True)
+        g = wg(duT, a2T, 4 * E, E, Kp)
+        grads[prefix + "mlp.c_fc.weight"], grads[prefix + "mlp.c_fc.bias"] = g[:, :E], g[:, E]
         dx1, g16, dgb2 = ops.layernorm_bwd(da2, c["x1"], pk.ln2_w, add=dx2, want32=True, want16=True, alpha=inv)
         grads[prefix + "ln_2.weight"], grads[prefix + "ln_2.bias"] = dgb2[0], dgb2[1]
         # forced-fp16 out-projection (clip/myAtt.py:321): gradient rounded to fp16 on both sides
         do16 = torch.empty(M, E, device=dev, dtype=F16)
         ops.gemm(g16, _wT(blk.attn.out_proj.weight, False), M, E, E, out16=do16)
         g16T, _ = ops.transpose_f16(g16, M, E)
-        o16T, _ = ops.transpose_f16(c["o16"], M, E)
-        grads[prefix + "attn.out_proj.weight"] = wg(g16T, o16T, E, E, Kp)
-        grads[prefix + "attn.out_proj.bias"] = ops.colsum(g16, M, E, alpha=inv)
+        o16T, _ = ops.transpose_f16(c["o16"], M, E, ones_row=True)
+        g = wg(g16T, o16T, E, E, Kp)
+        grads[prefix + "attn.out_proj.weight"], grads[prefix + "attn.out_proj.bias"] = g[:, :E], g[:, E]
         # attention + in-projection
         dqkv = ops.attention_bwd(c["qkv"], do16, c["o32"], c["lse"], B, Lq, H, DH, with_lo=True)
         da = torch.empty(M, E, device=dev, dtype=F32)
         ops.gemm(dqkv, _wT(blk.attn.in_proj_weight, ex), M, E, 3 * E, out32=da)
         dqT, _ = ops.transpose_f16(dqkv.hi, M, 3 * E)
-        aT, _ = ops.transpose_f16(c["a"].hi, M, E)
-        grads[prefix + "attn.in_proj_weight"] = wg(dqT, aT, 3 * E, E, Kp)
-        grads[prefix + "attn.in_proj_bias"] = ops.colsum(dqkv.hi, M, 3 * E, alpha=inv)
+        aT, _ = ops.transpose_f16(c["a"].hi, M, E, ones_row=True)
+        g = wg(dqT, aT, 3 * E, E, Kp)
+        grads[prefix + "attn.in_proj_weight"], grads[prefix + "attn.in_proj_bias"] = g[:, :E], g[:, E]
         dx, _, dgb1 = ops.layernorm_bwd(da, c["x"], pk.ln1_w, add=dx1, want32=True, alpha=inv)
         grads[prefix + "ln_1.weight"], grads[prefix + "ln_1.bias"] = dgb1[0], dgb1[1]
         return dx

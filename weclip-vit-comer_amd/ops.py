@@ -164,7 +164,7 @@ def attention_bwd(qkv16, do16, o32, lse, B, Lq, H, DH, with_lo=True):
     return d
 
 
-def transpose_f16(src, R, C, *, ld=None, batch=1, sSrc=0, with_lo=False, scale=1.0, oR=None):
+def transpose_f16(src, R, C, *, ld=None, batch=1, sSrc=0, with_lo=False, scale=1.0, oR=None, ones_row=False):
     """out (C, Kp) fp16 with out[c, b*R + r] = scale*src[b, r, c]; Kp = batch*R rounded up to 64
     (zero padded) so it can be the K dimension of a weight-gradient GEMM."""
     ld = C if ld is None else ld
@@ -172,9 +172,14 @@ def transpose_f16(src, R, C, *, ld=None, batch=1, sSrc=0, with_lo=False, scale=1
     K = (batch - 1) * oR + R
     Kp = (batch * oR + 63) // 64 * 64
     dev = src.device
-    alloc = torch.zeros if Kp != K else torch.empty
-    hi = alloc(C, Kp, device=dev, dtype=F16)
-    lo = alloc(C, Kp, device=dev, dtype=F16) if with_lo else None
+    alloc = torch.zeros if (Kp != K or ones_row) else torch.empty
+    rows = C + 1 if ones_row else C     # optional extra row of ones: dY^T [X | 1] yields the bias gradient too
+    hi = alloc(rows, Kp, device=dev, dtype=F16)
+    lo = alloc(rows, Kp, device=dev, dtype=F16) if with_lo else None
+    if ones_row:
+        if oR != R:
+            raise RuntimeError("ones_row needs densely packed batches")
+        hi[C, :K] = 1.0
     f32 = src.dtype == F32
     L.lib().wc_transpose_f16(L.ptr(src, F32 if f32 else F16, "src"), 1 if f32 else 0, ld, sSrc, L.ptr(hi), L.ptr(lo),
                              Kp, oR, batch, R, C, float(scale), L.stream())

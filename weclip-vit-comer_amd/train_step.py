@@ -64,7 +64,11 @@ class TrainStep:
         return self._mask[key]
 
     def losses(self, seg, cam, attn_pred):
-        segs = F.interpolate(seg, size=cam.shape[1:], mode="bilinear", align_corners=False)
+        if seg.is_cuda:
+            from .resize import bilinear_upsample
+            segs = bilinear_upsample(seg, cam.shape[1:], align_corners=False)
+        else:
+            segs = F.interpolate(seg, size=cam.shape[1:], mode="bilinear", align_corners=False)
         h, w = cam.shape[1] // 16, cam.shape[2] // 16
         aff_label = cams_to_affinity_label(cam, mask=self.mask(h, w, cam.device), ignore_index=self.ignore)
         attn_loss, _, _ = get_aff_loss(attn_pred, aff_label)
