@@ -126,13 +126,23 @@ def main():
     summ = ops.KernelTimer.summary()
     peaks = {"gemm_f16_kernel": ("mfma", 2500.0, "TFLOP/s"), "attn_fwd_kernel": ("mfma", 2500.0, "TFLOP/s"),
              "attn_mean_kernel": ("mfma", 2500.0, "TFLOP/s"), "par_iter_kernel": ("hbm", 8000.0, "GB/s")}
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
+    # (tools/pmc_traffic.py -> profiles/r01_traffic.json; 2*FETCH_SIZE + WRITE_SIZE, KiB, per the MI355X guide)
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tpath) and B == 16 and S == 512 and K == 2:
+        t = json.load(open(tpath))
+        for short, full in (("gemm_f16_kernel", "gemm_f16_kernel<false>"), ("par_iter_kernel", "par_iter_kernel<3>"),
+                            ("attn_fwd_kernel", "attn_fwd_kernel<64>"), ("attn_mean_kernel", "attn_mean_kernel<64>")):
+            if full in t:
+                traffic[short] = round(t[full]["hbm_bytes_per_launch"])
     roofs = []
     for name, r in summ.items():
         bound, peak, unit = peaks[name]
         sec = r["ms"] * 1e-3
         ach = r["work"] / sec / (1e12 if bound == "mfma" else 1e9)
         roofs.append({"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                      "frac": round(ach / peak, 4), "traffic": None, "launches": r["launches"],
+                      "frac": round(ach / peak, 4), "traffic": traffic.get(name), "launches": r["launches"],
                       "avg_launch_us": round(r["ms"] * 1e3 / max(r["launches"], 1), 2),
                       "share_of_step": round(r["ms"] * 1e-3 / dt, 4)})
     roofs.sort(key=lambda x: -x["share_of_step"])

@@ -65,7 +65,8 @@ class PAR(nn.Module):
                                self.num_iter, group, L.stream())
         # algorithmic bytes: (T + 2C) planes per iteration + (3 + T) planes for the affinity set-up
         KernelTimer.stop("par_iter_kernel", t0,
-                         4.0 * b * h * w * ((T + 2 * C) * self.num_iter + 3 + T), launches=self.num_iter)
+                         4.0 * b * h * w * ((T + 2 * C) * self.num_iter + 3 + T),
+                         launches=self.num_iter * ((b + group - 1) // group))
         return out
 
 

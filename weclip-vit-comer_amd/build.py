@@ -61,9 +61,9 @@ def build(force=False, verbose=True):
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
         if verbose:
-            print(f"[build] linked {LIB} from {len(objs)} objects")
+            print(f"[build] linked {LIB} from {len(objs)} objects", file=sys.stderr)
     elif verbose:
-        print(f"[build] {LIB} up to date")
+        print(f"[build] {LIB} up to date", file=sys.stderr)
     return LIB
 
 

@@ -38,18 +38,22 @@ __global__ __launch_bounds__(256) void head_transpose_kernel(const __half* __res
 
 __global__ __launch_bounds__(256) void attn_delta_rows_kernel(const __half* __restrict__ dO, const float* __restrict__ o32,
                                                                float* __restrict__ delta, int L, int H, int DH, long total) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;   // over (b, q, h)
-    if (i >= total) return;
-    const int h = i % H;
-    const long bq = i / H;
-    const int q = bq % L;
-    const long b = bq / L;
+    // one wave per token row (b, q): coalesced E-wide reads, segmented shuffle reduction per head
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= total) return;
+    const int lane = threadIdx.x & 63;
+    const int q = row % L;
+    const long b = row / L;
     const int E = H * DH;
-    const __half* a = dO + bq * E + h * DH;
-    const float* o = o32 + bq * E + h * DH;
-    float s = 0.f;
-    for (int d = 0; d < DH; ++d) s = fmaf(__half2float(a[d]), o[d], s);
-    delta[(b * H + h) * L + q] = s;
+    const __half* a = dO + row * E;
+    const float* o = o32 + row * E;
+    for (int e0 = 0; e0 < E; e0 += 64) {
+        float s = __half2float(a[e0 + lane]) * o[e0 + lane];
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
+        if (DH == 64) s += __shfl_xor(s, 32, 64);
+        if ((lane & (DH - 1)) == 0) delta[(b * H + (e0 + lane) / DH) * L + q] = s;
+    }
 }
 
 __device__ __forceinline__ void store_split4(__half* hi, __half* lo, const float* v) {
@@ -369,8 +373,8 @@ extern "C" int wc_attn_bwd(const void* qkv, const void* dO, const float* o32, co
     hipLaunchKernelGGL(head_transpose_kernel, tg, dim3(256), 0, st, (const __half*)qkv, 3L * E, E, (__half*)kt, L, Lp, H, DH);
     hipLaunchKernelGGL(head_transpose_kernel, tg, dim3(256), 0, st, (const __half*)dO, (long)E, 0, (__half*)dot, L, Lp, H, DH);
     WC_LAUNCH_CHECK("head_transpose_kernel");
-    const long total = (long)B * L * H;
-    hipLaunchKernelGGL(attn_delta_rows_kernel, dim3(wc_cdiv(total, 256)), dim3(256), 0, st, (const __half*)dO, o32, delta,
+    const long total = (long)B * L;
+    hipLaunchKernelGGL(attn_delta_rows_kernel, dim3(wc_cdiv(total, 4)), dim3(256), 0, st, (const __half*)dO, o32, delta,
                        L, H, DH, total);
     WC_LAUNCH_CHECK("attn_delta_rows_kernel");
     dim3 grid(wc_cdiv(L, 128), H, B);

@@ -212,23 +212,28 @@ __global__ __launch_bounds__(256) void ln2_bwd_add_kernel(const float* __restric
     }
 }
 
-// (h) delta[p,h,q] = sum_d dO[p,q,h,d] * O[img,q,h,d]
+// (h) delta[p,h,q] = sum_d dO[p,q,h,d] * O[img,q,h,d].  One wave per token row (coalesced reads of the
+//     whole E-wide row), segmented shuffle reduction per head (DH = 32 or 64).
 __global__ __launch_bounds__(256) void attn_delta_kernel(const __half* __restrict__ dO,
                                                           const float* __restrict__ o32,
                                                           const int* __restrict__ pair_img,
                                                           float* __restrict__ delta, int L, int H, int DH,
                                                           long total) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;   // over (p, q, h)
-    if (i >= total) return;
-    const int h = i % H;
-    const long pq = i / H;
-    const int q = pq % L, p = pq / L;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // over (p, q)
+    if (row >= total) return;
+    const int lane = threadIdx.x & 63;
+    const int q = row % L;
+    const long p = row / L;
     const int E = H * DH;
-    const __half* a = dO + ((long)p * L + q) * E + h * DH;
-    const float* b = o32 + ((long)pair_img[p] * L + q) * E + h * DH;
-    float s = 0.f;
-    for (int d = 0; d < DH; ++d) s = fmaf(__half2float(a[d]), b[d], s);
-    delta[((long)p * H + h) * L + q] = s;
+    const __half* a = dO + row * E;
+    const float* b = o32 + ((long)pair_img[p] * L + q) * E;
+    for (int e0 = 0; e0 < E; e0 += 64) {
+        float s = __half2float(a[e0 + lane]) * b[e0 + lane];
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
+        if (DH == 64) s += __shfl_xor(s, 32, 64);
+        if ((lane & (DH - 1)) == 0) delta[(p * H + (e0 + lane) / DH) * L + q] = s;
+    }
 }
 
 // (i) u[p,h,l] = sum_q dS[q,l];  column 0:  dS0[p,h,q] = dS[q,0], P0[p,h,q] = P[q,0].
@@ -511,8 +516,8 @@ extern "C" int wc_attn_bwd_colsum(const void* qkv, const void* dO, const float* 
     WC_CHECK_ARG(P <= 65535 && H <= 65535, "wc_attn_bwd_colsum: too many pairs/heads for one launch");
     hipStream_t st = (hipStream_t)stream;
     const int E = H * DH;
-    const long total = (long)P * L * H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(wc_cdiv(total, 256)), dim3(256), 0, st, (const __half*)dO, o32,
+    const long total = (long)P * L;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(wc_cdiv(total, 4)), dim3(256), 0, st, (const __half*)dO, o32,
                        pair_img, delta, L, H, DH, total);
     WC_LAUNCH_CHECK("attn_delta_kernel");
     dim3 grid(wc_cdiv(L, 128), H, P);
