@@ -216,6 +216,18 @@ int wc_sigmoid_gram_bwd(const float* dAP, const float* AP, void* hi, void* lo, i
 int wc_colscale_split(const float* x, const float* cs, float* out32, void* hi, void* lo, long rows, int C,
                       int rows_per_batch, float alpha, void* stream);
 
+/* ---- ViT-CoMer: multi-scale deformable attention core ---------------------------------- */
+/* No reference code exists for the CoMer inserts (paper ViT_CoMer.pdf 3.3 / Deformable-DETR eq. 2-3).
+ * value (N,S,M,D) f32, S = sum_l H_l*W_l (h_shapes: HOST array of n_levels (H,W) pairs);
+ * loc (N,Lq,M,nL,P,2) f32 in [0,1] as (x,y); attn (N,Lq,M,nL,P) f32; out (N,Lq,M*D) f32:
+ * out = sum_l sum_p attn * bilinear_zero_pad(value_l, loc*size - 0.5).
+ * wc_msda_bwd: gvalue (ZERO-INITIALISED by the caller, accumulated with atomics), gloc, gattn. */
+int wc_msda_fwd(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
+                float* out, int N, int Lq, int M, int D, int P, void* stream);
+int wc_msda_bwd(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
+                const float* gout, float* gvalue, float* gloc, float* gattn, int N, int Lq, int M, int D,
+                int P, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,185 @@
+"""ViT-CoMer feature-interaction inserts for WeCLIP.
+
+There is no CoMer code in the reference repository -- only the paper (ViT_CoMer.pdf §3.2-3.3) and
+the task brief (WeCLIP+ViT-CoMer.hwp): a CNN branch gives a {1/8, 1/16, 1/32} pyramid refined by MRFP
+(FC -> multi-kernel depth-wise conv -> FC); at the four stage ends (ViT blocks [2,5,8,11]) a
+bidirectional CTI exchanges features with the ViT branch through multi-scale deformable attention:
+  CTI-toV:  v <- v + g * MSDeformAttn(LN(v), LN(c))          (query: ViT tokens, values: pyramid)
+  CTI-toC:  c <- c + MSDeformAttn(LN(c), LN(v));  c <- c + FFN(LN(c))
+Per the brief the ViT stays frozen and the *WeCLIP adapter outputs* (256-d maps of those blocks) are
+the ViT-side features; the 8 CTI outputs (4 toV maps + 4 toC 1/16 maps) are channel-concatenated and
+fused by a 1x1 conv into the decoder input.  Everything here is trainable.  The deformable-attention
+core runs on the HIP kernels of csrc/msdeform.hip (forward gather + backward scatter); the small
+Linear / conv layers around it are stock PyTorch-ROCm modules.  Parity is pinned only against
+oracle/comer_oracle.py (no reference exists).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib as L
+
+F32 = torch.float32
+
+
+class _MSDAFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, value, loc, attn, shapes):
+        value, loc, attn = value.float().contiguous(), loc.float().contiguous(), attn.float().contiguous()
+        N, S, M, D = value.shape
+        Lq, nL, P = loc.shape[1], loc.shape[3], loc.shape[4]
+        out = torch.empty(N, Lq, M * D, device=value.device, dtype=F32)
+        hs = L.int_array([v for hw in shapes for v in hw])
+        L.lib().wc_msda_fwd(L.ptr(value, F32, "value"), hs, nL, L.ptr(loc, F32, "loc"), L.ptr(attn, F32, "attn"),
+                            L.ptr(out), N, Lq, M, D, P, L.stream())
+        ctx.save_for_backward(value, loc, attn)
+        ctx.shapes = shapes
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        value, loc, attn = ctx.saved_tensors
+        N, S, M, D = value.shape
+        Lq, nL, P = loc.shape[1], loc.shape[3], loc.shape[4]
+        gv, gl, ga = torch.zeros_like(value), torch.empty_like(loc), torch.empty_like(attn)
+        hs = L.int_array([v for hw in ctx.shapes for v in hw])
+        L.lib().wc_msda_bwd(L.ptr(value), hs, nL, L.ptr(loc), L.ptr(attn), L.ptr(gout.float().contiguous(), F32, "gout"),
+                            L.ptr(gv), L.ptr(gl), L.ptr(ga), N, Lq, M, D, P, L.stream())
+        return gv, gl, ga, None
+
+
+def ms_deform_attn_core(value, shapes, loc, attn):
+    """value (N,S,M,D), shapes [(H,W)...], loc (N,Lq,M,nL,P,2), attn (N,Lq,M,nL,P) -> (N,Lq,M*D)."""
+    L.require_gpu()
+    return _MSDAFunction.apply(value, loc, attn, tuple(tuple(s) for s in shapes))
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=3, n_heads=8, n_points=4):
+        super().__init__()
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        nn.init.zeros_(self.sampling_offsets.weight)
+        th = torch.arange(n_heads, dtype=torch.float32) * (2.0 * math.pi / n_heads)
+        grid = torch.stack([th.cos(), th.sin()], -1)
+        grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(n_heads, 1, 1, 2).repeat(1, n_levels, n_points, 1)
+        grid = grid * torch.arange(1, n_points + 1, dtype=torch.float32).view(1, 1, n_points, 1)
+        with torch.no_grad():
+            self.sampling_offsets.bias.copy_(grid.view(-1))
+        nn.init.zeros_(self.attention_weights.weight)
+        nn.init.zeros_(self.attention_weights.bias)
+
+    def forward(self, query, reference_points, feat, shapes):
+        """query (N,Lq,C); reference_points (N,Lq,nL,2) in [0,1]; feat (N,S,C), S = sum H_l*W_l."""
+        N, Lq, C = query.shape
+        M, nL, P = self.n_heads, self.n_levels, self.n_points
+        value = self.value_proj(feat).view(N, feat.shape[1], M, C // M)
+        off = self.sampling_offsets(query).view(N, Lq, M, nL, P, 2)
+        aw = F.softmax(self.attention_weights(query).view(N, Lq, M, nL * P), -1).view(N, Lq, M, nL, P)
+        norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32, device=query.device)
+        loc = reference_points[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+        return self.output_proj(ms_deform_attn_core(value, shapes, loc, aw))
+
+
+def _ref_points(h, w, device):
+    ys, xs = torch.meshgrid((torch.arange(h, device=device) + 0.5) / h, (torch.arange(w, device=device) + 0.5) / w,
+                            indexing="ij")
+    return torch.stack([xs.reshape(-1), ys.reshape(-1)], -1)        # (h*w, 2) as (x, y)
+
+
+class MRFP(nn.Module):
+    """FC -> depth-wise convs with two receptive fields (3x3 / 5x5 on channel halves) -> FC."""
+
+    def __init__(self, dim=256, hidden=128):
+        super().__init__()
+        self.fc1, self.fc2 = nn.Linear(dim, hidden), nn.Linear(hidden, dim)
+        self.dw3 = nn.Conv2d(hidden // 2, hidden // 2, 3, padding=1, groups=hidden // 2)
+        self.dw5 = nn.Conv2d(hidden // 2, hidden // 2, 5, padding=2, groups=hidden // 2)
+
+    def forward(self, c, shapes):
+        x = self.fc1(c)
+        outs, s = [], 0
+        for h, w in shapes:
+            t = x[:, s:s + h * w].transpose(1, 2).reshape(x.shape[0], -1, h, w)
+            a, b = t.chunk(2, dim=1)
+            outs.append(torch.cat([self.dw3(a), self.dw5(b)], 1).flatten(2).transpose(1, 2))
+            s += h * w
+        return c + self.fc2(F.gelu(torch.cat(outs, 1)))
+
+
+class CTI(nn.Module):
+    def __init__(self, dim=256, heads=8, points=4):
+        super().__init__()
+        self.nv_q, self.nv_f = nn.LayerNorm(dim), nn.LayerNorm(dim)
+        self.to_v = MSDeformAttn(dim, 3, heads, points)
+        self.gamma = nn.Parameter(torch.zeros(dim))
+        self.nc_q, self.nc_f = nn.LayerNorm(dim), nn.LayerNorm(dim)
+        self.to_c = MSDeformAttn(dim, 1, heads, points)
+        self.ffn_norm = nn.LayerNorm(dim)
+        self.ffn = nn.Sequential(nn.Linear(dim, dim), nn.GELU(), nn.Linear(dim, dim))
+
+    def forward(self, v, c, hw, shapes):
+        """v (N, h*w, C) ViT-side tokens at 1/16; c (N, S, C) pyramid tokens."""
+        h, w = hw
+        dev = v.device
+        rv = _ref_points(h, w, dev)[None, :, None, :].expand(v.shape[0], -1, 3, -1)
+        v = v + self.gamma * self.to_v(self.nv_q(v), rv, self.nv_f(c), shapes)
+        rc = torch.cat([_ref_points(a, b, dev) for a, b in shapes], 0)[None, :, None, :].expand(v.shape[0], -1, 1, -1)
+        c = c + self.to_c(self.nc_q(c), rc, self.nc_f(v), [(h, w)])
+        c = c + self.ffn(self.ffn_norm(c))
+        return v, c
+
+
+class SpatialPrior(nn.Module):
+    """Small conv stem giving the {1/8, 1/16, 1/32} pyramid at `dim` channels."""
+
+    def __init__(self, dim=256, inplanes=32):
+        super().__init__()
+        def block(i, o, s):
+            return nn.Sequential(nn.Conv2d(i, o, 3, s, 1, bias=False), nn.GroupNorm(8, o), nn.ReLU(inplace=True))
+        self.stem = nn.Sequential(block(3, inplanes, 2), block(inplanes, inplanes, 2))          # 1/4
+        self.c2 = block(inplanes, 2 * inplanes, 2)                                              # 1/8
+        self.c3 = block(2 * inplanes, 4 * inplanes, 2)                                          # 1/16
+        self.c4 = block(4 * inplanes, 4 * inplanes, 2)                                          # 1/32
+        self.p2, self.p3, self.p4 = nn.Conv2d(2 * inplanes, dim, 1), nn.Conv2d(4 * inplanes, dim, 1), nn.Conv2d(4 * inplanes, dim, 1)
+
+    def forward(self, img):
+        x = self.stem(img)
+        c2 = self.c2(x)
+        c3 = self.c3(c2)
+        c4 = self.c4(c3)
+        feats = [self.p2(c2), self.p3(c3), self.p4(c4)]
+        shapes = [tuple(f.shape[-2:]) for f in feats]
+        return torch.cat([f.flatten(2).transpose(1, 2) for f in feats], 1), shapes
+
+
+class CoMerInteraction(nn.Module):
+    """4 stages of MRFP + bidirectional CTI on the adapter outputs of ViT blocks `stage_blocks`;
+    returns the 1x1-conv fusion of the 8 CTI outputs as the decoder input (B, dim, h, w)."""
+
+    def __init__(self, dim=256, stage_blocks=(2, 5, 8, 10), heads=8, points=4):
+        super().__init__()
+        self.stage_blocks = tuple(stage_blocks)
+        self.spm = SpatialPrior(dim)
+        self.mrfp = nn.ModuleList([MRFP(dim) for _ in stage_blocks])
+        self.cti = nn.ModuleList([CTI(dim, heads, points) for _ in stage_blocks])
+        self.fuse = nn.Conv2d(2 * len(stage_blocks) * dim, dim, 1)
+
+    def forward(self, img, adapter_maps, hw):
+        """adapter_maps: list of (B, h*w, dim) adapter outputs, one per ViT block; hw = (h, w)."""
+        h, w = hw
+        c, shapes = self.spm(img)
+        outs = []
+        for i, blk in enumerate(self.stage_blocks):
+            c = self.mrfp[i](c, shapes)
+            v, c = self.cti[i](adapter_maps[blk], c, hw, shapes)
+            n16 = shapes[0][0] * shapes[0][1]
+            outs += [v, c[:, n16:n16 + shapes[1][0] * shapes[1][1]]]
+        cat = torch.cat(outs, 2)                                                        # (B, hw, 8*dim)
+        y = F.linear(cat, self.fuse.weight.flatten(1), self.fuse.bias)
+        return y.transpose(1, 2).reshape(img.shape[0], -1, h, w)

@@ -15,6 +15,7 @@ from ..clip import vit_engine as VE
 from ..clip.clip import load as clip_load
 from ..head_engine import HeadEngine, HeadFunction
 from ..pytorch_grad_cam import GradCAM
+from .comer import CoMerInteraction
 from .Decoder.TransDecoder import DecoderTransformer
 from .PAR import PAR, refine_labels
 from .segformer_head import SegFormerHead
@@ -33,7 +34,7 @@ class WeCLIP(nn.Module):
     val_runs_cam = True      # the VOC model runs the CAM/PAR path in 'val' too (:146-155)
 
     def __init__(self, num_classes=None, clip_model=None, embedding_dim=256, in_channels=512,
-                 dataset_root_path=None, device="cuda", text_features=None):
+                 dataset_root_path=None, device="cuda", text_features=None, comer=False):
         """`text_features=(bg (n_bg, Ed), fg (n_fg, Ed))`: the zero-shot text rows.  The reference
         computes them at construction with the CLIP text tower + tokenizer (:34-46,81-82); that
         init-time step is outside this package, so they are passed in (or assigned later to
@@ -58,12 +59,18 @@ class WeCLIP(nn.Module):
         self.require_all_fts = True
         self.head_impl = os.environ.get("WECLIP_HEAD", "hip")   # "hip" (head_engine.py) | "torch" (stock autograd)
         self.head_engine = HeadEngine(self.decoder_fts_fuse, self.decoder)
+        # optional ViT-CoMer inserts (comer.py): MRFP + bidirectional CTI on the adapter outputs of
+        # blocks [2,5,8,11]; their fusion replaces `linear_fuse` as the decoder input.  Extra keys
+        # `comer.*` in the state dict; absent (and the reference contract untouched) by default.
+        self.comer = CoMerInteraction(embedding_dim) if comer else None
         self.to(device)
 
     def get_param_groups(self):
         groups = [[], [], [], []]   # backbone; backbone_norm; cls_head; seg_head
         groups[3].extend(self.decoder.parameters())
         groups[3].extend(self.decoder_fts_fuse.parameters())
+        if self.comer is not None:
+            groups[3].extend(self.comer.parameters())
         return groups
 
     # ------------------------------------------------------------------------------------------
@@ -106,7 +113,7 @@ class WeCLIP(nn.Module):
         self.iter_num += 1
         seg_trans = self.iter_num > self.seg_trans_after or mode == "val"
         img = img.cuda().float().contiguous()
-        hip_head = self.head_impl == "hip"
+        hip_head = self.head_impl == "hip" and self.comer is None
         x16 = [] if hip_head else None
         with torch.no_grad():
             xs, maps, _, Lq = self.encode(img, seg_trans, x16)
@@ -118,7 +125,12 @@ class WeCLIP(nn.Module):
                 drop = ((torch.rand(B, self.embedding_dim, device=img.device) >= p).float() / (1.0 - p)).contiguous()
             seg, attn_pred = HeadFunction.apply(self.head_engine, x16, B, Lq, h, w, drop, *self.head_engine.params())
         else:
-            fts = self.decoder_fts_fuse.forward_rows(xs, B, Lq, h, w)
+            if self.comer is not None:
+                toks = [mlp.tokens(r.view(B, Lq, -1)[:, 1:, :]) for mlp, r in
+                        zip(self.decoder_fts_fuse.linears_modulelist, xs)]
+                fts = self.decoder_fts_fuse.dropout(self.comer(img, toks, (h, w)))
+            else:
+                fts = self.decoder_fts_fuse.forward_rows(xs, B, Lq, h, w)
             seg, _ = self.decoder(fts, need_weights=False)
             f = fts.reshape(B, fts.shape[1], h * w)
             attn_pred = torch.sigmoid(f.transpose(2, 1).bmm(f))
