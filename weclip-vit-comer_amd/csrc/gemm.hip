@@ -11,10 +11,10 @@
 // the concatenated K of 3 (activation, weight) pointer pairs; 1 segment = plain fp16 GEMM.
 //
 // Tile 128x128x64, 256 threads = 2x2 waves, each wave 64x64 = 2x2 MFMA 32x32 tiles
-// (64 accumulator VGPRs).  Global -> registers -> LDS (rows padded to 144 B: conflict-free
-// ds_read_b128 of 16-B k-slices across 16 consecutive rows), double-buffered LDS, the global
-// loads of tile t+1 are issued before the MFMAs of tile t, one barrier per K-tile.
-// blockIdx.x walks N tiles (they share the A tile through L2), blockIdx.y M tiles.
+// (64 accumulator VGPRs).  Operand tiles are DMA'd global -> LDS (global_load_lds_dwordx4) into an
+// XOR-swizzled, unpadded image (conflict-free ds_read_b128 fragment reads), two LDS stages: the
+// DMA of tile t+1 is issued before the MFMAs of tile t, one barrier per K-tile, 64 KiB LDS -> two
+// workgroups per CU.  blockIdx.x walks N tiles (they share the A tile through L2), blockIdx.y M tiles.
 #include "common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -60,101 +60,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// Epilogue shared by the kernel variants.  C/D layout of the 32x32 MFMA: col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Side inputs (residual / aux) of a 32x32 tile are fetched before
+// use so the loads overlap; out-of-range rows/cols read a clamped address and are not stored.
+// AUX (act 4/5) is a separate instantiation so the common epilogue carries no aux registers.
 template <bool AUX>
-__global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // layout: buf b (0/1): A rows [0,128) then W rows [0,128), each LDS_ROW bytes
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const long zb = blockIdx.z;
-
-    // per-thread staging coordinates: 4 chunks of 16 B for A and 4 for W per K-tile
-    int srow[4], scol[4], soff[4];
-    long aoff[4], woff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + 256 * i;
-        srow[i] = c >> 3;
-        scol[i] = c & 7;
-        int ar = m0 + srow[i];
-        if (ar > g.M - 1) ar = g.M - 1;
-        int wrow = n0 + srow[i];
-        if (wrow > g.N - 1) wrow = g.N - 1;
-        soff[i] = srow[i] * LDS_ROW + scol[i] * 16;
-        aoff[i] = zb * g.sA + (long)ar * g.lda + scol[i] * 8;
-        woff[i] = zb * g.sW + (long)wrow * g.ldw + scol[i] * 8;
-    }
-    const int ktiles = g.K / BK;
-    const int nt = ktiles * g.nseg;
-
-    // staging registers as scalars + macros (arrays captured by lambdas ended up in scratch)
-    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
-#define GLOAD(t)                                                                         \
-    {                                                                                    \
-        const int seg_ = (t) / ktiles;                                                   \
-        const long k0_ = (long)((t) - seg_ * ktiles) * BK;                               \
-        const __half* Ap_ = seg_ == 0 ? g.A[0] : (seg_ == 1 ? g.A[1] : g.A[2]);          \
-        const __half* Wp_ = seg_ == 0 ? g.W[0] : (seg_ == 1 ? g.W[1] : g.W[2]);          \
-        ra0 = *reinterpret_cast<const uint4*>(Ap_ + aoff[0] + k0_);                      \
-        ra1 = *reinterpret_cast<const uint4*>(Ap_ + aoff[1] + k0_);                      \
-        ra2 = *reinterpret_cast<const uint4*>(Ap_ + aoff[2] + k0_);                      \
-        ra3 = *reinterpret_cast<const uint4*>(Ap_ + aoff[3] + k0_);                      \
-        rw0 = *reinterpret_cast<const uint4*>(Wp_ + woff[0] + k0_);                      \
-        rw1 = *reinterpret_cast<const uint4*>(Wp_ + woff[1] + k0_);                      \
-        rw2 = *reinterpret_cast<const uint4*>(Wp_ + woff[2] + k0_);                      \
-        rw3 = *reinterpret_cast<const uint4*>(Wp_ + woff[3] + k0_);                      \
-    }
-#define LSTORE(buf)                                                                      \
-    {                                                                                    \
-        char* base_ = smem + (buf) * (2 * BM * LDS_ROW);                                 \
-        *reinterpret_cast<uint4*>(base_ + soff[0]) = ra0;                                \
-        *reinterpret_cast<uint4*>(base_ + soff[1]) = ra1;                                \
-        *reinterpret_cast<uint4*>(base_ + soff[2]) = ra2;                                \
-        *reinterpret_cast<uint4*>(base_ + soff[3]) = ra3;                                \
-        *reinterpret_cast<uint4*>(base_ + BM * LDS_ROW + soff[0]) = rw0;                 \
-        *reinterpret_cast<uint4*>(base_ + BM * LDS_ROW + soff[1]) = rw1;                 \
-        *reinterpret_cast<uint4*>(base_ + BM * LDS_ROW + soff[2]) = rw2;                 \
-        *reinterpret_cast<uint4*>(base_ + BM * LDS_ROW + soff[3]) = rw3;                 \
-    }
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    GLOAD(0);
-    LSTORE(0);
-    __syncthreads();
-
-    const int frow = lane & 31, fk = (lane >> 5) * 16;   // fragment row / byte offset of k-half
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) GLOAD(t + 1);
-        const char* As = smem + buf * (2 * BM * LDS_ROW) + (wr * 64 + frow) * LDS_ROW + fk;
-        const char* Ws = smem + buf * (2 * BM * LDS_ROW) + (BM + wc * 64 + frow) * LDS_ROW + fk;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            f16x8 a0 = *reinterpret_cast<const f16x8*>(As + ks * 32);
-            f16x8 a1 = *reinterpret_cast<const f16x8*>(As + 32 * LDS_ROW + ks * 32);
-            f16x8 b0 = *reinterpret_cast<const f16x8*>(Ws + ks * 32);
-            f16x8 b1 = *reinterpret_cast<const f16x8*>(Ws + 32 * LDS_ROW + ks * 32);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (t + 1 < nt) LSTORE(buf ^ 1);
-        __syncthreads();
-    }
-
-    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // Side inputs (residual / aux) of a 32x32 tile are fetched before use so the loads overlap;
-    // out-of-range rows/cols read a clamped address and are not stored.  AUX (act 4/5) is a
-    // separate instantiation so the common epilogue carries no aux registers.
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int m0, int n0, int wr, int wc,
+                                              int lane, long zb) {
     const long cb = zb * g.sC;
     const int act = g.act;
     const bool has_res = g.resid != nullptr;
@@ -212,6 +124,92 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
         }
 }
 
+// Main kernel.  Operand tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging and no
+// ds_write: the LDS store path, ~79 B/clk/CU for ds_write_b128, was the bottleneck of the register-staged
+// version).  An LDS-DMA wave-instruction writes 64 lanes x 16 B = 1 KiB linearly (8 unpadded 128-B tile
+// rows), so bank conflicts are avoided by an XOR swizzle carried on the per-lane GLOBAL source address:
+// physical 16-B chunk pc of row r holds logical chunk pc ^ ((r >> 1) & 7); fragment reads apply the same
+// XOR (16 consecutive rows then cover all 64 banks exactly once per ds_read_b128 lane group).
+template <bool AUX>
+__global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A tile 16 KiB | W tile 16 KiB]
+    constexpr int TILE = BM * BK * 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const long zb = blockIdx.z;
+
+    long aoff[4], woff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wave * 256 + i * 64 + lane;        // 16-B chunk index inside the tile image
+        const int row = q >> 3;
+        const int c = (q & 7) ^ ((row >> 1) & 7);        // logical chunk this lane must fetch
+        int ar = m0 + row;
+        if (ar > g.M - 1) ar = g.M - 1;
+        int wrow = n0 + row;
+        if (wrow > g.N - 1) wrow = g.N - 1;
+        aoff[i] = zb * g.sA + (long)ar * g.lda + c * 8;
+        woff[i] = zb * g.sW + (long)wrow * g.ldw + c * 8;
+    }
+    const int ktiles = g.K / BK;
+    const int nt = ktiles * g.nseg;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+#define GLDS(t, buf)                                                                                          \
+    {                                                                                                         \
+        const int seg_ = (t) / ktiles;                                                                        \
+        const long k0_ = (long)((t) - seg_ * ktiles) * BK;                                                    \
+        const __half* Ap_ = seg_ == 0 ? g.A[0] : (seg_ == 1 ? g.A[1] : g.A[2]);                               \
+        const __half* Wp_ = seg_ == 0 ? g.W[0] : (seg_ == 1 ? g.W[1] : g.W[2]);                               \
+        char* dst_ = smem + (buf) * (2 * TILE) + wave * 4096;                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(Ap_ + aoff[i] + k0_), (lds_ptr)(dst_ + i * 1024), 16, 0, 0);        \
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(Wp_ + woff[i] + k0_), (lds_ptr)(dst_ + TILE + i * 1024), 16, 0, 0); \
+        }                                                                                                     \
+    }
+    // fragment read addresses (bytes inside an operand tile) for this lane
+    const int hh = lane >> 5, l31 = lane & 31;
+    int arow[2], aswz[2], brow[2], bswz[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = wr * 64 + i * 32 + l31, rb = wc * 64 + i * 32 + l31;
+        arow[i] = ra * 128; aswz[i] = (ra >> 1) & 7;
+        brow[i] = rb * 128; bswz[i] = (rb >> 1) & 7;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    GLDS(0, 0);
+    __syncthreads();     // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) GLDS(t + 1, buf ^ 1);
+        const char* As = smem + buf * (2 * TILE);
+        const char* Ws = As + TILE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int ch = 2 * ks + hh;
+            const f16x8 a0 = *reinterpret_cast<const f16x8*>(As + arow[0] + ((ch ^ aswz[0]) << 4));
+            const f16x8 a1 = *reinterpret_cast<const f16x8*>(As + arow[1] + ((ch ^ aswz[1]) << 4));
+            const f16x8 b0 = *reinterpret_cast<const f16x8*>(Ws + brow[0] + ((ch ^ bswz[0]) << 4));
+            const f16x8 b1 = *reinterpret_cast<const f16x8*>(Ws + brow[1] + ((ch ^ bswz[1]) << 4));
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#undef GLDS
+    gemm_epilogue<AUX>(g, acc, m0, n0, wr, wc, lane, zb);
+}
+
 // out[i] = alpha * sum_s part[s*n + i]   (split-K reduction: slices are a batched GEMM over K ranges)
 __global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                           int nslices, long n, float alpha) {
@@ -260,7 +258,7 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
     g.auxh = (const __half*)auxh; g.cscale = cscale; g.sCS = sCS;
     dim3 grid(wc_cdiv(N, BN), wc_cdiv(M, BM), batch);
     WC_CHECK_ARG(grid.y <= 65535, "wc_gemm_f16: M too large for one launch");
-    const size_t lds = 2 * 2 * BM * LDS_ROW;
+    const size_t lds = 2 * 2 * BM * BK * 2;
     if (act >= 4)
         hipLaunchKernelGGL(gemm_f16_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, g);
     else
