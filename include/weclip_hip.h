@@ -38,7 +38,7 @@ int wc_par_affinity(const float* img, float* aff, int B, int H, int W,
 int wc_par_iterate(const float* aff, const float* masks_in, float* masks_out, int B, int C,
                    int H, int W, const int* h_dilations, int n_dil, void* stream);
 /* WeCLIP_model/PAR.py:64-92, whole `PAR.forward` for imgs already at mask resolution.
- * out/tmp: (B,C,H,W) f32 workspaces (result in out); aff_ws: min(group,B)*8*n_dil*H*W f32.
+ * out/tmp: (B,C,H,W) f32 workspaces (result in out); aff_ws: min(group,B)*8*n_dil*H*ceil64(W) f32.
  * Images are swept in groups of `group` so a group's aff planes stay cache resident. */
 int wc_par_forward(const float* img, const float* masks, float* out, float* tmp, float* aff_ws,
                    int B, int C, int H, int W, const int* h_dilations, int n_dil, int num_iter,

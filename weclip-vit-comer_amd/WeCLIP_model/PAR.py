@@ -51,12 +51,15 @@ class PAR(nn.Module):
             # PAR.py:67 -- F.interpolate(imgs, size=masks, bilinear, align_corners=True)
             imgs = bilinear_resize(imgs, (h, w), align_corners=True)
         T = 8 * len(self.dilations)
-        # group so that aff planes + masks of a group stay inside the 256 MiB Infinity Cache
+        # group so that aff + masks of a group stay inside the 256 MiB Infinity Cache across the sweeps
         per_img = (T + 3 * C) * h * w * 4
-        group = max(1, min(b, (160 << 20) // max(per_img, 1)))
+        group = max(1, min(b, (240 << 20) // max(per_img, 1)))   # measured best: 4 images at 512x512, C=3
+        import os
+        if os.environ.get("WECLIP_PAR_GROUP"):
+            group = max(1, min(b, int(os.environ["WECLIP_PAR_GROUP"])))
         out = torch.empty_like(masks)
         tmp = torch.empty_like(masks)
-        aff = torch.empty(group * T * h * w, device=masks.device, dtype=torch.float32)
+        aff = torch.empty(group * T * h * ((w + 63) // 64 * 64), device=masks.device, dtype=torch.float32)
         d = L.int_array(self.dilations)
         from ..ops import KernelTimer
         t0 = KernelTimer.start()

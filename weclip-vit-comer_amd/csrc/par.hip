@@ -7,6 +7,7 @@
 // Neighbour fetch is by index clamping (== replicate padding).  Everything is fp32.
 // Layout: aff is tap-major planes so a wave reads 64 consecutive x of one plane (256 B).
 #include "common.h"
+#include <stdlib.h>
 
 #define PAR_MAX_TAPS 64
 
@@ -70,7 +71,20 @@ __global__ __launch_bounds__(256) void par_affinity_kernel(const float* __restri
 
 // Register-resident variant for a compile-time tap count (ND dilations, T = 8*ND taps): the 3*T
 // neighbour values are fetched once and kept in VGPRs (one pass over the image instead of four).
-template <int ND>
+// TILED aff layout (internal to wc_par_forward): [image][y][x/64][tap][64] -- the T tap values of a
+// 64-pixel strip are contiguous (T*256 B), so one wave streams one contiguous block per sweep instead of
+// T streams 1 MiB apart (DRAM/MALL friendlier); plane-major (B,T,H,W) stays the public wc_par_affinity layout.
+__device__ __forceinline__ long aff_base(bool tiled, long img, int T, int H, int W, int y, int x, long* tstride) {
+    if (tiled) {
+        const int XT = (W + 63) >> 6;
+        *tstride = 64;
+        return ((img * H + y) * XT + (x >> 6)) * (long)T * 64 + (x & 63);
+    }
+    *tstride = (long)H * W;
+    return img * T * (long)H * W + (long)y * W + x;
+}
+
+template <int ND, bool TILED>
 __global__ __launch_bounds__(256) void par_affinity_reg_kernel(const float* __restrict__ img,
                                                                 float* __restrict__ aff, int H, int W,
                                                                 float w1, ParTaps taps) {
@@ -114,16 +128,19 @@ __global__ __launch_bounds__(256) void par_affinity_reg_kernel(const float* __re
         sum += v0[t];
     }
     const float inv = 1.0f / sum;
-    float* A = aff + (long)blockIdx.z * T * HW + p;
+    long ts;
+    float* A = aff + aff_base(TILED, blockIdx.z, T, H, W, y, x, &ts);
 #pragma unroll
-    for (int t = 0; t < T; ++t) A[(long)t * HW] = v0[t] * inv + taps.pi[t];
+    for (int t = 0; t < T; ++t) A[t * ts] = v0[t] * inv + taps.pi[t];
 }
 
 static void launch_affinity(const float* img, float* aff, int nb, int H, int W, const ParTaps& tp,
-                            hipStream_t st) {
+                            hipStream_t st, bool tiled) {
     dim3 grid(wc_cdiv(W, 64), wc_cdiv(H, 4), nb);
-    if (tp.n == 48)
-        hipLaunchKernelGGL(par_affinity_reg_kernel<6>, grid, dim3(256), 0, st, img, aff, H, W, 0.3f, tp);
+    if (tp.n == 48 && tiled)
+        hipLaunchKernelGGL((par_affinity_reg_kernel<6, true>), grid, dim3(256), 0, st, img, aff, H, W, 0.3f, tp);
+    else if (tp.n == 48)
+        hipLaunchKernelGGL((par_affinity_reg_kernel<6, false>), grid, dim3(256), 0, st, img, aff, H, W, 0.3f, tp);
     else
         hipLaunchKernelGGL(par_affinity_kernel, grid, dim3(256), 0, st, img, aff, H, W, 0.3f, tp);
 }
@@ -131,7 +148,10 @@ static void launch_affinity(const float* img, float* aff, int nb, int H, int W, 
 // One PAR iteration.  Thread = one pixel, CG channels at a time (aff value reused across the
 // channel group).  HBM traffic per launch: T*H*W*4 (aff) + 2*C*H*W*4 (masks in/out); the
 // neighbour gathers of `min` hit L1/L2 (C planes of H*W floats).
-template <int CG>
+#ifndef PAR_TAP_BATCH
+#define PAR_TAP_BATCH 8
+#endif
+template <int CG, bool TILED>
 __global__ __launch_bounds__(256) void par_iter_kernel(const float* __restrict__ aff,
                                                         const float* __restrict__ min,
                                                         float* __restrict__ mout, int C, int H,
@@ -142,7 +162,8 @@ __global__ __launch_bounds__(256) void par_iter_kernel(const float* __restrict__
     const long HW = (long)H * W;
     const long p = (long)y * W + x;
     const int T = taps.n;
-    const float* A = aff + (long)blockIdx.z * T * HW + p;
+    long ts;
+    const float* A = aff + aff_base(TILED, blockIdx.z, T, H, W, y, x, &ts);
     const float* M = min + (long)blockIdx.z * C * HW;
     float* O = mout + (long)blockIdx.z * C * HW + p;
     for (int cb = 0; cb < C; cb += CG) {
@@ -153,15 +174,92 @@ __global__ __launch_bounds__(256) void par_iter_kernel(const float* __restrict__
             acc[k] = 0.f;
             Mc[k] = M + (long)(cb + k < C ? cb + k : C - 1) * HW;
         }
-        for (int t = 0; t < T; ++t) {
-            const float a = A[(long)t * HW];
-            const long o = (long)clampi(y + taps.dy[t], H - 1) * W + clampi(x + taps.dx[t], W - 1);
+        constexpr int TB_ = PAR_TAP_BATCH;
+        // TB_ taps per batch: their aff loads and TB_*CG gathers are all issued before the first FMA
+        // (the rolled loop kept only 1+CG loads in flight per wave and was latency bound).
+        int t = 0;
+        for (; t + TB_ <= T; t += TB_) {
+            float a[TB_], m[TB_][CG];
+#pragma unroll
+            for (int u = 0; u < TB_; ++u) {
+                a[u] = A[(t + u) * ts];
+                const int o = clampi(y + taps.dy[t + u], H - 1) * W + clampi(x + taps.dx[t + u], W - 1);
+#pragma unroll
+                for (int k = 0; k < CG; ++k) m[u][k] = Mc[k][o];
+            }
+#pragma unroll
+            for (int u = 0; u < TB_; ++u)
+#pragma unroll
+                for (int k = 0; k < CG; ++k) acc[k] = fmaf(a[u], m[u][k], acc[k]);
+        }
+        for (; t < T; ++t) {
+            const float a = A[t * ts];
+            const int o = clampi(y + taps.dy[t], H - 1) * W + clampi(x + taps.dx[t], W - 1);
 #pragma unroll
             for (int k = 0; k < CG; ++k) acc[k] = fmaf(a, Mc[k][o], acc[k]);
         }
 #pragma unroll
         for (int k = 0; k < CG; ++k)
             if (cb + k < C) O[(long)(cb + k) * HW] = acc[k];
+    }
+}
+
+// Wide variant (W % 4 == 0): one thread = 4 consecutive pixels, so the aff stream is read as aligned
+// 16-B vectors (1 KiB per wave-instruction) and each neighbour gather is one dword-aligned dwordx4 load
+// (global memory only needs dword alignment); pixels whose tap crosses the left/right border fall back
+// to per-element clamped loads.  4x fewer memory instructions than par_iter_kernel for the same bytes.
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+
+template <int CG>
+__global__ __launch_bounds__(256) void par_iter4_kernel(const float* __restrict__ aff, const float* __restrict__ min,
+                                                         float* __restrict__ mout, int C, int H, int W, ParTaps taps) {
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x0 >= W || y >= H) return;
+    const long HW = (long)H * W;
+    const long p = (long)y * W + x0;
+    const int T = taps.n;
+    const float* A = aff + (long)blockIdx.z * T * HW + p;
+    const float* M = min + (long)blockIdx.z * C * HW;
+    float* O = mout + (long)blockIdx.z * C * HW + p;
+    for (int cb = 0; cb < C; cb += CG) {
+        float acc[CG][4];
+        const float* Mc[CG];
+#pragma unroll
+        for (int k = 0; k < CG; ++k) {
+            acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.f;
+            Mc[k] = M + (long)(cb + k < C ? cb + k : C - 1) * HW;
+        }
+        for (int t = 0; t < T; ++t) {
+            const float4 a = *reinterpret_cast<const float4*>(A + (long)t * HW);
+            const long rowo = (long)clampi(y + taps.dy[t], H - 1) * W;
+            const int xs = x0 + taps.dx[t];
+            if (xs >= 0 && xs + 3 <= W - 1) {
+#pragma unroll
+                for (int k = 0; k < CG; ++k) {
+                    const f4u m = *reinterpret_cast<const f4u*>(Mc[k] + rowo + xs);
+                    acc[k][0] = fmaf(a.x, m.x, acc[k][0]);
+                    acc[k][1] = fmaf(a.y, m.y, acc[k][1]);
+                    acc[k][2] = fmaf(a.z, m.z, acc[k][2]);
+                    acc[k][3] = fmaf(a.w, m.w, acc[k][3]);
+                }
+            } else {
+                const int c0 = clampi(xs, W - 1), c1 = clampi(xs + 1, W - 1), c2 = clampi(xs + 2, W - 1),
+                          c3 = clampi(xs + 3, W - 1);
+#pragma unroll
+                for (int k = 0; k < CG; ++k) {
+                    const float* r = Mc[k] + rowo;
+                    acc[k][0] = fmaf(a.x, r[c0], acc[k][0]);
+                    acc[k][1] = fmaf(a.y, r[c1], acc[k][1]);
+                    acc[k][2] = fmaf(a.z, r[c2], acc[k][2]);
+                    acc[k][3] = fmaf(a.w, r[c3], acc[k][3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CG; ++k)
+            if (cb + k < C)
+                *reinterpret_cast<float4*>(O + (long)(cb + k) * HW) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
     }
 }
 
@@ -221,20 +319,32 @@ extern "C" int wc_par_affinity(const float* img, float* aff, int B, int H, int W
     WC_CHECK_ARG(img && aff && B > 0 && H > 0 && W > 0, "wc_par_affinity: bad argument");
     ParTaps tp;
     WC_CHECK_ARG(build_taps(&tp, dilations, n_dil, 0.3f, 0.01f) == 0, "wc_par_affinity: 1..8 dilations");
-    launch_affinity(img, aff, B, H, W, tp, (hipStream_t)stream);
+    launch_affinity(img, aff, B, H, W, tp, (hipStream_t)stream, false);
     WC_LAUNCH_CHECK("par_affinity_kernel");
     return WC_OK;
 }
 
 static int launch_iter(const float* aff, const float* src, float* dst, int B, int C, int H, int W,
-                       const ParTaps& tp, hipStream_t st) {
+                       const ParTaps& tp, hipStream_t st, bool tiled) {
+    static const bool wide = getenv("WECLIP_PAR_WIDE") != nullptr;   // experiment: slower than the scalar kernel
+    if (wide && W % 4 == 0 && (((uintptr_t)aff | (uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        dim3 g4(wc_cdiv(W, 256), wc_cdiv(H, 4), B);
+        if (C <= 2)
+            hipLaunchKernelGGL(par_iter4_kernel<2>, g4, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
+        else if (C == 3)
+            hipLaunchKernelGGL(par_iter4_kernel<3>, g4, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
+        else
+            hipLaunchKernelGGL(par_iter4_kernel<4>, g4, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
+        WC_LAUNCH_CHECK("par_iter4_kernel");
+        return WC_OK;
+    }
     dim3 grid(wc_cdiv(W, 64), wc_cdiv(H, 4), B);
-    if (C <= 2)
-        hipLaunchKernelGGL(par_iter_kernel<2>, grid, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
-    else if (C == 3)
-        hipLaunchKernelGGL(par_iter_kernel<3>, grid, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
-    else
-        hipLaunchKernelGGL(par_iter_kernel<4>, grid, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
+#define PAR_ITER_LAUNCH(CG_) \
+    if (tiled) hipLaunchKernelGGL((par_iter_kernel<CG_, true>), grid, dim3(256), 0, st, aff, src, dst, C, H, W, tp); \
+    else hipLaunchKernelGGL((par_iter_kernel<CG_, false>), grid, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
+    if (C <= 2) { PAR_ITER_LAUNCH(2) }
+    else if (C == 3) { PAR_ITER_LAUNCH(3) }
+    else { PAR_ITER_LAUNCH(4) }
     WC_LAUNCH_CHECK("par_iter_kernel");
     return WC_OK;
 }
@@ -245,13 +355,13 @@ extern "C" int wc_par_iterate(const float* aff, const float* masks_in, float* ma
                  "wc_par_iterate: bad argument (in-place not allowed)");
     ParTaps tp;
     WC_CHECK_ARG(build_taps(&tp, dilations, n_dil, 0.3f, 0.01f) == 0, "wc_par_iterate: 1..8 dilations");
-    return launch_iter(aff, masks_in, masks_out, B, C, H, W, tp, (hipStream_t)stream);
+    return launch_iter(aff, masks_in, masks_out, B, C, H, W, tp, (hipStream_t)stream, false);
 }
 
 // Whole PAR.forward for images already at mask resolution (PAR.py:64-92).
 // Images are processed in groups of `group` so that a group's aff planes (T*H*W*4 B each)
 // stay resident in the 256 MiB Infinity Cache across the num_iter sweeps.
-// Workspaces: aff_ws >= min(group,B)*T*H*W floats, tmp >= B*C*H*W floats.
+// Workspaces: aff_ws >= min(group,B)*T*H*ceil64(W) floats, tmp >= B*C*H*W floats.
 extern "C" int wc_par_forward(const float* img, const float* masks, float* out, float* tmp,
                               float* aff_ws, int B, int C, int H, int W, const int* dilations,
                               int n_dil, int num_iter, int group, void* stream) {
@@ -263,14 +373,15 @@ extern "C" int wc_par_forward(const float* img, const float* masks, float* out, 
     WC_CHECK_ARG(build_taps(&tp, dilations, n_dil, 0.3f, 0.01f) == 0, "wc_par_forward: 1..8 dilations");
     hipStream_t st = (hipStream_t)stream;
     const long HW = (long)H * W;
+    const bool tiled = (tp.n == 48);   // strip-interleaved aff (needs aff_ws >= group*T*H*ceil64(W) floats)
     for (int b0 = 0; b0 < B; b0 += group) {
         const int nb = (B - b0 < group) ? B - b0 : group;
-        launch_affinity(img + (long)b0 * 3 * HW, aff_ws, nb, H, W, tp, st);
+        launch_affinity(img + (long)b0 * 3 * HW, aff_ws, nb, H, W, tp, st, tiled);
         WC_LAUNCH_CHECK("par_affinity_kernel");
         const float* src = masks + (long)b0 * C * HW;
         for (int i = 0; i < num_iter; ++i) {
             float* dst = (((num_iter - i) & 1) ? out : tmp) + (long)b0 * C * HW;
-            int rc = launch_iter(aff_ws, src, dst, nb, C, H, W, tp, st);
+            int rc = launch_iter(aff_ws, src, dst, nb, C, H, W, tp, st, tiled);
             if (rc) return rc;
             src = dst;
         }
