@@ -72,74 +72,82 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
     const long cb = zb * g.sC;
     const int act = g.act;
     const bool has_res = g.resid != nullptr;
-    if constexpr (!AUX) {
-        if (g.vec && !g.P32 && g.C16 && !g.C32) {   // fp32 outputs are already 128-B coalesced per half-wave: measured slower here
-            // Wide epilogue: the MFMA C layout gives a lane one column and 16 scattered rows (64 narrow
-            // stores per lane, store-issue bound).  Each wave instead drops its finished 64x64 sub-tile into
-            // its own 16 KiB of the (now idle) operand LDS and re-reads it row-major, 4 columns per lane:
-            // residual is one float4 load, outputs are one 16-B (fp32) / 8-B (fp16) store per 4 values.
-            float* tile = reinterpret_cast<float*>(smem) + wave * 4096;
+    if (g.vec && !g.P32 && g.C16 && !g.C32) {   // fp32 outputs are already 128-B coalesced per half-wave: measured slower there
+        // Wide epilogue: the MFMA C layout gives a lane one column and 16 scattered rows (64 narrow
+        // stores per lane, store-issue bound).  Each wave instead drops its finished 64x64 sub-tile into
+        // its own 16 KiB of the (now idle) operand LDS and re-reads it row-major, 4 columns per lane:
+        // residual / aux side inputs are one 16-B (8-B) load, outputs one 8-B store per 4 values.
+        float* tile = reinterpret_cast<float*>(smem) + wave * 4096;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const int cl = ni * 32 + (lane & 31);
-                    const int col = n0 + wc * 64 + cl;
-                    const int colc = col < g.N ? col : g.N - 1;
-                    const float bv = g.bias ? g.bias[colc] : 0.f;
-                    float sc = (col < g.scale_cols) ? g.scale : 1.0f;
-                    if (g.cscale) sc *= g.cscale[zb * g.sCS + colc];
+            for (int ni = 0; ni < 2; ++ni) {
+                const int cl = ni * 32 + (lane & 31);
+                const int col = n0 + wc * 64 + cl;
+                const int colc = col < g.N ? col : g.N - 1;
+                const float bv = g.bias ? g.bias[colc] : 0.f;
+                float sc = (col < g.scale_cols) ? g.scale : 1.0f;
+                if (g.cscale) sc *= g.cscale[zb * g.sCS + colc];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = acc[mi][ni][r] + bv;
-                        if (g.round16) v = __half2float(__float2half(v));
-                        v = apply_act(v * sc, act);
-                        tile[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + cl] = v;
-                    }
-                }
-            // same wave reads what it wrote: LDS ops of a wave complete in order, no barrier needed
-            const int c4 = (lane & 15) * 4;
-            const int gcol = n0 + wc * 64 + c4;
-#pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                const int rl = it * 4 + (lane >> 4);
-                const int grow = m0 + wr * 64 + rl;
-                if (grow >= g.M || gcol >= g.N) continue;
-                float4 v = *reinterpret_cast<const float4*>(tile + rl * 64 + c4);
-                const long o = cb + (long)grow * g.ldc + gcol;
-                if (gcol + 3 < g.N) {
-                    if (has_res) {
-                        const float4 rr = *reinterpret_cast<const float4*>(g.resid + zb * g.sR + (long)grow * g.ldr + gcol);
-                        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-                    }
-                    if (g.C32) *reinterpret_cast<float4*>(g.C32 + o) = v;
-                    if (g.C16) {
-                        const float f[4] = {v.x, v.y, v.z, v.w};
-                        __half h[4], l[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            h[k] = __float2half(f[k]);
-                            l[k] = __float2half(f[k] - __half2float(h[k]));
-                        }
-                        *reinterpret_cast<u32x2*>(g.C16 + o) = *reinterpret_cast<u32x2*>(h);
-                        if (g.C16lo) *reinterpret_cast<u32x2*>(g.C16lo + o) = *reinterpret_cast<u32x2*>(l);
-                    }
-                } else {
-                    const float f[4] = {v.x, v.y, v.z, v.w};
-                    for (int k = 0; k < 4 && gcol + k < g.N; ++k) {
-                        float x = f[k];
-                        if (has_res) x += g.resid[zb * g.sR + (long)grow * g.ldr + gcol + k];
-                        if (g.C32) g.C32[o + k] = x;
-                        if (g.C16) {
-                            const __half h = __float2half(x);
-                            g.C16[o + k] = h;
-                            if (g.C16lo) g.C16lo[o + k] = __float2half(x - __half2float(h));
-                        }
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[mi][ni][r] + bv;
+                    if (g.round16) v = __half2float(__float2half(v));
+                    v *= sc;
+                    if constexpr (!AUX) v = apply_act(v, act);
+                    tile[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + cl] = v;
                 }
             }
-            return;
+        // same wave reads what it wrote: LDS ops of a wave complete in order, no barrier needed
+        const int c4 = (lane & 15) * 4;
+        const int gcol = n0 + wc * 64 + c4;
+#pragma unroll 2
+        for (int it = 0; it < 16; ++it) {
+            const int rl = it * 4 + (lane >> 4);
+            const int grow = m0 + wr * 64 + rl;
+            if (grow >= g.M || gcol >= g.N) continue;
+            const float4 t4 = *reinterpret_cast<const float4*>(tile + rl * 64 + c4);
+            float f[4] = {t4.x, t4.y, t4.z, t4.w};
+            const long o = cb + (long)grow * g.ldc + gcol;
+            const bool full = gcol + 3 < g.N;
+            if constexpr (AUX) {
+                if (act == 4) {
+                    const long arow = g.rowmap ? (long)g.rowmap[grow / g.rpg] * g.rpg + grow % g.rpg : grow;
+                    const float* up = g.aux + arow * g.ldaux + gcol;
+                    float u[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (full) { const float4 u4 = *reinterpret_cast<const float4*>(up); u[0] = u4.x; u[1] = u4.y; u[2] = u4.z; u[3] = u4.w; }
+                    else for (int k = 0; k < 4 && gcol + k < g.N; ++k) u[k] = up[k];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float sg = 1.0f / (1.0f + __expf(-1.702f * u[k]));
+                        f[k] *= sg * (1.0f + 1.702f * u[k] * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
+                    }
+                } else {
+                    const __half* hp = g.auxh + (long)grow * g.ldaux + gcol;
+                    for (int k = 0; k < 4 && gcol + k < g.N; ++k) f[k] *= __half2float(hp[k]) > 0.f ? 1.f : 0.f;   // ReLU'
+                }
+            }
+            if (has_res) {
+                const float* rp = g.resid + zb * g.sR + (long)grow * g.ldr + gcol;
+                if (full) { const float4 rr = *reinterpret_cast<const float4*>(rp); f[0] += rr.x; f[1] += rr.y; f[2] += rr.z; f[3] += rr.w; }
+                else for (int k = 0; k < 4 && gcol + k < g.N; ++k) f[k] += rp[k];
+            }
+            __half h[4], l[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                h[k] = __float2half(f[k]);
+                l[k] = __float2half(f[k] - __half2float(h[k]));
+            }
+            if (full) {
+                *reinterpret_cast<u32x2*>(g.C16 + o) = *reinterpret_cast<u32x2*>(h);
+                if (g.C16lo) *reinterpret_cast<u32x2*>(g.C16lo + o) = *reinterpret_cast<u32x2*>(l);
+            } else {
+                for (int k = 0; k < 4 && gcol + k < g.N; ++k) {
+                    g.C16[o + k] = h[k];
+                    if (g.C16lo) g.C16lo[o + k] = l[k];
+                }
+            }
         }
+        return;
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -210,10 +218,18 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so linear
     // ids l, l+8, l+16.. share an L2.  Give each XCD whole M-tile rows: its consecutive workgroups walk
     // the N tiles of one M tile and re-use the A tile from that XCD's L2 instead of 8 L2s fetching it.
+    // (Only for tall grids: with fewer than 16 M tiles the remap would park the work on a few XCDs.)
     const int gx = g.gx, gy = g.gy;
     const int lin = blockIdx.x;
-    const int slot = lin >> 3;
-    const int ty = (slot / gx) * 8 + (lin & 7), tx = slot - (slot / gx) * gx;
+    int tx, ty;
+    if (gy >= 16) {
+        const int slot = lin >> 3;
+        ty = (slot / gx) * 8 + (lin & 7);
+        tx = slot - (slot / gx) * gx;
+    } else {
+        ty = lin / gx;
+        tx = lin - ty * gx;
+    }
     if (ty >= gy) return;
     const int m0 = ty * BM, n0 = tx * BN;
     const long zb = blockIdx.z;
@@ -337,7 +353,8 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
     g.auxh = (const __half*)auxh; g.cscale = cscale; g.sCS = sCS;
     // wide epilogue needs every 4-column group of a row 16-B (fp32) / 8-B (fp16) addressable
     g.vec = (ldc % 4 == 0 && sC % 4 == 0 && (!resid || (ldr % 4 == 0 && sR % 4 == 0 && (uintptr_t)resid % 16 == 0)) &&
-             (!C32 || (uintptr_t)C32 % 16 == 0) && (!C16 || (uintptr_t)C16 % 8 == 0) && (!C16lo || (uintptr_t)C16lo % 8 == 0))
+             (!C32 || (uintptr_t)C32 % 16 == 0) && (!C16 || (uintptr_t)C16 % 8 == 0) && (!C16lo || (uintptr_t)C16lo % 8 == 0) &&
+             (act != 4 || (ldaux % 4 == 0 && (uintptr_t)aux % 16 == 0)))
                 ? 1 : 0;
     g.gx = wc_cdiv(N, BN);
     g.gy = wc_cdiv(M, BM);
