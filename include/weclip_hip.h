@@ -56,10 +56,23 @@ int wc_par_labels(const float* masks, const int64_t* valid_key, const int* nch, 
 int wc_bilinear_resize(const float* src, float* dst, int planes, int Hs, int Ws, int Hd, int Wd,
                        int align_corners, void* stream);
 /* backward of the same (up-sampling): gsrc (planes,Hs,Ws) = sum over destination pixels of their
- * gradient gdst (planes,Hd,Wd) times the interpolation weight; gather form, no atomics
+ * gradient gdst (planes,Hd,Wd) times the interpolation weight; separable two-pass gather, no atomics
+ * (tmp: planes*Hd*Ws f32 workspace)
  * (autograd of F.interpolate at scripts/dist_clip_voc.py:250). */
-int wc_bilinear_resize_bwd(const float* gdst, float* gsrc, int planes, int Hs, int Ws, int Hd, int Wd,
-                           int align_corners, void* stream);
+int wc_bilinear_resize_bwd(const float* gdst, float* gsrc, float* tmp, int planes, int Hs, int Ws, int Hd,
+                           int Wd, int align_corners, void* stream);
+
+/* ---- segmentation loss fused with the logit up-sampling -------------------------------- */
+/* scripts/dist_clip_voc.py:250 (bilinear up-sampling of seg to H x W) + get_seg_loss :105-113.
+ * seg (B,nc,h,w) f32 low-res logits, label (B,H,W) i64 (ignore = 255).
+ * wc_seg_loss_fwd: sums (4) = [sum nll over label==0, #label==0, sum nll over fg labels, #fg];
+ *                  loss = 0.5*(sums[0]/sums[1] + sums[2]/sums[3]); part: ceil(W/64)*ceil(H/4)*B*4 f32.
+ * wc_seg_loss_bwd: ghr (B,nc,H,W) = wts[bg|fg] * (softmax - onehot) per pixel (0 for ignored); the
+ *                  low-res gradient is wc_bilinear_resize_bwd(ghr). */
+int wc_seg_loss_fwd(const float* seg, const int64_t* label, float* part, float* sums, int B, int nc, int h, int w,
+                    int H, int W, int ignore, void* stream);
+int wc_seg_loss_bwd(const float* seg, const int64_t* label, const float* wts, float* ghr, int B, int nc, int h,
+                    int w, int H, int W, int ignore, void* stream);
 
 /* ---- MFMA GEMM ------------------------------------------------------------------------ */
 /* C[M,N] = epilogue(sum_{s<nseg} A_s[M,K] * W_s[N,K]^T), fp16 operands (K contiguous), fp32

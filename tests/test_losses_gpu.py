@@ -1,0 +1,41 @@
+"""Fused segmentation loss (up-sampling + two CE terms) and the bilinear backward vs torch autograd."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import weclip_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,nc,h,w,scale", [(2, 21, 4, 6, 16), (1, 5, 7, 5, 16), (2, 21, 32, 32, 16)])
+def test_fused_seg_loss_forward_backward(B, nc, h, w, scale):
+    from weclip_vit_comer_amd.utils.losses import get_seg_loss_fused
+    g = torch.Generator().manual_seed(h)
+    H, W = h * scale, w * scale
+    seg = torch.randn(B, nc, h, w, generator=g)
+    lab = torch.randint(0, nc, (B, H, W), generator=g)
+    lab[:, : H // 3] = 0
+    lab[:, -5:, -7:] = 255
+    ref_in = seg.double().requires_grad_(True)
+    ref = O.seg_loss(F.interpolate(ref_in, size=(H, W), mode="bilinear", align_corners=False), lab)
+    ref.backward()
+    x = seg.cuda().requires_grad_(True)
+    out = get_seg_loss_fused(x, lab.cuda())
+    (3.0 * out).backward()
+    assert abs(out.item() - ref.item()) < 2e-5 * max(1.0, abs(ref.item()))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), 3.0 * ref_in.grad.numpy(), rtol=2e-3, atol=2e-7)
+
+
+@pytest.mark.parametrize("align", [False, True])
+def test_bilinear_upsample_backward(align):
+    from weclip_vit_comer_amd.resize import bilinear_upsample
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 3, 5, 7, generator=g)
+    gy = torch.randn(2, 3, 40, 61, generator=g)
+    xr = x.double().requires_grad_(True)
+    (F.interpolate(xr, size=(40, 61), mode="bilinear", align_corners=align) * gy.double()).sum().backward()
+    xc = x.cuda().requires_grad_(True)
+    (bilinear_upsample(xc, (40, 61), align) * gy.cuda()).sum().backward()
+    np.testing.assert_allclose(xc.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-5)

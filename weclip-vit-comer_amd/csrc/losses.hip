@@ -1,0 +1,111 @@
+// Segmentation loss of the training step, fused with the bilinear up-sampling of the logits.
+// reference scripts/dist_clip_voc.py:250 (F.interpolate(segs, size=(H,W), bilinear, align_corners=False))
+// + get_seg_loss :105-113:  0.5 * (CE(pred, label with fg->ignore) + CE(pred, label with bg->ignore)),
+// each CE a mean over its non-ignored pixels.  The reference materialises the (B, nc, H, W) up-sampled
+// logits (352 MB at 16x21x512x512) for log_softmax forward and backward; here every high-res pixel
+// interpolates its nc logits from the low-res map on the fly.
+//   seg_loss_fwd_kernel : per pixel nll; block sums of (nll_bg, n_bg, nll_fg, n_fg) -> partials
+//   seg_loss_bwd_kernel : per pixel g[c] = w_pix * (softmax_c - [c == label]) written as (B, nc, H, W);
+//                         the low-res gradient is then the separable bilinear backward (resize.hip).
+#include "common.h"
+
+#define SEG_MAX_C 96
+
+__device__ __forceinline__ void bil_index(int d, int in, float scale, int& i0, int& i1, float& l1) {
+    float s = fmaxf(scale * (d + 0.5f) - 0.5f, 0.f);
+    i0 = (int)s;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = s - i0;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__ seg, const long* __restrict__ label,
+                                                        float* __restrict__ part, const float* __restrict__ wts,
+                                                        float* __restrict__ ghr, int nc, int h, int w, int H, int W,
+                                                        float sy, float sx, int ignore) {
+    __shared__ float red[16];
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    float nll = 0.f;
+    int cls = -1;   // -1: outside / ignored, 0: background pixel, 1: foreground pixel
+    if (x < W && y < H) {
+        const long lab = label[((long)b * H + y) * W + x];
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bil_index(y, h, sy, y0, y1, ly);
+        bil_index(x, w, sx, x0, x1, lx);
+        const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+        const float* S = seg + (long)b * nc * h * w;
+        const long o00 = (long)y0 * w + x0, o01 = (long)y0 * w + x1, o10 = (long)y1 * w + x0, o11 = (long)y1 * w + x1;
+        float mx = -INFINITY, sum = 0.f, zl = 0.f;
+        for (int c = 0; c < nc; ++c) {
+            const float* Sc = S + (long)c * h * w;
+            const float z = w00 * Sc[o00] + w01 * Sc[o01] + w10 * Sc[o10] + w11 * Sc[o11];
+            if (c == lab) zl = z;
+            const float nm = fmaxf(mx, z);
+            sum = sum * __expf(mx - nm) + __expf(z - nm);
+            mx = nm;
+        }
+        const bool valid = lab != ignore && lab >= 0 && lab < nc;
+        if (valid) {
+            cls = lab == 0 ? 0 : 1;
+            nll = mx + __logf(sum) - zl;
+        }
+        if (BWD) {
+            const float wp = valid ? wts[cls] : 0.f;     // 0.5 / n_bg or 0.5 / n_fg (times upstream grad)
+            float* G = ghr + (long)b * nc * H * W + (long)y * W + x;
+            const float lse = mx + __logf(sum);
+            for (int c = 0; c < nc; ++c) {
+                const float* Sc = S + (long)c * h * w;
+                const float z = w00 * Sc[o00] + w01 * Sc[o01] + w10 * Sc[o10] + w11 * Sc[o11];
+                G[(long)c * H * W] = wp * (__expf(z - lse) - (c == lab ? 1.f : 0.f));
+            }
+        }
+    }
+    if (!BWD) {
+        const float a0 = block_sum(cls == 0 ? nll : 0.f, red), a1 = block_sum(cls == 0 ? 1.f : 0.f, red);
+        const float a2 = block_sum(cls == 1 ? nll : 0.f, red), a3 = block_sum(cls == 1 ? 1.f : 0.f, red);
+        if (threadIdx.x == 0) {
+            const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            part[blk * 4] = a0; part[blk * 4 + 1] = a1; part[blk * 4 + 2] = a2; part[blk * 4 + 3] = a3;
+        }
+    }
+}
+
+// sums[k] = sum over blocks of part[blk*4 + k]  (deterministic second stage)
+__global__ __launch_bounds__(256) void seg_loss_reduce_kernel(const float* __restrict__ part, float* __restrict__ sums, long nblk) {
+    __shared__ float red[16];
+    for (int k = 0; k < 4; ++k) {
+        float s = 0.f;
+        for (long i = threadIdx.x; i < nblk; i += 256) s += part[i * 4 + k];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) sums[k] = s;
+        __syncthreads();
+    }
+}
+
+extern "C" int wc_seg_loss_fwd(const float* seg, const int64_t* label, float* part, float* sums, int B, int nc, int h,
+                               int w, int H, int W, int ignore, void* stream) {
+    WC_CHECK_ARG(seg && label && part && sums && B > 0 && nc > 0 && nc <= SEG_MAX_C && h > 0 && w > 0 && H >= h && W >= w,
+                 "wc_seg_loss_fwd: bad argument");
+    dim3 grid(wc_cdiv(W, 64), wc_cdiv(H, 4), B);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(seg_loss_kernel<false>, grid, dim3(256), 0, st, seg, (const long*)label, part, nullptr, nullptr, nc,
+                       h, w, H, W, (float)h / H, (float)w / W, ignore);
+    WC_LAUNCH_CHECK("seg_loss_kernel<fwd>");
+    hipLaunchKernelGGL(seg_loss_reduce_kernel, dim3(1), dim3(256), 0, st, part, sums, (long)grid.x * grid.y * grid.z);
+    WC_LAUNCH_CHECK("seg_loss_reduce_kernel");
+    return WC_OK;
+}
+
+// wts (2) device floats: gradient weight of a background / foreground pixel.  ghr: (B, nc, H, W) workspace.
+extern "C" int wc_seg_loss_bwd(const float* seg, const int64_t* label, const float* wts, float* ghr, int B, int nc, int h,
+                               int w, int H, int W, int ignore, void* stream) {
+    WC_CHECK_ARG(seg && label && wts && ghr && B > 0 && nc > 0 && nc <= SEG_MAX_C && h > 0 && w > 0 && H >= h && W >= w,
+                 "wc_seg_loss_bwd: bad argument");
+    dim3 grid(wc_cdiv(W, 64), wc_cdiv(H, 4), B);
+    hipLaunchKernelGGL(seg_loss_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, seg, (const long*)label, nullptr, wts,
+                       ghr, nc, h, w, H, W, (float)h / H, (float)w / W, ignore);
+    WC_LAUNCH_CHECK("seg_loss_kernel<bwd>");
+    return WC_OK;
+}

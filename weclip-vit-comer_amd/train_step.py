@@ -9,7 +9,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from .utils.camutils import cams_to_affinity_label, get_mask_by_radius
-from .utils.losses import get_aff_loss, get_seg_loss
+from .utils.losses import get_aff_loss, get_seg_loss, get_seg_loss_fused
 from .utils.optimizer import PolyWarmupAdamW
 
 
@@ -64,15 +64,14 @@ class TrainStep:
         return self._mask[key]
 
     def losses(self, seg, cam, attn_pred):
-        if seg.is_cuda:
-            from .resize import bilinear_upsample
-            segs = bilinear_upsample(seg, cam.shape[1:], align_corners=False)
-        else:
-            segs = F.interpolate(seg, size=cam.shape[1:], mode="bilinear", align_corners=False)
         h, w = cam.shape[1] // 16, cam.shape[2] // 16
         aff_label = cams_to_affinity_label(cam, mask=self.mask(h, w, cam.device), ignore_index=self.ignore)
         attn_loss, _, _ = get_aff_loss(attn_pred, aff_label)
-        seg_loss = get_seg_loss(segs, cam.long(), ignore_index=self.ignore)
+        if seg.is_cuda:     # up-sampling + both CE terms fused (csrc/losses.hip)
+            seg_loss = get_seg_loss_fused(seg, cam, ignore_index=self.ignore)
+        else:
+            segs = F.interpolate(seg, size=cam.shape[1:], mode="bilinear", align_corners=False)
+            seg_loss = get_seg_loss(segs, cam.long(), ignore_index=self.ignore)
         return seg_loss + 0.1 * attn_loss, seg_loss, attn_loss
 
     def __call__(self, img, names=None, labels=None):

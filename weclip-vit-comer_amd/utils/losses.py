@@ -21,3 +21,45 @@ def get_seg_loss(pred, label, ignore_index=255):
     fg[label == 0] = ignore_index
     return 0.5 * (F.cross_entropy(pred, bg.long(), ignore_index=ignore_index)
                   + F.cross_entropy(pred, fg.long(), ignore_index=ignore_index))
+
+
+class _SegLossFn(torch.autograd.Function):
+    """get_seg_loss(F.interpolate(seg, (H,W), bilinear), label) without materialising the up-sampled
+    logits (csrc/losses.hip); backward = per-pixel softmax gradient + separable bilinear backward."""
+
+    @staticmethod
+    def forward(ctx, seg, label, ignore_index):
+        from .. import _lib as L
+        seg = seg.float().contiguous()
+        label = label.long().contiguous()
+        B, nc, h, w = seg.shape
+        H, W = label.shape[1:]
+        nblk = ((W + 63) // 64) * ((H + 3) // 4) * B
+        part = torch.empty(nblk * 4, device=seg.device, dtype=torch.float32)
+        sums = torch.empty(4, device=seg.device, dtype=torch.float32)
+        L.lib().wc_seg_loss_fwd(L.ptr(seg, torch.float32, "seg"), L.ptr(label, torch.int64, "label"), L.ptr(part),
+                                L.ptr(sums), B, nc, h, w, H, W, int(ignore_index), L.stream())
+        ctx.save_for_backward(seg, label, sums)
+        ctx.ignore = int(ignore_index)
+        # mean over an empty set is NaN in F.cross_entropy too (0/0)
+        return 0.5 * (sums[0] / sums[1] + sums[2] / sums[3])
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _lib as L
+        seg, label, sums = ctx.saved_tensors
+        B, nc, h, w = seg.shape
+        H, W = label.shape[1:]
+        wts = (0.5 * g / sums[[1, 3]]).float().contiguous()
+        ghr = torch.empty(B, nc, H, W, device=seg.device, dtype=torch.float32)
+        L.lib().wc_seg_loss_bwd(L.ptr(seg), L.ptr(label), L.ptr(wts, torch.float32, "wts"), L.ptr(ghr), B, nc, h, w, H, W,
+                                ctx.ignore, L.stream())
+        out = torch.empty_like(seg)
+        tmp = torch.empty(B * nc * H * w, device=seg.device, dtype=torch.float32)
+        L.lib().wc_bilinear_resize_bwd(L.ptr(ghr), L.ptr(out), L.ptr(tmp), B * nc, h, w, H, W, 0, L.stream())
+        return out, None, None
+
+
+def get_seg_loss_fused(seg_lowres, label, ignore_index=255):
+    """== get_seg_loss(F.interpolate(seg_lowres, label.shape[1:], 'bilinear', align_corners=False), label)."""
+    return _SegLossFn.apply(seg_lowres, label, ignore_index)
