@@ -150,7 +150,7 @@ int wc_cls_rows(float* x, const float* cls, const float* pos0, int B, int L, int
  * wc_attn_bwd_colsum: column sums over tokens of dq,dk,dv -> c (P,3E) f32 from the packed
  *   qkv (B*L,3E fp16, q pre-scaled), dO (P*L,E fp16), o32 (B*L,E), lse (B,H,L).
  *   Workspaces: delta,u,dS0,P0 each (P,H,L) f32.
- * wc_rowvec_matmul: out (P,E) = scale * c (P,N) @ W (N,E), fp32 FMA.
+ * wc_rowvec_matmul: out (P,E) = scale * c (P,N) @ W (N,E), fp32 FMA; ws: workspace 16*P*E f32.
  * wc_cam_map: cam (P,L-1) = scale_cam(scale_cam(relu(A w))) with A = a32[img, 1:, :]
  *   (base_cam.py:56-60,144-154; utils/image.py:51-61). */
 int wc_cam_head(const float* x2, const float* lnw, const float* lnb, const float* proj,
@@ -164,7 +164,7 @@ int wc_ln2_bwd_add(const float* da2, const float* dx2, const float* x1, const fl
 int wc_attn_bwd_colsum(const void* qkv, const void* dO, const float* o32, const float* lse,
                        const int* pair_img, float* delta, float* u, float* dS0, float* P0, float* c,
                        int P, int L, int H, int DH, void* stream);
-int wc_rowvec_matmul(const float* c, const float* W, float* out, int P, int N, int E, float scale,
+int wc_rowvec_matmul(const float* c, const float* W, float* out, float* ws, int P, int N, int E, float scale,
                      void* stream);
 int wc_cam_map(const float* a32, const float* w, const int* pair_img, float* cam, int P, int L, int E,
                void* stream);

@@ -74,7 +74,21 @@ __global__ __launch_bounds__(256) void matvec_cols_kernel(const float* __restric
     float acc[MAXK] = {0.f, 0.f, 0.f, 0.f};
     if (j < hw) {
         const float* Wb = W + (long)b * hw * hw + j;
-        for (int i = wv; i < hw; i += 4) {
+        int i = wv;
+        for (; i + 28 < hw; i += 32) {      // 8 rows per trip: their W loads are issued before the FMAs
+            float wr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                wr[u] = Wb[(long)(i + 4 * u) * hw] * (sin ? sin[(long)b * hw + i + 4 * u] : 1.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float* xr = X + ((long)b * hw + i + 4 * u) * K + k0;
+#pragma unroll
+                for (int k = 0; k < MAXK; ++k)
+                    if (k < kn) acc[k] = fmaf(wr[u], xr[k], acc[k]);
+            }
+        }
+        for (; i < hw; i += 4) {
             const float wv_ = Wb[(long)i * hw] * (sin ? sin[(long)b * hw + i] : 1.f);
             const float* xr = X + ((long)b * hw + i) * K + k0;
 #pragma unroll

@@ -427,26 +427,28 @@ __global__ __launch_bounds__(256) void qkv_colsum_kernel(const __half* __restric
 }
 
 // (l) cam[p, l] = norm(norm(relu(sum_c w[p,c] A[img, l+1, c]))), norm(z) = (z - min z)/(1e-7 + max(z - min z))
-//     base_cam.py:56-60,144-154 + utils/image.py:51-61.  One 1024-thread block per pair.
-__global__ __launch_bounds__(1024) void cam_map_kernel(const float* __restrict__ a32,
-                                                        const float* __restrict__ w,
-                                                        const int* __restrict__ pair_img,
-                                                        float* __restrict__ cam, int L, int E) {
-    extern __shared__ float sm[];   // w[E] | cam[L-1] | red[16]
-    float* ws = sm;
-    float* cs = sm + E;
-    float* red = cs + (L - 1);
-    const int p = blockIdx.x, img = pair_img[p], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int hw = L - 1;
-    for (int e = tid; e < E; e += 1024) ws[e] = w[(long)p * E + e];
-    __syncthreads();
-    for (int l = wv; l < hw; l += 16) {
-        const float* ar = a32 + ((long)img * L + l + 1) * E;
-        float s = 0.f;
-        for (int e = lane; e < E; e += 64) s = fmaf(ws[e], ar[e], s);
-        s = wave_sum(s);
-        if (lane == 0) cs[l] = fmaxf(s, 0.f);
-    }
+//     base_cam.py:56-60,144-154 + utils/image.py:51-61.  cam_raw_kernel: one wave per (pair, token), 16 tokens
+//     per block; cam_norm_kernel: one block per pair does the two min-max passes in LDS.
+__global__ __launch_bounds__(1024) void cam_raw_kernel(const float* __restrict__ a32, const float* __restrict__ w,
+                                                        const int* __restrict__ pair_img, float* __restrict__ cam, int L,
+                                                        int E) {
+    const int p = blockIdx.y, img = pair_img[p], lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l = blockIdx.x * 16 + wv, hw = L - 1;
+    if (l >= hw) return;
+    const float* ar = a32 + ((long)img * L + l + 1) * E;
+    const float* wr = w + (long)p * E;
+    float s = 0.f;
+    for (int e = lane; e < E; e += 64) s = fmaf(wr[e], ar[e], s);
+    s = wave_sum(s);
+    if (lane == 0) cam[(long)p * hw + l] = fmaxf(s, 0.f);
+}
+
+__global__ __launch_bounds__(1024) void cam_norm_kernel(float* __restrict__ cam, int hw) {
+    extern __shared__ float sm[];   // cam[hw] | red[16]
+    float* cs = sm;
+    float* red = cs + hw;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    for (int l = tid; l < hw; l += 1024) cs[l] = cam[(long)p * hw + l];
     __syncthreads();
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
@@ -539,19 +541,24 @@ extern "C" int wc_attn_bwd_colsum(const void* qkv, const void* dO, const float* 
 }
 
 // out[p, e] = scale * sum_n c[p, n] * W[n, e]   (plain fp32 FMA: P is tiny, values span ~1e-9..1e-3)
-// block = 64 columns x 4 row-slices of n (LDS reduce), all pairs of a PB-chunk share each W read.
+// block = 64 columns x 4 row-slices of n (LDS reduce); all pairs of a PB-chunk share each W read; the n
+// range is additionally split over blockIdx.z into `ns` slices (partials summed by a second kernel) so the
+// launch has enough workgroups to fill the chip.
 #define RVM_PB 8
 __global__ __launch_bounds__(256) void rowvec_matmul_kernel(const float* __restrict__ c,
-                                                             const float* __restrict__ W, float* __restrict__ out,
-                                                             int P, int N, int E, float scale) {
+                                                             const float* __restrict__ W, float* __restrict__ part,
+                                                             int P, int N, int E, int nper) {
     __shared__ float red[4][RVM_PB][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane, p0 = blockIdx.y * RVM_PB;
+    const int nbeg = blockIdx.z * nper;
+    int nend = nbeg + nper;
+    if (nend > N) nend = N;
     float acc[RVM_PB];
 #pragma unroll
     for (int k = 0; k < RVM_PB; ++k) acc[k] = 0.f;
     if (e < E)
-        for (int n = wv; n < N; n += 4) {
+        for (int n = nbeg + wv; n < nend; n += 4) {
             const float w = W[(long)n * E + e];
 #pragma unroll
             for (int k = 0; k < RVM_PB; ++k)
@@ -562,24 +569,41 @@ __global__ __launch_bounds__(256) void rowvec_matmul_kernel(const float* __restr
     __syncthreads();
     if (wv == 0 && e < E)
         for (int k = 0; k < RVM_PB && p0 + k < P; ++k)
-            out[(long)(p0 + k) * E + e] = (red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane]) * scale;
+            part[((long)blockIdx.z * P + p0 + k) * E + e] = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
 }
 
-extern "C" int wc_rowvec_matmul(const float* c, const float* W, float* out, int P, int N, int E, float scale,
+__global__ __launch_bounds__(256) void rowvec_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int ns,
+                                                          long n, float scale) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < ns; ++k) s += part[(long)k * n + i];
+    out[i] = s * scale;
+}
+
+// ws: workspace of 16 * P * E floats.
+extern "C" int wc_rowvec_matmul(const float* c, const float* W, float* out, float* ws, int P, int N, int E, float scale,
                                 void* stream) {
-    WC_CHECK_ARG(c && W && out && P > 0 && N > 0 && E > 0 && P <= 65535 * RVM_PB, "wc_rowvec_matmul: bad argument");
-    hipLaunchKernelGGL(rowvec_matmul_kernel, dim3(wc_cdiv(E, 64), wc_cdiv(P, RVM_PB)), dim3(256), 0,
-                       (hipStream_t)stream, c, W, out, P, N, E, scale);
+    WC_CHECK_ARG(c && W && out && ws && P > 0 && N > 0 && E > 0 && P <= 65535 * RVM_PB, "wc_rowvec_matmul: bad argument");
+    const int ns = 16, nper = wc_cdiv(N, ns);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(rowvec_matmul_kernel, dim3(wc_cdiv(E, 64), wc_cdiv(P, RVM_PB), ns), dim3(256), 0, st, c, W, ws, P, N, E,
+                       nper);
     WC_LAUNCH_CHECK("rowvec_matmul_kernel");
+    hipLaunchKernelGGL(rowvec_sum_kernel, dim3(wc_cdiv((long)P * E, 256)), dim3(256), 0, st, ws, out, ns, (long)P * E, scale);
+    WC_LAUNCH_CHECK("rowvec_sum_kernel");
     return WC_OK;
 }
 
 extern "C" int wc_cam_map(const float* a32, const float* w, const int* pair_img, float* cam, int P, int L,
                           int E, void* stream) {
     WC_CHECK_ARG(a32 && w && pair_img && cam && P > 0 && L > 1 && E > 0, "wc_cam_map: bad argument");
-    const size_t sm = (E + (L - 1) + 16) * sizeof(float);
-    WC_CHECK_ARG(sm <= 160 * 1024, "wc_cam_map: token grid too large for LDS");
-    hipLaunchKernelGGL(cam_map_kernel, dim3(P), dim3(1024), sm, (hipStream_t)stream, a32, w, pair_img, cam, L, E);
-    WC_LAUNCH_CHECK("cam_map_kernel");
+    const size_t sm = ((L - 1) + 16) * sizeof(float);
+    WC_CHECK_ARG(sm <= 160 * 1024 && P <= 65535, "wc_cam_map: token grid too large for LDS");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(cam_raw_kernel, dim3(wc_cdiv(L - 1, 16), P), dim3(1024), 0, st, a32, w, pair_img, cam, L, E);
+    WC_LAUNCH_CHECK("cam_raw_kernel");
+    hipLaunchKernelGGL(cam_norm_kernel, dim3(P), dim3(1024), sm, st, cam, L - 1);
+    WC_LAUNCH_CHECK("cam_norm_kernel");
     return WC_OK;
 }

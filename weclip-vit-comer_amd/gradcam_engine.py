@@ -110,7 +110,8 @@ class LastLayerState:
                                L.ptr(pair_img), L.ptr(ws[0]), L.ptr(ws[1]), L.ptr(ws[2]), L.ptr(ws[3]),
                                L.ptr(c), P, Lq, H, DH, st())
         w = torch.empty(P, E, device=dev, dtype=F32)
-        lib.wc_rowvec_matmul(L.ptr(c), L.ptr(bw.w_in), L.ptr(w), P, 3 * E, E, 1.0 / (Lq - 1), st())
+        ws2 = torch.empty(16 * P * E, device=dev, dtype=F32)
+        lib.wc_rowvec_matmul(L.ptr(c), L.ptr(bw.w_in), L.ptr(w), L.ptr(ws2), P, 3 * E, E, 1.0 / (Lq - 1), st())
         cams = torch.empty(P, Lq - 1, device=dev, dtype=F32)
         lib.wc_cam_map(L.ptr(k["a32"]), L.ptr(w), L.ptr(pair_img), L.ptr(cams), P, Lq, E, st())
         return cams, probs, w
