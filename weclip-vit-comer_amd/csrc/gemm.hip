@@ -16,6 +16,7 @@
 // DMA of tile t+1 is issued before the MFMAs of tile t, one barrier per K-tile, 64 KiB LDS -> two
 // workgroups per CU.  blockIdx.x walks N tiles (they share the A tile through L2), blockIdx.y M tiles.
 #include "common.h"
+#include <stdlib.h>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -287,21 +288,180 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
         if (t + 1 < nt) GLDS(t + 1, buf ^ 1);
         const char* As = smem + buf * (2 * TILE);
         const char* Ws = As + TILE;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int ch = 2 * ks + hh;
-            const f16x8 a0 = *reinterpret_cast<const f16x8*>(As + arow[0] + ((ch ^ aswz[0]) << 4));
-            const f16x8 a1 = *reinterpret_cast<const f16x8*>(As + arow[1] + ((ch ^ aswz[1]) << 4));
-            const f16x8 b0 = *reinterpret_cast<const f16x8*>(Ws + brow[0] + ((ch ^ bswz[0]) << 4));
-            const f16x8 b1 = *reinterpret_cast<const f16x8*>(Ws + brow[1] + ((ch ^ bswz[1]) << 4));
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+        // software-pipelined fragment reads: the ds_reads of k-step ks+1 are issued before the MFMAs of
+        // ks (the compiler otherwise parks the wave on lgkmcnt(0) in front of every MFMA group)
+        f16x8 fa0, fa1, fb0, fb1, na0, na1, nb0, nb1;
+#define FRAG_LOAD(ks_, a0_, a1_, b0_, b1_)                                                           \
+        {                                                                                            \
+            const int ch_ = 2 * (ks_) + hh;                                                          \
+            a0_ = *reinterpret_cast<const f16x8*>(As + arow[0] + ((ch_ ^ aswz[0]) << 4));            \
+            a1_ = *reinterpret_cast<const f16x8*>(As + arow[1] + ((ch_ ^ aswz[1]) << 4));            \
+            b0_ = *reinterpret_cast<const f16x8*>(Ws + brow[0] + ((ch_ ^ bswz[0]) << 4));            \
+            b1_ = *reinterpret_cast<const f16x8*>(Ws + brow[1] + ((ch_ ^ bswz[1]) << 4));            \
         }
+#define FRAG_MMA(a0_, a1_, b0_, b1_)                                                                 \
+        {                                                                                            \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0_, b0_, acc[0][0], 0, 0, 0);        \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0_, b1_, acc[0][1], 0, 0, 0);        \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_, b0_, acc[1][0], 0, 0, 0);        \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_, b1_, acc[1][1], 0, 0, 0);        \
+        }
+        // sched_barrier(0) pins the issue order (hipcc otherwise sinks the reads back in front of their use)
+        FRAG_LOAD(0, fa0, fa1, fb0, fb1);
+        FRAG_LOAD(1, na0, na1, nb0, nb1);
+        __builtin_amdgcn_sched_barrier(0);
+        FRAG_MMA(fa0, fa1, fb0, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        FRAG_LOAD(2, fa0, fa1, fb0, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        FRAG_MMA(na0, na1, nb0, nb1);
+        __builtin_amdgcn_sched_barrier(0);
+        FRAG_LOAD(3, na0, na1, nb0, nb1);
+        __builtin_amdgcn_sched_barrier(0);
+        FRAG_MMA(fa0, fa1, fb0, fb1);
+        FRAG_MMA(na0, na1, nb0, nb1);
+        __builtin_amdgcn_sched_barrier(0);
+#undef FRAG_LOAD
+#undef FRAG_MMA
         __syncthreads();
     }
 #undef GLDS
+    gemm_epilogue<AUX>(g, acc, m0, n0, wr, wc, lane, zb, smem, wave);
+}
+
+// Large-M variant: 256x128x64 tile, 512 threads = 4x2 waves (each still 64x64), THREE LDS stages of 48 KiB and
+// a prefetch distance of two K-tiles: the LDS-DMA of tile t+2 is issued while tile t is multiplied, and it stays
+// in flight ACROSS the (raw) barrier -- each wave waits only for its own DMA of the tile about to be read with a
+// counted s_waitcnt vmcnt(6) (6 DMA instructions per thread per stage), then the barrier publishes the tile.
+// Per K-tile: wait(stage t) -> s_barrier -> issue DMA(t+2) into the stage every wave finished reading before
+// that barrier -> 16 MFMAs per wave.  25 % less L2->LDS traffic per flop than the 128x128 tile.
+#define BM2 256
+template <bool AUX>
+__global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [3 stages][A 32 KiB | W 16 KiB]
+    constexpr int TA = BM2 * BK * 2, TW = BN * BK * 2, STAGE = TA + TW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int gx = g.gx, gy = g.gy;
+    const int lin = blockIdx.x;
+    int tx, ty;
+    if (gy >= 16) {
+        const int slot = lin >> 3;
+        ty = (slot / gx) * 8 + (lin & 7);
+        tx = slot - (slot / gx) * gx;
+    } else {
+        ty = lin / gx;
+        tx = lin - ty * gx;
+    }
+    if (ty >= gy) return;
+    const int m0 = ty * BM2, n0 = tx * BN;
+    const long zb = blockIdx.z;
+
+    long aoff[4], woff[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wave * 256 + i * 64 + lane;        // A image: 2048 chunks, 256 per wave
+        const int row = q >> 3;
+        const int c = (q & 7) ^ ((row >> 1) & 7);
+        int ar = m0 + row;
+        if (ar > g.M - 1) ar = g.M - 1;
+        aoff[i] = zb * g.sA + (long)ar * g.lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = wave * 128 + i * 64 + lane;        // W image: 1024 chunks, 128 per wave
+        const int row = q >> 3;
+        const int c = (q & 7) ^ ((row >> 1) & 7);
+        int wrow = n0 + row;
+        if (wrow > g.N - 1) wrow = g.N - 1;
+        woff[i] = zb * g.sW + (long)wrow * g.ldw + c * 8;
+    }
+    const int ktiles = g.K / BK;
+    const int nt = ktiles * g.nseg;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+#define GLDS2(t, st)                                                                                          \
+    {                                                                                                         \
+        const int seg_ = (t) / ktiles;                                                                        \
+        const long k0_ = (long)((t) - seg_ * ktiles) * BK;                                                    \
+        const __half* Ap_ = seg_ == 0 ? g.A[0] : (seg_ == 1 ? g.A[1] : g.A[2]);                               \
+        const __half* Wp_ = seg_ == 0 ? g.W[0] : (seg_ == 1 ? g.W[1] : g.W[2]);                               \
+        char* da_ = smem + (st) * STAGE + wave * 4096;                                                        \
+        char* dw_ = smem + (st) * STAGE + TA + wave * 2048;                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(Ap_ + aoff[i] + k0_), (lds_ptr)(da_ + i * 1024), 16, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(Wp_ + woff[i] + k0_), (lds_ptr)(dw_ + i * 1024), 16, 0, 0); \
+    }
+    const int hh = lane >> 5, l31 = lane & 31;
+    int arow[2], aswz[2], brow[2], bswz[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = wr * 64 + i * 32 + l31, rb = wc * 64 + i * 32 + l31;
+        arow[i] = ra * 128; aswz[i] = (ra >> 1) & 7;
+        brow[i] = rb * 128; bswz[i] = (rb >> 1) & 7;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    GLDS2(0, 0);
+    if (nt > 1) GLDS2(1, 1);
+    int st = 0;
+    for (int t = 0; t < nt; ++t) {
+        // own DMA of tile t landed (tile t+1's 6 instructions may still be in flight), then publish
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nt) {
+            const int st2 = st >= 1 ? st - 1 : 2;     // (t + 2) % 3
+            GLDS2(t + 2, st2);
+        }
+        const char* As = smem + st * STAGE;
+        const char* Ws = As + TA;
+        // software-pipelined fragment reads: the ds_reads of k-step ks+1 are issued before the MFMAs of
+        // ks (the compiler otherwise parks the wave on lgkmcnt(0) in front of every MFMA group)
+        f16x8 fa0, fa1, fb0, fb1, na0, na1, nb0, nb1;
+#define FRAG_LOAD(ks_, a0_, a1_, b0_, b1_)                                                           \
+        {                                                                                            \
+            const int ch_ = 2 * (ks_) + hh;                                                          \
+            a0_ = *reinterpret_cast<const f16x8*>(As + arow[0] + ((ch_ ^ aswz[0]) << 4));            \
+            a1_ = *reinterpret_cast<const f16x8*>(As + arow[1] + ((ch_ ^ aswz[1]) << 4));            \
+            b0_ = *reinterpret_cast<const f16x8*>(Ws + brow[0] + ((ch_ ^ bswz[0]) << 4));            \
+            b1_ = *reinterpret_cast<const f16x8*>(Ws + brow[1] + ((ch_ ^ bswz[1]) << 4));            \
+        }
+#define FRAG_MMA(a0_, a1_, b0_, b1_)                                                                 \
+        {                                                                                            \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0_, b0_, acc[0][0], 0, 0, 0);        \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0_, b1_, acc[0][1], 0, 0, 0);        \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_, b0_, acc[1][0], 0, 0, 0);        \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_, b1_, acc[1][1], 0, 0, 0);        \
+        }
+        // sched_barrier(0) pins the issue order (hipcc otherwise sinks the reads back in front of their use)
+        FRAG_LOAD(0, fa0, fa1, fb0, fb1);
+        FRAG_LOAD(1, na0, na1, nb0, nb1);
+        __builtin_amdgcn_sched_barrier(0);
+        FRAG_MMA(fa0, fa1, fb0, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        FRAG_LOAD(2, fa0, fa1, fb0, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        FRAG_MMA(na0, na1, nb0, nb1);
+        __builtin_amdgcn_sched_barrier(0);
+        FRAG_LOAD(3, na0, na1, nb0, nb1);
+        __builtin_amdgcn_sched_barrier(0);
+        FRAG_MMA(fa0, fa1, fb0, fb1);
+        FRAG_MMA(na0, na1, nb0, nb1);
+        __builtin_amdgcn_sched_barrier(0);
+#undef FRAG_LOAD
+#undef FRAG_MMA
+        st = st == 2 ? 0 : st + 1;
+    }
+#undef GLDS2
+    __syncthreads();     // every wave is done with the operand stages before they are reused by the epilogue
     gemm_epilogue<AUX>(g, acc, m0, n0, wr, wc, lane, zb, smem, wave);
 }
 
@@ -357,6 +517,18 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
              (act != 4 || (ldaux % 4 == 0 && (uintptr_t)aux % 16 == 0)))
                 ? 1 : 0;
     g.gx = wc_cdiv(N, BN);
+    static const int big_min_m = getenv("WECLIP_GEMM_BIG_MIN_M") ? atoi(getenv("WECLIP_GEMM_BIG_MIN_M")) : 4096;
+    if (M >= big_min_m) {     // tall GEMMs (token dimension): 256x128 tile, 3-stage LDS-DMA pipeline
+        g.gy = wc_cdiv(M, BM2);
+        dim3 grid2((unsigned)(g.gx * (g.gy >= 16 ? (g.gy + 7) / 8 * 8 : g.gy)), 1, batch);
+        const size_t lds2 = 3 * (BM2 + BN) * BK * 2;
+        if (act >= 4)
+            hipLaunchKernelGGL(gemm_f16_big_kernel<true>, grid2, dim3(512), lds2, (hipStream_t)stream, g);
+        else
+            hipLaunchKernelGGL(gemm_f16_big_kernel<false>, grid2, dim3(512), lds2, (hipStream_t)stream, g);
+        WC_LAUNCH_CHECK("gemm_f16_big_kernel");
+        return WC_OK;
+    }
     g.gy = wc_cdiv(M, BM);
     dim3 grid((unsigned)(g.gx * ((g.gy + 7) / 8 * 8)), 1, batch);
     const size_t lds = 2 * 2 * BM * BK * 2;
