@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void lnpost_bwd_kernel(const float* __restrict
         for (int e = lane; e < E; e += 64) {
             d32[o + e] = 0.f;
             dhi[o + e] = __float2half(0.f);
-            dlo[o + e] = __float2half(0.f);
+            if (dlo) dlo[o + e] = __float2half(0.f);
         }
         return;
     }
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void lnpost_bwd_kernel(const float* __restrict
         d32[o + e] = v;
         const __half h = __float2half(v);
         dhi[o + e] = h;
-        dlo[o + e] = __float2half(v - __half2float(h));
+        if (dlo) dlo[o + e] = __float2half(v - __half2float(h));
     }
 }
 
@@ -489,7 +489,7 @@ extern "C" int wc_cam_head(const float* x2, const float* lnw, const float* lnb, 
 extern "C" int wc_lnpost_bwd(const float* df, const float* x2, const float* lnw, float gs,
                              const int* pair_img, float* d32, void* dhi, void* dlo, int P, int L, int E,
                              void* stream) {
-    WC_CHECK_ARG(df && x2 && lnw && pair_img && d32 && dhi && dlo && P > 0 && L > 1 && E > 0,
+    WC_CHECK_ARG(df && x2 && lnw && pair_img && d32 && dhi && P > 0 && L > 1 && E > 0,
                  "wc_lnpost_bwd: bad argument");
     const long rows = (long)P * L;
     hipLaunchKernelGGL(lnpost_bwd_kernel, dim3(wc_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, df, x2,

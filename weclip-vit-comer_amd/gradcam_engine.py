@@ -87,12 +87,14 @@ class LastLayerState:
         v = self.m.visual
         # dx2 = gs * d/dx2 (through mean-pool + ln_post)
         dx2 = torch.empty(M, E, device=dev, dtype=F32)
-        dx2s = Split(torch.empty(M, E, device=dev, dtype=F16), torch.empty(M, E, device=dev, dtype=F16))
+        from . import config
+        ex = config.exact()      # fast mode: gradients (scaled by 2^12) as single fp16 operands
+        dx2s = Split(torch.empty(M, E, device=dev, dtype=F16), torch.empty(M, E, device=dev, dtype=F16) if ex else None)
         lib.wc_lnpost_bwd(L.ptr(df), L.ptr(self.x2), L.ptr(v.ln_post.weight.detach().float(), F32),
                           GRAD_SCALE, L.ptr(pair_img), L.ptr(dx2), L.ptr(dx2s.hi), L.ptr(dx2s.lo), P, Lq, E,
                           st())
         # MLP backward: du = (dx2 Wproj) * QuickGELU'(u);  da2 = du Wfc
-        du = Split(torch.empty(M, 4 * E, device=dev, dtype=F16), torch.empty(M, 4 * E, device=dev, dtype=F16))
+        du = Split(torch.empty(M, 4 * E, device=dev, dtype=F16), torch.empty(M, 4 * E, device=dev, dtype=F16) if ex else None)
         ops.gemm(dx2s, bw.pjT, M, 4 * E, E, out16=du.hi, out16lo=du.lo, act=4, aux=k["u32"],
                  rowmap=pair_img, rpg=Lq, ldaux=4 * E)
         da2 = torch.empty(M, E, device=dev, dtype=F32)

@@ -126,7 +126,7 @@ class HeadEngine:
         if dseg is not None:
             d = torch.zeros(M, 64, device=dev, dtype=F32)
             d[:, :nc] = dseg.permute(0, 2, 3, 1).reshape(M, nc)
-            d32, dS = ops.colscale_split(d, None, M, alpha=GS)
+            d32, dS = ops.colscale_split(d, None, M, alpha=GS, with_lo=ex)
             wpT = torch.zeros(E, 64, device=dev, dtype=F32)
             wpT[:, :nc] = self.dec.linear_pred.weight.detach().flatten(1).t()
             dx = torch.empty(M, E, device=dev, dtype=F32)
@@ -145,7 +145,7 @@ class HeadEngine:
             dx = self._block_bwd(ctx["blocks"][i], dx, B, hw, f"dec.transformer.resblocks.{i}.", grads, inv)
         # ---- attn_pred = sigmoid(F^T F):  dF += (Z + Z^T) F
         if dap is not None:
-            S = ops.sigmoid_gram_bwd(dap.contiguous(), ctx["ap"], scale=GS, with_lo=True)
+            S = ops.sigmoid_gram_bwd(dap.contiguous(), ctx["ap"], scale=GS, with_lo=ex)
             hwp = S.hi.shape[-1]
             FT, Kp = ops.transpose_f16(ctx["F32"], hw, E, batch=B, sSrc=hw * E, oR=hwp)   # (E, B*hwp)
             dF = torch.empty(M, E, device=dev, dtype=F32)
@@ -153,9 +153,9 @@ class HeadEngine:
         else:
             dF = dx
         # ---- Dropout2d backward + fuse
-        dFp32, dFp = ops.colscale_split(dF, ctx["drop"], hw)
+        dFp32, dFp = ops.colscale_split(dF, ctx["drop"], hw, with_lo=ex)
         cat = ctx["cat"]
-        dcat = Split(torch.empty(M, n * E, device=dev, dtype=F16), torch.empty(M, n * E, device=dev, dtype=F16))
+        dcat = Split(torch.empty(M, n * E, device=dev, dtype=F16), torch.empty(M, n * E, device=dev, dtype=F16) if ex else None)
         ops.gemm(dFp, _wT(self.fuse.linear_fuse.weight.detach().flatten(1), ex), M, n * E, E, out16=dcat.hi, out16lo=dcat.lo)
         dFT, Kp = ops.transpose_f16(dFp32, M, E)
         catT, _ = ops.transpose_f16(cat.hi, M, n * E, ones_row=True)
@@ -167,7 +167,7 @@ class HeadEngine:
         C = xs[0].hi.shape[1]
         for l, mlp in enumerate(self.fuse.linears_modulelist):
             p = f"fuse.linears_modulelist.{l}."
-            dt2 = Split(dcat.hi.view(-1)[l * E:], dcat.lo.view(-1)[l * E:])
+            dt2 = Split(dcat.hi.view(-1)[l * E:], dcat.lo.view(-1)[l * E:] if ex else None)
             t1 = ctx["t1s"][l]
             dt1_32 = torch.empty(M, E, device=dev, dtype=F32)
             ops.gemm(dt2, _wT(mlp.proj_2.weight, ex), M, E, E, lda=n * E, out32=dt1_32, act=5, auxh=t1.hi, ldaux=E)
@@ -210,8 +210,8 @@ class HeadEngine:
         ex = pk.exact
         wg = lambda dyT, xT, N_, K_, Kp: self._wgrad(dyT, xT, N_, K_, Kp, inv)
         # MLP
-        _, dx2s = ops.colscale_split(dx2, None, M, want32=False)
-        du = Split(torch.empty(M, 4 * E, device=dev, dtype=F16), torch.empty(M, 4 * E, device=dev, dtype=F16))
+        _, dx2s = ops.colscale_split(dx2, None, M, want32=False, with_lo=ex)
+        du = Split(torch.empty(M, 4 * E, device=dev, dtype=F16), torch.empty(M, 4 * E, device=dev, dtype=F16) if ex else None)
         ops.gemm(dx2s, _wT(blk.mlp.c_proj.weight, ex), M, 4 * E, E, out16=du.hi, out16lo=du.lo, act=4, aux=c["u32"],
                  ldaux=4 * E, rpg=1)
         dx2T, Kp = ops.transpose_f16(dx2, M, E)
@@ -234,7 +234,7 @@ class HeadEngine:
         g = wg(g16T, o16T, E, E, Kp)
         grads[prefix + "attn.out_proj.weight"], grads[prefix + "attn.out_proj.bias"] = g[:, :E], g[:, E]
         # attention + in-projection
-        dqkv = ops.attention_bwd(c["qkv"], do16, c["o32"], c["lse"], B, Lq, H, DH, with_lo=True)
+        dqkv = ops.attention_bwd(c["qkv"], do16, c["o32"], c["lse"], B, Lq, H, DH, with_lo=ex)
         da = torch.empty(M, E, device=dev, dtype=F32)
         ops.gemm(dqkv, _wT(blk.attn.in_proj_weight, ex), M, E, 3 * E, out32=da)
         dqT, _ = ops.transpose_f16(dqkv.hi, M, 3 * E)
