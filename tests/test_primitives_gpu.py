@@ -71,6 +71,32 @@ def test_gemm_split_precision_and_scale(ops):
     assert _rel(out.cpu().double(), ref) < 5e-6
 
 
+def test_gemm_persistent_stream(ops):
+    """Grids of more than two workgroups per CU take the persistent tile-stream kernel: ragged M/N edges,
+    several tiles per workgroup, wide (fp16-only) and narrow (fp32 + residual) epilogues, 2 K-segments."""
+    M, N, K = 8300, 1000, 192
+    g = torch.Generator().manual_seed(7)
+    a = torch.randn(M, K, generator=g).half()
+    w = (torch.randn(N, K, generator=g) * 0.05).half()
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ref = a.double() @ w.double().t() + bias.double()
+    ac, wcu, bc = a.cuda(), w.cuda(), bias.cuda()
+    out16 = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+    lo16 = torch.zeros_like(out16)
+    ops.gemm(ac, wcu, M, N, K, bias=bc, out16=out16, out16lo=lo16, act=1)
+    ref1 = ref * torch.sigmoid(1.702 * ref)
+    assert _rel((out16.float() + lo16.float()).cpu().double(), ref1) < 2e-6
+    out = torch.zeros(M, N, device="cuda")
+    ops.gemm(ac, wcu, M, N, K, bias=bc, resid=res.cuda(), out32=out)
+    assert _rel(out.cpu().double(), ref + res.double()) < 2e-6
+    # two K-segments (hi/lo activation against the same weight) through the same stream
+    x = torch.randn(M, K, generator=g)
+    sp = ops.split_f16(x.cuda(), True)
+    ops.gemm(sp, ops.Split(wcu, None), M, N, K, out32=out)
+    assert _rel(out.cpu().double(), x.double() @ w.double().t()) < 5e-6
+
+
 def test_gemm_batched(ops):
     Bn, M, N, K = 3, 130, 70, 64
     g = torch.Generator().manual_seed(1)

@@ -8,3 +8,10 @@ o = torch.empty(M, N, device="cuda", dtype=torch.float16)
 for _ in range(5):
     ops.gemm(a, w, M, N, K, out16=o)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    ops.gemm(a, w, M, N, K, out16=o)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 20
+print(f"M={M} N={N} K={K} dbg={os.environ.get('WECLIP_GEMM_DBG','0')} stream={os.environ.get('WECLIP_GEMM_STREAM','1')}: {ms*1e3:8.1f} us {2.0*M*N*K/ms/1e9:7.1f} TF/s")

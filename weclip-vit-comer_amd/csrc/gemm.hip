@@ -53,102 +53,163 @@ struct GemmArgs {
     const float* cscale;  // optional per-batch column scale after bias: v *= cscale[z*sCS + n] (Dropout2d)
     long sCS;
     int gx, gy;           // tile grid (N tiles, M tiles); the launch is 1-D over gx * roundup8(gy)
+    int dbg;              // WECLIP_GEMM_DBG experiment bits (0 in production)
     int vec;              // outputs / residual are 16-byte addressable per 4 columns: LDS-transposed wide epilogue
 };
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == 1) return v * (1.0f / (1.0f + __expf(-1.702f * v)));
-    if (act == 2) return fmaxf(v, 0.f);
-    if (act == 3) return 1.0f / (1.0f + __expf(-v));
-    return v;
+// Epilogue shared by the kernel variants.  C/D layout of the 32x32 MFMA: col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Every run-time option (activation, fp16 rounding, which outputs
+// exist) is tested once per block of 8/16 accumulator values, never per value: the per-value scalar
+// branches of a naive epilogue cost more than its stores.  Side inputs (residual / aux) of a block are
+// fetched together so the loads overlap; out-of-range rows/cols read a clamped address and are not stored.
+// AUX (act 4/5) is a separate instantiation so the common epilogue carries no aux registers.
+#define WC_EPI_ACT(v_, n_)                                                                        \
+    if (act == 1) {                                                                               \
+        _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_)                                       \
+            (v_)[e_] = (v_)[e_] * (1.0f / (1.0f + __expf(-1.702f * (v_)[e_])));                   \
+    } else if (act == 2) {                                                                        \
+        _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_) (v_)[e_] = fmaxf((v_)[e_], 0.f);      \
+    } else if (act == 3) {                                                                        \
+        _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_) (v_)[e_] = 1.0f / (1.0f + __expf(-(v_)[e_])); \
+    }
+
+// Per-column epilogue constants of a lane's two output columns (bias, scale): fetched BEFORE the K loop of a
+// tile so that their latency (and, with LDS-DMA in flight, the in-order wait behind it) is off the epilogue.
+__device__ __forceinline__ void gemm_colvals(const GemmArgs& g, int n0, int wc, int lane, long zb, float (&bv)[2],
+                                             float (&sc)[2]) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int col = n0 + wc * 64 + ni * 32 + (lane & 31);
+        const int colc = col < g.N ? col : g.N - 1;
+        bv[ni] = g.bias ? g.bias[colc] : 0.f;
+        sc[ni] = (col < g.scale_cols) ? g.scale : 1.0f;
+        if (g.cscale) sc[ni] *= g.cscale[zb * g.sCS + colc];
+    }
 }
 
-// Epilogue shared by the kernel variants.  C/D layout of the 32x32 MFMA: col = lane&31,
-// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Side inputs (residual / aux) of a 32x32 tile are fetched before
-// use so the loads overlap; out-of-range rows/cols read a clamped address and are not stored.
-// AUX (act 4/5) is a separate instantiation so the common epilogue carries no aux registers.
 template <bool AUX>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int m0, int n0, int wr, int wc,
-                                              int lane, long zb, char* smem, int wave) {
+                                              int lane, long zb, char* scratch, const float (&bv)[2],
+                                              const float (&sc)[2]) {
     const long cb = zb * g.sC;
     const int act = g.act;
     const bool has_res = g.resid != nullptr;
+    const bool r16 = g.round16 != 0;
     if (g.vec && !g.P32 && g.C16 && !g.C32) {   // fp32 outputs are already 128-B coalesced per half-wave: measured slower there
         // Wide epilogue: the MFMA C layout gives a lane one column and 16 scattered rows (64 narrow
-        // stores per lane, store-issue bound).  Each wave instead drops its finished 64x64 sub-tile into
-        // its own 16 KiB of the (now idle) operand LDS and re-reads it row-major, 4 columns per lane:
-        // residual / aux side inputs are one 16-B (8-B) load, outputs one 8-B store per 4 values.
-        float* tile = reinterpret_cast<float*>(smem) + wave * 4096;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int cl = ni * 32 + (lane & 31);
-                const int col = n0 + wc * 64 + cl;
-                const int colc = col < g.N ? col : g.N - 1;
-                const float bv = g.bias ? g.bias[colc] : 0.f;
-                float sc = (col < g.scale_cols) ? g.scale : 1.0f;
-                if (g.cscale) sc *= g.cscale[zb * g.sCS + colc];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[mi][ni][r] + bv;
-                    if (g.round16) v = __half2float(__float2half(v));
-                    v *= sc;
-                    if constexpr (!AUX) v = apply_act(v, act);
-                    tile[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + cl] = v;
-                }
-            }
-        // same wave reads what it wrote: LDS ops of a wave complete in order, no barrier needed
+        // stores per lane, store-issue bound).  Each wave instead drops 16 finished rows at a time into
+        // its own 4 KiB of LDS scratch and re-reads them row-major, 4 columns per lane: residual / aux
+        // side inputs are one 16-B (8-B) load, outputs one 8-B store per 4 values.
+        float* tile = reinterpret_cast<float*>(scratch);
         const int c4 = (lane & 15) * 4;
         const int gcol = n0 + wc * 64 + c4;
-#pragma unroll 2
-        for (int it = 0; it < 16; ++it) {
-            const int rl = it * 4 + (lane >> 4);
-            const int grow = m0 + wr * 64 + rl;
-            if (grow >= g.M || gcol >= g.N) continue;
-            const float4 t4 = *reinterpret_cast<const float4*>(tile + rl * 64 + c4);
-            float f[4] = {t4.x, t4.y, t4.z, t4.w};
-            const long o = cb + (long)grow * g.ldc + gcol;
-            const bool full = gcol + 3 < g.N;
-            if constexpr (AUX) {
-                if (act == 4) {
-                    const long arow = g.rowmap ? (long)g.rowmap[grow / g.rpg] * g.rpg + grow % g.rpg : grow;
-                    const float* up = g.aux + arow * g.ldaux + gcol;
-                    float u[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (full) { const float4 u4 = *reinterpret_cast<const float4*>(up); u[0] = u4.x; u[1] = u4.y; u[2] = u4.z; u[3] = u4.w; }
-                    else for (int k = 0; k < 4 && gcol + k < g.N; ++k) u[k] = up[k];
+        const bool full = gcol + 3 < g.N;
+        const bool has_lo = g.C16lo != nullptr;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float sg = 1.0f / (1.0f + __expf(-1.702f * u[k]));
-                        f[k] *= sg * (1.0f + 1.702f * u[k] * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
+        for (int c = 0; c < 4; ++c) {            // rows [16c, 16c+16) of the wave's 64x64 sub-tile
+            const int mi = c >> 1, rq0 = (c & 1) * 8;
+            float v[16];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) v[ni * 8 + rr] = acc[mi][ni][rq0 + rr] + bv[ni];
+            if (r16) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = __half2float(__float2half(v[e]));
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] *= sc[e >> 3];
+            if constexpr (!AUX) { WC_EPI_ACT(v, 16) }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr)
+                    tile[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * 64 + ni * 32 + (lane & 31)] = v[ni * 8 + rr];
+            // same wave reads what it wrote: LDS ops of a wave complete in order, no barrier needed
+            float f[4][4];
+            bool ok[4];
+            long o[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rl = it * 4 + (lane >> 4);
+                const int grow = m0 + wr * 64 + c * 16 + rl;
+                const float4 t4 = *reinterpret_cast<const float4*>(tile + rl * 64 + c4);
+                f[it][0] = t4.x; f[it][1] = t4.y; f[it][2] = t4.z; f[it][3] = t4.w;
+                ok[it] = grow < g.M && gcol < g.N;
+                o[it] = (long)(grow < g.M ? grow : g.M - 1) * g.ldc + (gcol < g.N ? gcol : 0);
+            }
+            if constexpr (AUX) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    if (!ok[it]) continue;
+                    const int grow = m0 + wr * 64 + c * 16 + it * 4 + (lane >> 4);
+                    if (act == 4) {
+                        const long arow = g.rowmap ? (long)g.rowmap[grow / g.rpg] * g.rpg + grow % g.rpg : grow;
+                        const float* up = g.aux + arow * g.ldaux + gcol;
+                        float u[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (full) { const float4 u4 = *reinterpret_cast<const float4*>(up); u[0] = u4.x; u[1] = u4.y; u[2] = u4.z; u[3] = u4.w; }
+                        else for (int k = 0; k < 4 && gcol + k < g.N; ++k) u[k] = up[k];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float sg = 1.0f / (1.0f + __expf(-1.702f * u[k]));
+                            f[it][k] *= sg * (1.0f + 1.702f * u[k] * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
+                        }
+                    } else {
+                        const __half* hp = g.auxh + (long)grow * g.ldaux + gcol;
+                        for (int k = 0; k < 4 && gcol + k < g.N; ++k) f[it][k] *= __half2float(hp[k]) > 0.f ? 1.f : 0.f;   // ReLU'
                     }
-                } else {
-                    const __half* hp = g.auxh + (long)grow * g.ldaux + gcol;
-                    for (int k = 0; k < 4 && gcol + k < g.N; ++k) f[k] *= __half2float(hp[k]) > 0.f ? 1.f : 0.f;   // ReLU'
                 }
             }
             if (has_res) {
-                const float* rp = g.resid + zb * g.sR + (long)grow * g.ldr + gcol;
-                if (full) { const float4 rr = *reinterpret_cast<const float4*>(rp); f[0] += rr.x; f[1] += rr.y; f[2] += rr.z; f[3] += rr.w; }
-                else for (int k = 0; k < 4 && gcol + k < g.N; ++k) f[k] += rp[k];
-            }
-            __half h[4], l[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                h[k] = __float2half(f[k]);
-                l[k] = __float2half(f[k] - __half2float(h[k]));
+                for (int it = 0; it < 4; ++it) {
+                    if (!ok[it]) continue;
+                    const int grow = m0 + wr * 64 + c * 16 + it * 4 + (lane >> 4);
+                    const float* rp = g.resid + zb * g.sR + (long)grow * g.ldr + gcol;
+                    if (full) { const float4 rr4 = *reinterpret_cast<const float4*>(rp); f[it][0] += rr4.x; f[it][1] += rr4.y; f[it][2] += rr4.z; f[it][3] += rr4.w; }
+                    else for (int k = 0; k < 4 && gcol + k < g.N; ++k) f[it][k] += rp[k];
+                }
             }
-            if (full) {
-                *reinterpret_cast<u32x2*>(g.C16 + o) = *reinterpret_cast<u32x2*>(h);
-                if (g.C16lo) *reinterpret_cast<u32x2*>(g.C16lo + o) = *reinterpret_cast<u32x2*>(l);
-            } else {
-                for (int k = 0; k < 4 && gcol + k < g.N; ++k) {
-                    g.C16[o + k] = h[k];
-                    if (g.C16lo) g.C16lo[o + k] = l[k];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                __half h[4], l[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    h[k] = __float2half(f[it][k]);
+                    l[k] = __float2half(f[it][k] - __half2float(h[k]));
+                }
+                if (!ok[it]) continue;
+                if (full) {
+                    *reinterpret_cast<u32x2*>(g.C16 + cb + o[it]) = *reinterpret_cast<u32x2*>(h);
+                    if (has_lo) *reinterpret_cast<u32x2*>(g.C16lo + cb + o[it]) = *reinterpret_cast<u32x2*>(l);
+                } else {
+                    for (int k = 0; k < 4 && gcol + k < g.N; ++k) {
+                        g.C16[cb + o[it] + k] = h[k];
+                        if (has_lo) g.C16lo[cb + o[it] + k] = l[k];
+                    }
                 }
             }
         }
         return;
+    }
+    // all 64 residual values of the wave's sub-tile are requested up front: one memory latency, not four
+    // (the output may alias the residual, so the compiler cannot hoist these loads over the stores itself)
+    float rva[AUX ? 1 : 2][AUX ? 1 : 2][16];
+    if (!AUX && has_res) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int col = n0 + wc * 64 + ni * 32 + (lane & 31);
+                const int colc = col < g.N ? col : g.N - 1;
+                const int rbase = m0 + wr * 64 + mi * 32 + 4 * (lane >> 5);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row > g.M - 1) row = g.M - 1;
+                    rva[AUX ? 0 : mi][AUX ? 0 : ni][r] = g.resid[zb * g.sR + (long)row * g.ldr + colc];
+                }
+            }
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -157,17 +218,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
             const int col = n0 + wc * 64 + ni * 32 + (lane & 31);
             const bool colok = col < g.N;
             const int colc = colok ? col : g.N - 1;
-            const float bv = g.bias ? g.bias[colc] : 0.f;
-            float sc = (col < g.scale_cols) ? g.scale : 1.0f;
-            if (g.cscale) sc *= g.cscale[zb * g.sCS + colc];
             const int rbase = m0 + wr * 64 + mi * 32 + 4 * (lane >> 5);
-            f32x16 rv, uv;
+            float uv[16], v[16], pre[16];
+            float (&rv)[16] = rva[AUX ? 0 : mi][AUX ? 0 : ni];
+            if constexpr (AUX) {      // the aux variants are register-bound: residual per block
+                if (has_res) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row > g.M - 1) row = g.M - 1;
-                rv[r] = has_res ? g.resid[zb * g.sR + (long)row * g.ldr + colc] : 0.f;
-                if constexpr (AUX) {
+                    for (int r = 0; r < 16; ++r) {
+                        int row = rbase + (r & 3) + 8 * (r >> 2);
+                        if (row > g.M - 1) row = g.M - 1;
+                        rv[r] = g.resid[zb * g.sR + (long)row * g.ldr + colc];
+                    }
+                }
+            }
+            if constexpr (AUX) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row > g.M - 1) row = g.M - 1;
                     if (act == 4) {
                         const long arow = g.rowmap ? (long)g.rowmap[row / g.rpg] * g.rpg + row % g.rpg : row;
                         const float u = g.aux[arow * g.ldaux + colc];
@@ -179,25 +247,50 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                float v = acc[mi][ni][r] + bv;
-                if (g.round16) v = __half2float(__float2half(v));
-                v *= sc;
-                const float pre = v;
-                if constexpr (AUX)
-                    v *= uv[r];
-                else
-                    v = apply_act(v, act);
-                v += rv[r];
-                if (colok && row < g.M) {
-                    const long o = cb + (long)row * g.ldc + col;
-                    if (g.P32) g.P32[o] = pre;
-                    if (g.C32) g.C32[o] = v;
-                    if (g.C16) {
-                        const __half h = __float2half(v);
-                        g.C16[o] = h;
-                        if (g.C16lo) g.C16lo[o] = __float2half(v - __half2float(h));
+            for (int r = 0; r < 16; ++r) v[r] = acc[mi][ni][r] + bv[ni];
+            if (r16) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = __half2float(__float2half(v[r]));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { v[r] *= sc[ni]; pre[r] = v[r]; }
+            if constexpr (AUX) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] *= uv[r];
+            } else {
+                WC_EPI_ACT(v, 16)
+            }
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += rv[r];
+            }
+            const long o0 = cb + (long)rbase * g.ldc + col;
+            if (g.P32) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (colok && rbase + dr < g.M) g.P32[o0 + (long)dr * g.ldc] = pre[r];
+                }
+            }
+            if (g.C32) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (colok && rbase + dr < g.M) g.C32[o0 + (long)dr * g.ldc] = v[r];
+                }
+            }
+            if (g.C16) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (colok && rbase + dr < g.M) g.C16[o0 + (long)dr * g.ldc] = __float2half(v[r]);
+                }
+                if (g.C16lo) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        if (colok && rbase + dr < g.M)
+                            g.C16lo[o0 + (long)dr * g.ldc] = __float2half(v[r] - __half2float(__float2half(v[r])));
                     }
                 }
             }
@@ -281,6 +374,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    float bv[2], sc[2];
+    gemm_colvals(g, n0, wc, lane, zb, bv, sc);
     GLDS(0, 0);
     __syncthreads();     // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
     for (int t = 0; t < nt; ++t) {
@@ -326,143 +421,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
         __syncthreads();
     }
 #undef GLDS
-    gemm_epilogue<AUX>(g, acc, m0, n0, wr, wc, lane, zb, smem, wave);
-}
-
-// Large-M variant: 256x128x64 tile, 512 threads = 4x2 waves (each still 64x64), THREE LDS stages of 48 KiB and
-// a prefetch distance of two K-tiles: the LDS-DMA of tile t+2 is issued while tile t is multiplied, and it stays
-// in flight ACROSS the (raw) barrier -- each wave waits only for its own DMA of the tile about to be read with a
-// counted s_waitcnt vmcnt(6) (6 DMA instructions per thread per stage), then the barrier publishes the tile.
-// Per K-tile: wait(stage t) -> s_barrier -> issue DMA(t+2) into the stage every wave finished reading before
-// that barrier -> 16 MFMAs per wave.  25 % less L2->LDS traffic per flop than the 128x128 tile.
-#define BM2 256
-template <bool AUX>
-__global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [3 stages][A 32 KiB | W 16 KiB]
-    constexpr int TA = BM2 * BK * 2, TW = BN * BK * 2, STAGE = TA + TW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int gx = g.gx, gy = g.gy;
-    const int lin = blockIdx.x;
-    int tx, ty;
-    if (gy >= 16) {
-        const int slot = lin >> 3;
-        ty = (slot / gx) * 8 + (lin & 7);
-        tx = slot - (slot / gx) * gx;
-    } else {
-        ty = lin / gx;
-        tx = lin - ty * gx;
-    }
-    if (ty >= gy) return;
-    const int m0 = ty * BM2, n0 = tx * BN;
-    const long zb = blockIdx.z;
-
-    long aoff[4], woff[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = wave * 256 + i * 64 + lane;        // A image: 2048 chunks, 256 per wave
-        const int row = q >> 3;
-        const int c = (q & 7) ^ ((row >> 1) & 7);
-        int ar = m0 + row;
-        if (ar > g.M - 1) ar = g.M - 1;
-        aoff[i] = zb * g.sA + (long)ar * g.lda + c * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int q = wave * 128 + i * 64 + lane;        // W image: 1024 chunks, 128 per wave
-        const int row = q >> 3;
-        const int c = (q & 7) ^ ((row >> 1) & 7);
-        int wrow = n0 + row;
-        if (wrow > g.N - 1) wrow = g.N - 1;
-        woff[i] = zb * g.sW + (long)wrow * g.ldw + c * 8;
-    }
-    const int ktiles = g.K / BK;
-    const int nt = ktiles * g.nseg;
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    typedef const __attribute__((address_space(1))) void* gbl_ptr;
-#define GLDS2(t, st)                                                                                          \
-    {                                                                                                         \
-        const int seg_ = (t) / ktiles;                                                                        \
-        const long k0_ = (long)((t) - seg_ * ktiles) * BK;                                                    \
-        const __half* Ap_ = seg_ == 0 ? g.A[0] : (seg_ == 1 ? g.A[1] : g.A[2]);                               \
-        const __half* Wp_ = seg_ == 0 ? g.W[0] : (seg_ == 1 ? g.W[1] : g.W[2]);                               \
-        char* da_ = smem + (st) * STAGE + wave * 4096;                                                        \
-        char* dw_ = smem + (st) * STAGE + TA + wave * 2048;                                                   \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(Ap_ + aoff[i] + k0_), (lds_ptr)(da_ + i * 1024), 16, 0, 0); \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(Wp_ + woff[i] + k0_), (lds_ptr)(dw_ + i * 1024), 16, 0, 0); \
-    }
-    const int hh = lane >> 5, l31 = lane & 31;
-    int arow[2], aswz[2], brow[2], bswz[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ra = wr * 64 + i * 32 + l31, rb = wc * 64 + i * 32 + l31;
-        arow[i] = ra * 128; aswz[i] = (ra >> 1) & 7;
-        brow[i] = rb * 128; bswz[i] = (rb >> 1) & 7;
-    }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    GLDS2(0, 0);
-    if (nt > 1) GLDS2(1, 1);
-    int st = 0;
-    for (int t = 0; t < nt; ++t) {
-        // own DMA of tile t landed (tile t+1's 6 instructions may still be in flight), then publish
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + 2 < nt) {
-            const int st2 = st >= 1 ? st - 1 : 2;     // (t + 2) % 3
-            GLDS2(t + 2, st2);
-        }
-        const char* As = smem + st * STAGE;
-        const char* Ws = As + TA;
-        // software-pipelined fragment reads: the ds_reads of k-step ks+1 are issued before the MFMAs of
-        // ks (the compiler otherwise parks the wave on lgkmcnt(0) in front of every MFMA group)
-        f16x8 fa0, fa1, fb0, fb1, na0, na1, nb0, nb1;
-#define FRAG_LOAD(ks_, a0_, a1_, b0_, b1_)                                                           \
-        {                                                                                            \
-            const int ch_ = 2 * (ks_) + hh;                                                          \
-            a0_ = *reinterpret_cast<const f16x8*>(As + arow[0] + ((ch_ ^ aswz[0]) << 4));            \
-            a1_ = *reinterpret_cast<const f16x8*>(As + arow[1] + ((ch_ ^ aswz[1]) << 4));            \
-            b0_ = *reinterpret_cast<const f16x8*>(Ws + brow[0] + ((ch_ ^ bswz[0]) << 4));            \
-            b1_ = *reinterpret_cast<const f16x8*>(Ws + brow[1] + ((ch_ ^ bswz[1]) << 4));            \
-        }
-#define FRAG_MMA(a0_, a1_, b0_, b1_)                                                                 \
-        {                                                                                            \
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0_, b0_, acc[0][0], 0, 0, 0);        \
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0_, b1_, acc[0][1], 0, 0, 0);        \
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_, b0_, acc[1][0], 0, 0, 0);        \
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_, b1_, acc[1][1], 0, 0, 0);        \
-        }
-        // sched_barrier(0) pins the issue order (hipcc otherwise sinks the reads back in front of their use)
-        FRAG_LOAD(0, fa0, fa1, fb0, fb1);
-        FRAG_LOAD(1, na0, na1, nb0, nb1);
-        __builtin_amdgcn_sched_barrier(0);
-        FRAG_MMA(fa0, fa1, fb0, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        FRAG_LOAD(2, fa0, fa1, fb0, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        FRAG_MMA(na0, na1, nb0, nb1);
-        __builtin_amdgcn_sched_barrier(0);
-        FRAG_LOAD(3, na0, na1, nb0, nb1);
-        __builtin_amdgcn_sched_barrier(0);
-        FRAG_MMA(fa0, fa1, fb0, fb1);
-        FRAG_MMA(na0, na1, nb0, nb1);
-        __builtin_amdgcn_sched_barrier(0);
-#undef FRAG_LOAD
-#undef FRAG_MMA
-        st = st == 2 ? 0 : st + 1;
-    }
-#undef GLDS2
-    __syncthreads();     // every wave is done with the operand stages before they are reused by the epilogue
-    gemm_epilogue<AUX>(g, acc, m0, n0, wr, wc, lane, zb, smem, wave);
+    gemm_epilogue<AUX>(g, acc, m0, n0, wr, wc, lane, zb, smem + wave * 4096, bv, sc);
 }
 
 // out[i] = alpha * sum_s part[s*n + i]   (split-K reduction: slices are a batched GEMM over K ranges)
@@ -517,18 +476,8 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
              (act != 4 || (ldaux % 4 == 0 && (uintptr_t)aux % 16 == 0)))
                 ? 1 : 0;
     g.gx = wc_cdiv(N, BN);
-    static const int big_min_m = getenv("WECLIP_GEMM_BIG_MIN_M") ? atoi(getenv("WECLIP_GEMM_BIG_MIN_M")) : 4096;
-    if (M >= big_min_m) {     // tall GEMMs (token dimension): 256x128 tile, 3-stage LDS-DMA pipeline
-        g.gy = wc_cdiv(M, BM2);
-        dim3 grid2((unsigned)(g.gx * (g.gy >= 16 ? (g.gy + 7) / 8 * 8 : g.gy)), 1, batch);
-        const size_t lds2 = 3 * (BM2 + BN) * BK * 2;
-        if (act >= 4)
-            hipLaunchKernelGGL(gemm_f16_big_kernel<true>, grid2, dim3(512), lds2, (hipStream_t)stream, g);
-        else
-            hipLaunchKernelGGL(gemm_f16_big_kernel<false>, grid2, dim3(512), lds2, (hipStream_t)stream, g);
-        WC_LAUNCH_CHECK("gemm_f16_big_kernel");
-        return WC_OK;
-    }
+    static const int dbg = getenv("WECLIP_GEMM_DBG") ? atoi(getenv("WECLIP_GEMM_DBG")) : 0;
+    g.dbg = dbg;
     g.gy = wc_cdiv(M, BM);
     dim3 grid((unsigned)(g.gx * ((g.gy + 7) / 8 * 8)), 1, batch);
     const size_t lds = 2 * 2 * BM * BK * 2;
