@@ -71,10 +71,10 @@ def test_gemm_split_precision_and_scale(ops):
     assert _rel(out.cpu().double(), ref) < 5e-6
 
 
-def test_gemm_persistent_stream(ops):
-    """Grids of more than two workgroups per CU take the persistent tile-stream kernel: ragged M/N edges,
-    several tiles per workgroup, wide (fp16-only) and narrow (fp32 + residual) epilogues, 2 K-segments."""
-    M, N, K = 8300, 1000, 192
+def test_gemm_tall_pingpong(ops):
+    """Tall GEMMs (>= 160 tiles of 256x256) take the 256x256 ping-pong kernel: ragged M/N edges, odd and even
+    K-tile counts, wide (fp16-only) and narrow (fp32 + residual) epilogues, 2 K-segments, ReLU' aux path."""
+    M, N, K = 8300, 1300, 192
     g = torch.Generator().manual_seed(7)
     a = torch.randn(M, K, generator=g).half()
     w = (torch.randn(N, K, generator=g) * 0.05).half()
@@ -95,6 +95,16 @@ def test_gemm_persistent_stream(ops):
     sp = ops.split_f16(x.cuda(), True)
     ops.gemm(sp, ops.Split(wcu, None), M, N, K, out32=out)
     assert _rel(out.cpu().double(), x.double() @ w.double().t()) < 5e-6
+    # ReLU backward from a saved fp16 activation (act 5)
+    saved = torch.randn(M, N, generator=g).half()
+    ops.gemm(ac, wcu, M, N, K, out32=out, act=5, auxh=saved.cuda(), ldaux=N)
+    assert _rel(out.cpu().double(), (a.double() @ w.double().t()) * (saved.double() > 0)) < 2e-6
+    # long K (many ring revolutions) against the fp32-accumulating reference
+    K2 = 1536
+    a2 = torch.randn(M, K2, generator=g).half()
+    w2 = (torch.randn(N, K2, generator=g) * 0.05).half()
+    ops.gemm(a2.cuda(), w2.cuda(), M, N, K2, out32=out)
+    assert _rel(out.cpu().double(), a2.double() @ w2.double().t()) < 2e-6
 
 
 def test_gemm_batched(ops):

@@ -424,6 +424,172 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
     gemm_epilogue<AUX>(g, acc, m0, n0, wr, wc, lane, zb, smem + wave * 4096, bv, sc);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256x256x64 "ping-pong" kernel for tall GEMMs (the token dimension): ONE workgroup of 8 waves per CU,
+// wave (wr, wc) = (wave>>2, wave&3) owns a 128x64 block of the tile (128 accumulator registers).
+//
+// The 128x128 kernel above is bound by the L2->LDS path (32 KiB of operands per 2.1 MFLOP); this tile needs
+// half the bytes per flop.  Each K-tile is staged as FOUR 16-KiB half-tiles, in the order they are consumed:
+//   A0 = rows 0..63 of both row groups, B0 = columns 0..31 of all four column groups, B1 = columns 32..63,
+//   A1 = rows 64..127 -- and computed in four phases: (A0,B0) (A0,B1) (A1,B1) (A1,B0), 8 MFMAs each.
+// LDS holds 8 half-tile slots (128 KiB).  Phase p issues the LDS-DMA of half-tile p+5, waits (counted
+// vmcnt) until half-tile p+2 has landed -- three half-tiles stay in flight across the barriers -- and reads
+// its fragments from half-tiles <= p+1; a slot is re-staged three phases after its last read.
+// The two row groups run one barrier apart: while the waves of one group multiply, the other group's waves
+// (their SIMD neighbours) read fragments and issue DMA, so LDS reads, DMA and MFMA overlap.
+#define PP_SLOT 16384
+template <bool AUX>
+__global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 8 half-tile slots [128 rows][64 halfs], XOR-swizzled
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int gx = g.gx, gy = g.gy;
+    const int lin = blockIdx.x;
+    int tx, ty;
+    if (gy >= 16) {          // XCD-aware order, as in the 128x128 kernel
+        const int slot = lin >> 3;
+        ty = (slot / gx) * 8 + (lin & 7);
+        tx = slot - (slot / gx) * gx;
+    } else {
+        ty = lin / gx;
+        tx = lin - ty * gx;
+    }
+    if (ty >= gy) return;
+    const int m0 = ty * 256, n0 = tx * 256;
+
+    // per-thread DMA sources of the four half-tile kinds (two 16-B chunks each)
+    long offA0[2], offA1[2], offB0[2], offB1[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = i * 512 + tid;                 // chunk index inside the half-tile image
+        const int row = q >> 3;
+        const int c = (q & 7) ^ ((row >> 1) & 7);    // logical chunk this lane must fetch (swizzle on the source)
+        int a0 = m0 + (row >> 6) * 128 + (row & 63), a1 = a0 + 64;
+        int b0 = n0 + (row >> 5) * 64 + (row & 31), b1 = b0 + 32;
+        a0 = a0 < g.M ? a0 : g.M - 1; a1 = a1 < g.M ? a1 : g.M - 1;
+        b0 = b0 < g.N ? b0 : g.N - 1; b1 = b1 < g.N ? b1 : g.N - 1;
+        offA0[i] = (long)a0 * g.lda + c * 8; offA1[i] = (long)a1 * g.lda + c * 8;
+        offB0[i] = (long)b0 * g.ldw + c * 8; offB1[i] = (long)b1 * g.ldw + c * 8;
+    }
+    const int ktiles = g.K / BK;
+    const int nt = ktiles * g.nseg;
+    const int nj = 4 * nt;                           // half-tiles in the stream
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    // half-tile j = 4*t + q (q: 0 A0, 1 B0, 2 B1, 3 A1) goes to slot j & 7; q_ and slot_ are compile-time
+#define PP_STAGE(t_, q_, slot_)                                                                              \
+    {                                                                                                         \
+        const int seg__ = (t_) / ktiles;                                                                      \
+        const long k0__ = (long)((t_) - seg__ * ktiles) * BK;                                                 \
+        const __half* P__ = ((q_) == 0 || (q_) == 3) ? (seg__ == 0 ? g.A[0] : (seg__ == 1 ? g.A[1] : g.A[2])) \
+                                                     : (seg__ == 0 ? g.W[0] : (seg__ == 1 ? g.W[1] : g.W[2])); \
+        const long o0__ = (q_) == 0 ? offA0[0] : (q_) == 1 ? offB0[0] : (q_) == 2 ? offB1[0] : offA1[0];      \
+        const long o1__ = (q_) == 0 ? offA0[1] : (q_) == 1 ? offB0[1] : (q_) == 2 ? offB1[1] : offA1[1];      \
+        char* d__ = smem + (slot_) * PP_SLOT + wave * 1024;                                                   \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(P__ + o0__ + k0__), (lds_ptr)d__, 16, 0, 0);               \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(P__ + o1__ + k0__), (lds_ptr)(d__ + 8192), 16, 0, 0);      \
+    }
+    // leave the n_ newest half-tiles (2 DMA instructions each) in flight
+#define PP_WAIT(n_)                                                                 \
+    {                                                                               \
+        const int w__ = (n_);                                                       \
+        if (w__ >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");              \
+        else if (w__ == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         \
+        else if (w__ == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");         \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       \
+    }
+    // fragment read addresses (bytes inside a slot): A rows wr*64 + mi*32 + l31, B rows wc*32 + l31
+    const int hh = lane >> 5, l31 = lane & 31;
+    int aaddr[2][4], baddr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int ra = wr * 64 + mi * 32 + l31;
+            aaddr[mi][ks] = ra * 128 + (((2 * ks + hh) ^ ((ra >> 1) & 7)) << 4);
+        }
+        const int rb = wc * 32 + l31;
+        baddr[ks] = rb * 128 + (((2 * ks + hh) ^ ((rb >> 1) & 7)) << 4);
+    }
+    f32x16 acc[2][2][2];      // [row half a][mi][column half b]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
+    float bv[2], sc[2];
+    gemm_colvals(g, n0, wc, lane, 0, bv, sc);
+
+    // prologue: half-tiles 0..4 (nt >= 2 is guaranteed by the launcher), the first two landed
+    PP_STAGE(0, 0, 0); PP_STAGE(0, 1, 1); PP_STAGE(0, 2, 2); PP_STAGE(0, 3, 3); PP_STAGE(1, 0, 4);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();       // row group 1 runs one barrier behind group 0
+
+    f16x8 fa[2][4], fb0[4], fb1[4];
+#define PP_READ_A(slot_)                                                                                      \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                        \
+        fa[0][ks] = *reinterpret_cast<const f16x8*>(smem + (slot_) * PP_SLOT + aaddr[0][ks]);                 \
+        fa[1][ks] = *reinterpret_cast<const f16x8*>(smem + (slot_) * PP_SLOT + aaddr[1][ks]);                 \
+    }
+#define PP_READ_B(fb_, slot_)                                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                          \
+        fb_[ks] = *reinterpret_cast<const f16x8*>(smem + (slot_) * PP_SLOT + baddr[ks]);
+#define PP_MMA(a_, fb_, b_)                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                        \
+        acc[a_][0][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][ks], fb_[ks], acc[a_][0][b_], 0, 0, 0); \
+        acc[a_][1][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][ks], fb_[ks], acc[a_][1][b_], 0, 0, 0); \
+    }                                                                                                         \
+    asm volatile("" : "+v"(acc[a_][0][b_]), "+v"(acc[a_][1][b_]));   /* keeps the MFMAs inside their phase */
+    // one phase: [fragment reads] -> DMA of half-tile phi+5 -> counted wait -> barrier -> 8 MFMAs -> barrier
+#define PP_PHASE(phi_, READS_, tj_, qj_, slotj_, MMA_)                                                        \
+    {                                                                                                         \
+        READS_;                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if ((phi_) + 5 < nj) PP_STAGE(tj_, qj_, slotj_);                                                      \
+        PP_WAIT(nj - 3 - (phi_));                                                                             \
+        __builtin_amdgcn_s_barrier();                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                                        \
+        MMA_;                                                                                                 \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_s_barrier();                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }
+    for (int t = 0; t < nt; t += 2) {
+        const int phi = 4 * t;
+        // K-tile t (even): slots 0..3; stages half-tiles phi+5.. = (t+1: B0 B1 A1), (t+2: A0)
+        PP_PHASE(phi + 0, PP_READ_B(fb0, 1) PP_READ_A(0), t + 1, 1, 5, PP_MMA(0, fb0, 0));
+        PP_PHASE(phi + 1, PP_READ_B(fb1, 2), t + 1, 2, 6, PP_MMA(0, fb1, 1));
+        PP_PHASE(phi + 2, PP_READ_A(3), t + 1, 3, 7, PP_MMA(1, fb1, 1));
+        PP_PHASE(phi + 3, , t + 2, 0, 0, PP_MMA(1, fb0, 0));
+        if (t + 1 < nt) {
+            // K-tile t+1 (odd): slots 4..7; stages (t+2: B0 B1 A1), (t+3: A0)
+            PP_PHASE(phi + 4, PP_READ_B(fb0, 5) PP_READ_A(4), t + 2, 1, 1, PP_MMA(0, fb0, 0));
+            PP_PHASE(phi + 5, PP_READ_B(fb1, 6), t + 2, 2, 2, PP_MMA(0, fb1, 1));
+            PP_PHASE(phi + 6, PP_READ_A(7), t + 2, 3, 3, PP_MMA(1, fb1, 1));
+            PP_PHASE(phi + 7, , t + 3, 0, 4, PP_MMA(1, fb0, 0));
+        }
+    }
+#undef PP_PHASE
+#undef PP_MMA
+#undef PP_READ_A
+#undef PP_READ_B
+#undef PP_WAIT
+#undef PP_STAGE
+    if (wr == 0) __builtin_amdgcn_s_barrier();       // re-align the two row groups
+    __syncthreads();                                 // every wave is done with the operand slots: epilogue scratch
+    if (g.dbg & 1) return;
+    gemm_epilogue<AUX>(g, acc[0], m0 + wr * 128, n0, 0, wc, lane, 0, smem + wave * 4096, bv, sc);
+    gemm_epilogue<AUX>(g, acc[1], m0 + wr * 128 + 64, n0, 0, wc, lane, 0, smem + wave * 4096, bv, sc);
+}
+
 // out[i] = alpha * sum_s part[s*n + i]   (split-K reduction: slices are a batched GEMM over K ranges)
 __global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                           int nslices, long n, float alpha) {
@@ -478,6 +644,27 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
     g.gx = wc_cdiv(N, BN);
     static const int dbg = getenv("WECLIP_GEMM_DBG") ? atoi(getenv("WECLIP_GEMM_DBG")) : 0;
     g.dbg = dbg;
+    static const int pp_mode = getenv("WECLIP_GEMM_PP") ? atoi(getenv("WECLIP_GEMM_PP")) : 1;
+    static const int pp_min_tiles = getenv("WECLIP_GEMM_PP_MIN_TILES") ? atoi(getenv("WECLIP_GEMM_PP_MIN_TILES")) : 160;
+    const long tiles256 = (long)wc_cdiv(N, 256) * wc_cdiv(M, 256);
+    if (pp_mode && batch == 1 && K * nseg >= 2 * BK && tiles256 >= pp_min_tiles) {   // tall GEMM: 256x256 ping-pong kernel
+        g.gx = wc_cdiv(N, 256);
+        g.gy = wc_cdiv(M, 256);
+        dim3 gridp((unsigned)(g.gx * (g.gy >= 16 ? (g.gy + 7) / 8 * 8 : g.gy)), 1, 1);
+        static bool lds_attr_set = false;
+        if (!lds_attr_set) {      // 128 KiB of dynamic LDS is above the default per-kernel limit
+            WC_CHECK_ARG(hipFuncSetAttribute((const void*)gemm_f16_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PP_SLOT) == hipSuccess &&
+                         hipFuncSetAttribute((const void*)gemm_f16_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PP_SLOT) == hipSuccess,
+                         "wc_gemm_f16: cannot reserve 128 KiB of LDS");
+            lds_attr_set = true;
+        }
+        if (act >= 4)
+            hipLaunchKernelGGL(gemm_f16_pp_kernel<true>, gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
+        else
+            hipLaunchKernelGGL(gemm_f16_pp_kernel<false>, gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
+        WC_LAUNCH_CHECK("gemm_f16_pp_kernel");
+        return WC_OK;
+    }
     g.gy = wc_cdiv(M, BM);
     dim3 grid((unsigned)(g.gx * ((g.gy + 7) / 8 * 8)), 1, batch);
     const size_t lds = 2 * 2 * BM * BK * 2;
