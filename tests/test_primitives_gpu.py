@@ -107,6 +107,27 @@ def test_gemm_tall_pingpong(ops):
     assert _rel(out.cpu().double(), a2.double() @ w2.double().t()) < 2e-6
 
 
+def test_gemm_ragged_rows_split(ops):
+    """65 x 4 tiles of 256x256 on 256 CUs: the 16 ragged rows go to a second launch (128x128 kernel);
+    residual / fp16 hi+lo outputs / saved pre-activation must line up across the seam."""
+    M, N, K = 64 * 256 + 16, 1024, 128
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(M, K, generator=g).half()
+    w = (torch.randn(N, K, generator=g) * 0.05).half()
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ref = a.double() @ w.double().t() + bias.double()
+    out = torch.zeros(M, N, device="cuda")
+    pre = torch.zeros(M, N, device="cuda")
+    ops.gemm(a.cuda(), w.cuda(), M, N, K, bias=bias.cuda(), resid=res.cuda(), out32=out, pre32=pre, act=1)
+    assert _rel(pre.cpu().double(), ref) < 2e-6
+    assert _rel(out.cpu().double(), ref * torch.sigmoid(1.702 * ref) + res.double()) < 2e-6
+    hi = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+    lo = torch.zeros_like(hi)
+    ops.gemm(a.cuda(), w.cuda(), M, N, K, bias=bias.cuda(), out16=hi, out16lo=lo)
+    assert _rel((hi.float() + lo.float()).cpu().double(), ref) < 2e-6
+
+
 def test_gemm_batched(ops):
     Bn, M, N, K = 3, 130, 70, 64
     g = torch.Generator().manual_seed(1)

@@ -658,12 +658,40 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
                          "wc_gemm_f16: cannot reserve 128 KiB of LDS");
             lds_attr_set = true;
         }
+        // A ragged last row of tiles (M % 256 rows) costs every CU a whole extra round when it tips the tile
+        // count over a multiple of the CU count (ViT-B fc1 at 16 x 1025 tokens: 65 x 12 tiles = 3.05 rounds):
+        // those rows then go to the 128x128 kernel in a second, small launch.
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+                n_cu = 256;
+        }
+        const int m_main = M / 256 * 256, m_rem = M - m_main;
+        const bool split = m_rem > 0 && !(act == 4 && rowmap) &&
+                           wc_cdiv((long)g.gx * (g.gy - 1), n_cu) < wc_cdiv((long)g.gx * g.gy, n_cu);
+        if (split) {
+            g.M = m_main;
+            g.gy -= 1;
+            gridp.x = (unsigned)(g.gx * (g.gy >= 16 ? (g.gy + 7) / 8 * 8 : g.gy));
+        }
         if (act >= 4)
             hipLaunchKernelGGL(gemm_f16_pp_kernel<true>, gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
         else
             hipLaunchKernelGGL(gemm_f16_pp_kernel<false>, gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
         WC_LAUNCH_CHECK("gemm_f16_pp_kernel");
-        return WC_OK;
+        if (!split) return WC_OK;
+        for (int i = 0; i < nseg; ++i) g.A[i] += (long)m_main * lda;
+        if (g.resid) g.resid += (long)m_main * ldr;
+        if (g.C32) g.C32 += (long)m_main * ldc;
+        if (g.C16) g.C16 += (long)m_main * ldc;
+        if (g.C16lo) g.C16lo += (long)m_main * ldc;
+        if (g.P32) g.P32 += (long)m_main * ldc;
+        if (g.aux) g.aux += (long)m_main * ldaux;
+        if (g.auxh) g.auxh += (long)m_main * ldaux;
+        g.M = M = m_rem;
+        g.gx = wc_cdiv(N, BN);
     }
     g.gy = wc_cdiv(M, BM);
     dim3 grid((unsigned)(g.gx * ((g.gy + 7) / 8 * 8)), 1, batch);
