@@ -124,7 +124,8 @@ def main():
         return
 
     summ = ops.KernelTimer.summary()
-    peaks = {"gemm_f16_kernel": ("mfma", 2500.0, "TFLOP/s"), "attn_fwd_kernel": ("mfma", 2500.0, "TFLOP/s"),
+    peaks = {"gemm_f16_kernel": ("mfma", 2500.0, "TFLOP/s"), "gemm_f16_pp_kernel": ("mfma", 2500.0, "TFLOP/s"),
+             "gemm_f16_pp_kernel+tail": ("mfma", 2500.0, "TFLOP/s"), "attn_fwd_kernel": ("mfma", 2500.0, "TFLOP/s"),
              "attn_mean_kernel": ("mfma", 2500.0, "TFLOP/s"), "par_iter_kernel": ("hbm", 8000.0, "GB/s")}
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
     # (tools/pmc_traffic.py -> profiles/r01_traffic.json; 2*FETCH_SIZE + WRITE_SIZE, KiB, per the MI355X guide)
@@ -132,7 +133,9 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
     if os.path.exists(tpath) and B == 16 and S == 512 and K == 2:
         t = json.load(open(tpath))
-        for short, full in (("gemm_f16_kernel", "gemm_f16_kernel<false>"), ("par_iter_kernel", "par_iter_kernel<3>"),
+        for short, full in (("gemm_f16_kernel", "gemm_f16_kernel<false>"),
+                            ("gemm_f16_pp_kernel", "gemm_f16_pp_kernel<false>"),
+                            ("par_iter_kernel", "par_iter_kernel<3, true>"),
                             ("attn_fwd_kernel", "attn_fwd_kernel<64>"), ("attn_mean_kernel", "attn_mean_kernel<64>")):
             if full in t:
                 traffic[short] = round(t[full]["hbm_bytes_per_launch"])

@@ -98,6 +98,11 @@ int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const void* W0, 
                 void* C16, void* C16lo, long ldc, int act, int round16, float scale,
                 int scale_cols, float* P32, const float* aux, const int* rowmap, int rpg,
                 long ldaux, const void* auxh, const float* cscale, long sCS, void* stream);
+
+/* Which kernel wc_gemm_f16 runs for a shape (for profiling / roofline bookkeeping only):
+ * 0 = 128x128x64 kernel, 1 = 256x256x64 ping-pong kernel, 2 = ping-pong kernel + 128x128 kernel on the ragged
+ * last M % 256 rows (two launches). */
+int wc_gemm_plan(int M, int N, int K, int nseg, int batch);
 /* out[i] = alpha * sum_s part[s*n + i]: reduction of split-K partial products (the slices are a
  * batched wc_gemm_f16 over K ranges: sA = sW = K/slices, sC = M*N). */
 int wc_sum_slices(const float* part, float* out, int nslices, long n, float alpha, void* stream);

@@ -608,6 +608,28 @@ extern "C" int wc_sum_slices(const float* part, float* out, int nslices, long n,
     return WC_OK;
 }
 
+// Which kernel a shape takes: 0 = 128x128 kernel, 1 = 256x256 ping-pong kernel, 2 = ping-pong kernel on the
+// full 256-row tiles + the 128x128 kernel on the ragged last M % 256 rows (see wc_gemm_f16).
+static int gemm_plan(int M, int N, int K, int nseg, int batch, bool row_mapped_aux) {
+    static const int pp_mode = getenv("WECLIP_GEMM_PP") ? atoi(getenv("WECLIP_GEMM_PP")) : 1;
+    static const int pp_min_tiles = getenv("WECLIP_GEMM_PP_MIN_TILES") ? atoi(getenv("WECLIP_GEMM_PP_MIN_TILES")) : 160;
+    const long gx = wc_cdiv(N, 256), gy = wc_cdiv(M, 256);
+    if (!pp_mode || batch != 1 || (long)K * nseg < 2 * BK || gx * gy < pp_min_tiles) return 0;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+            n_cu = 256;
+    }
+    const bool split = M % 256 != 0 && !row_mapped_aux && wc_cdiv(gx * (gy - 1), n_cu) < wc_cdiv(gx * gy, n_cu);
+    return split ? 2 : 1;
+}
+
+extern "C" int wc_gemm_plan(int M, int N, int K, int nseg, int batch) {
+    return gemm_plan(M, N, K, nseg, batch, false);
+}
+
 extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const void* W0,
                            const void* W1, const void* W2, int nseg, int M, int N, int K, long lda,
                            long ldw, int batch, long sA, long sW, long sC, const float* bias,
@@ -644,10 +666,8 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
     g.gx = wc_cdiv(N, BN);
     static const int dbg = getenv("WECLIP_GEMM_DBG") ? atoi(getenv("WECLIP_GEMM_DBG")) : 0;
     g.dbg = dbg;
-    static const int pp_mode = getenv("WECLIP_GEMM_PP") ? atoi(getenv("WECLIP_GEMM_PP")) : 1;
-    static const int pp_min_tiles = getenv("WECLIP_GEMM_PP_MIN_TILES") ? atoi(getenv("WECLIP_GEMM_PP_MIN_TILES")) : 160;
-    const long tiles256 = (long)wc_cdiv(N, 256) * wc_cdiv(M, 256);
-    if (pp_mode && batch == 1 && K * nseg >= 2 * BK && tiles256 >= pp_min_tiles) {   // tall GEMM: 256x256 ping-pong kernel
+    const int plan = gemm_plan(M, N, K, nseg, batch, act == 4 && rowmap);
+    if (plan) {   // tall GEMM: 256x256 ping-pong kernel
         g.gx = wc_cdiv(N, 256);
         g.gy = wc_cdiv(M, 256);
         dim3 gridp((unsigned)(g.gx * (g.gy >= 16 ? (g.gy + 7) / 8 * 8 : g.gy)), 1, 1);
@@ -661,16 +681,8 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
         // A ragged last row of tiles (M % 256 rows) costs every CU a whole extra round when it tips the tile
         // count over a multiple of the CU count (ViT-B fc1 at 16 x 1025 tokens: 65 x 12 tiles = 3.05 rounds):
         // those rows then go to the 128x128 kernel in a second, small launch.
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess ||
-                hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-                n_cu = 256;
-        }
         const int m_main = M / 256 * 256, m_rem = M - m_main;
-        const bool split = m_rem > 0 && !(act == 4 && rowmap) &&
-                           wc_cdiv((long)g.gx * (g.gy - 1), n_cu) < wc_cdiv((long)g.gx * g.gy, n_cu);
+        const bool split = plan == 2;
         if (split) {
             g.M = m_main;
             g.gy -= 1;

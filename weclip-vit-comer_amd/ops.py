@@ -96,7 +96,11 @@ def gemm(a, w, M, N, K, *, lda=None, ldw=None, bias=None, resid=None, ldr=None, 
                         float(scale), scale_cols, L.ptr(pre32, F32, "pre32"), L.ptr(aux, F32, "aux"),
                         L.ptr(rowmap, torch.int32, "rowmap"), rpg, ldaux, L.ptr(auxh, F16, "auxh"),
                         L.ptr(cscale, F32, "cscale"), sCS, L.stream())
-    KernelTimer.stop("gemm_f16_kernel", t0, 2.0 * M * N * K * batch)   # algorithmic flops (1 pass)
+    if t0 is not None:
+        plan = L.lib().wc_gemm_plan(M, N, K, len(segs), batch)
+        name = ("gemm_f16_kernel", "gemm_f16_pp_kernel", "gemm_f16_pp_kernel+tail")[plan]
+        # algorithmic flops of ONE pass over K (split-precision segments are not counted as extra work)
+        KernelTimer.stop(name, t0, 2.0 * M * N * K * batch, launches=2 if plan == 2 else 1)
 
 
 def layernorm(x, weight, bias, *, eps=1e-5, want32=False, want16=True, with_lo=False, rows=None,
