@@ -106,6 +106,12 @@ int wc_gemm_plan(int M, int N, int K, int nseg, int batch);
 /* out[i] = alpha * sum_s part[s*n + i]: reduction of split-K partial products (the slices are a
  * batched wc_gemm_f16 over K ranges: sA = sW = K/slices, sC = M*N). */
 int wc_sum_slices(const float* part, float* out, int nslices, long n, float alpha, void* stream);
+
+/* Split-K reduction of a weight-gradient GEMM whose X^T operand carried a ones row (the bias-gradient column):
+ * part (nslices, rows, cols+1) -> out_w (rows, cols) dense and out_b (rows); replaces the autograd-produced
+ * .weight/.bias gradients of nn.Linear / 1x1 nn.Conv2d (reference WeCLIP_model/segformer_head.py:22-28). */
+int wc_sum_slices_wb(const float* part, float* out_w, float* out_b, int nslices, int rows, int cols,
+                     float alpha, void* stream);
 /* fp32 -> fp16 hi (+ lo = fp16(x - hi), may be NULL): `.half()` casts of weights/activations
  * (clip/model.py:457-478 convert_weights; clip/myAtt.py:321). */
 int wc_split_f16(const float* x, void* hi, void* lo, long n, void* stream);

@@ -111,3 +111,27 @@ def test_val_mode_original_sizes(tmp_path):
     _, labels, _ = m(synth.make_images(2, H, W).cuda(), ["im0", "im1"], mode="val")
     assert [tuple(l.shape) for l in labels] == sizes
     assert set(np.unique(labels[0].cpu().numpy())) <= {0, 4, 8}
+
+
+def test_train_step_bucket_gradients_match_autograd_path():
+    """TrainStep lets the HIP head write its gradients straight into the flat all-reduce bucket
+    (HeadEngine.direct_grads); they must equal the gradients autograd receives without it."""
+    from weclip_vit_comer_amd.train_step import TrainStep
+    img = synth.make_images(2, H, W).cuda()
+
+    def run(direct):
+        torch.manual_seed(0)
+        m = _model()
+        m.train()
+        step = TrainStep(m, bucket=True)
+        if not direct:
+            m.head_engine.direct_grads = None
+        torch.manual_seed(1)                      # same Dropout2d mask in both runs
+        loss, _, _ = step(img, labels=synth.TINY_LABELS)
+        return loss.item(), step.bucket.flat.clone()
+
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    assert l0 == l1
+    assert g0.abs().max().item() > 0
+    assert torch.equal(g0, g1)

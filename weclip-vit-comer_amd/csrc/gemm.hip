@@ -600,6 +600,30 @@ __global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict
     out[i] = s * alpha;
 }
 
+// Same reduction for a weight-gradient GEMM whose operand carried a ones row: part is (slices, rows, cols+1),
+// columns 0..cols-1 go to the dense weight gradient out_w (rows, cols), the last column to the bias gradient.
+__global__ __launch_bounds__(256) void sum_slices_wb_kernel(const float* __restrict__ part, float* __restrict__ out_w,
+                                                             float* __restrict__ out_b, int nslices, int rows, int cols,
+                                                             float alpha) {
+    const long n = (long)rows * (cols + 1);
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nslices; ++k) s += part[(long)k * n + i];
+    const int r = (int)(i / (cols + 1)), c = (int)(i - (long)r * (cols + 1));
+    if (c < cols) out_w[(long)r * cols + c] = s * alpha;
+    else out_b[r] = s * alpha;
+}
+
+extern "C" int wc_sum_slices_wb(const float* part, float* out_w, float* out_b, int nslices, int rows, int cols,
+                                float alpha, void* stream) {
+    WC_CHECK_ARG(part && out_w && out_b && nslices > 0 && rows > 0 && cols > 0, "wc_sum_slices_wb: bad argument");
+    hipLaunchKernelGGL(sum_slices_wb_kernel, dim3(wc_cdiv((long)rows * (cols + 1), 256)), dim3(256), 0,
+                       (hipStream_t)stream, part, out_w, out_b, nslices, rows, cols, alpha);
+    WC_LAUNCH_CHECK("sum_slices_wb_kernel");
+    return WC_OK;
+}
+
 extern "C" int wc_sum_slices(const float* part, float* out, int nslices, long n, float alpha, void* stream) {
     WC_CHECK_ARG(part && out && nslices > 0 && n > 0, "wc_sum_slices: bad argument");
     hipLaunchKernelGGL(sum_slices_kernel, dim3(wc_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, part, out, nslices,

@@ -36,6 +36,9 @@ class HeadEngine:
         self.E = dec.linear_pred.weight.shape[1]
         self.nc = dec.linear_pred.weight.shape[0]
         self.index = fuse.indexes
+        # name -> fp32 buffer the gradient of that parameter is written INTO (not accumulated) by backward();
+        # set by TrainStep to views of its flat all-reduce bucket so no per-parameter copy/add kernels run
+        self.direct_grads = None
 
     def params(self):
         return list(self.fuse.parameters()) + list(self.dec.parameters())
@@ -120,7 +123,7 @@ class HeadEngine:
         dev = ctx["F32"].device
         GS, inv = GRAD_SCALE, 1.0 / GRAD_SCALE
         grads = {}
-        wg = lambda dyT, xT, N_, K_, Kp: self._wgrad(dyT, xT, N_, K_, Kp, inv)
+        wg = lambda dyT, xT, N_, K_, Kp, wn, bn: self._wgrad(dyT, xT, N_, K_, Kp, inv, grads, wn, bn)
         # ---- linear_pred
         x3h = ctx["blocks"][-1]["x2h"]
         if dseg is not None:
@@ -133,9 +136,7 @@ class HeadEngine:
             ops.gemm(dS, ops.split_f16(wpT, ex), M, E, 64, out32=dx)
             dT, Kp = ops.transpose_f16(d32, M, 64)
             xT, _ = ops.transpose_f16(x3h.hi, M, E, ones_row=True)
-            g = wg(dT, xT, nc, E, Kp)
-            grads["dec.linear_pred.weight"] = g[:, :E].reshape(nc, E, 1, 1)
-            grads["dec.linear_pred.bias"] = g[:, E]
+            wg(dT, xT, nc, E, Kp, "dec.linear_pred.weight", "dec.linear_pred.bias")
         else:
             dx = torch.zeros(M, E, device=dev, dtype=F32)
             grads["dec.linear_pred.weight"] = torch.zeros(nc, E, 1, 1, device=dev)
@@ -159,9 +160,7 @@ class HeadEngine:
         ops.gemm(dFp, _wT(self.fuse.linear_fuse.weight.detach().flatten(1), ex), M, n * E, E, out16=dcat.hi, out16lo=dcat.lo)
         dFT, Kp = ops.transpose_f16(dFp32, M, E)
         catT, _ = ops.transpose_f16(cat.hi, M, n * E, ones_row=True)
-        g = wg(dFT, catT, E, n * E, Kp)
-        grads["fuse.linear_fuse.weight"] = g[:, :n * E].reshape(E, n * E, 1, 1)
-        grads["fuse.linear_fuse.bias"] = g[:, n * E]
+        wg(dFT, catT, E, n * E, Kp, "fuse.linear_fuse.weight", "fuse.linear_fuse.bias")
         # ---- adapters
         xs, Lq = ctx["xs"], ctx["L"]
         C = xs[0].hi.shape[1]
@@ -173,42 +172,47 @@ class HeadEngine:
             ops.gemm(dt2, _wT(mlp.proj_2.weight, ex), M, E, E, lda=n * E, out32=dt1_32, act=5, auxh=t1.hi, ldaux=E)
             dt2T, Kp = ops.transpose_f16(dt2.hi, M, E, ld=n * E)
             t1T, _ = ops.transpose_f16(t1.hi, M, E, ones_row=True)
-            g = wg(dt2T, t1T, E, E, Kp)
-            grads[p + "proj_2.weight"], grads[p + "proj_2.bias"] = g[:, :E], g[:, E]
+            wg(dt2T, t1T, E, E, Kp, p + "proj_2.weight", p + "proj_2.bias")
             dt1T, _ = ops.transpose_f16(dt1_32, M, E)
             xT, _ = ops.transpose_f16(xs[l].hi.view(-1)[C:], hw, C, ld=C, batch=B, sSrc=Lq * C, ones_row=True)
-            g = wg(dt1T, xT, E, C, Kp)
-            grads[p + "proj.weight"], grads[p + "proj.bias"] = g[:, :C], g[:, C]
+            wg(dt1T, xT, E, C, Kp, p + "proj.weight", p + "proj.bias")
         return grads
 
-    @staticmethod
-    def _wgrad(dyT, xT, N_, K_, Kp, inv):
-        """dW (N_, K_) = inv * dY^T X from transposed operands (N_, Kp), (K_, Kp).
-        The output has few 128x128 tiles and a long K (all tokens), so K is split over `ns` slices
-        run as one batched GEMM (slice = z) and summed by wc_sum_slices."""
+    def _dest(self, name, shape):
+        """Where a parameter gradient is written: the caller-provided buffer (TrainStep's flat gradient
+        bucket, `direct_grads`) or a fresh dense tensor."""
+        d = self.direct_grads.get(name) if self.direct_grads else None
+        if d is not None:
+            return d.view(shape)
+        return torch.empty(shape, device=self.dec.linear_pred.weight.device, dtype=F32)
+
+    def _wgrad(self, dyT, xT, N_, K_, Kp, inv, grads, wname, bname):
+        """dW (N_, K_) = inv * dY^T X and db (N_) = inv * dY^T 1 from transposed operands (N_, Kp) and
+        (K_ + 1, Kp) -- the X^T operand carries a row of ones, so the bias gradient is one more output
+        column.  The output has few 128x128 tiles and a long K (all tokens), so K is split over `ns` slices
+        run as one batched GEMM (slice = z); wc_sum_slices_wb sums them straight into the (dense) weight
+        and bias gradient buffers."""
         dev = dyT.hi.device
-        K_ = xT.hi.shape[0]                 # K_ + 1 when xT carries the ones row (bias gradient column)
-        out = torch.empty(N_, K_, device=dev, dtype=F32)
-        tiles = ((N_ + 127) // 128) * ((K_ + 127) // 128)
+        K1 = xT.hi.shape[0]
+        assert K1 == K_ + 1
+        tiles = ((N_ + 127) // 128) * ((K1 + 127) // 128)
         ns = 1
         while ns * 2 * tiles <= 1024 and Kp % (ns * 2 * 64) == 0 and Kp // (ns * 2) >= 256:
             ns *= 2
-        if ns == 1:
-            ops.gemm(dyT, xT, N_, K_, Kp, out32=out, scale=inv, scale_cols=K_)
-            return out
-        part = torch.empty(ns, N_, K_, device=dev, dtype=F32)
+        part = torch.empty(ns, N_, K1, device=dev, dtype=F32)
         ks = Kp // ns
-        ops.gemm(dyT, xT, N_, K_, ks, lda=Kp, ldw=Kp, out32=part, batch=ns, sA=ks, sW=ks, sC=N_ * K_)
+        ops.gemm(dyT, xT, N_, K1, ks, lda=Kp, ldw=Kp, out32=part, batch=ns, sA=ks, sW=ks, sC=N_ * K1)
+        gw, gb = self._dest(wname, (N_, K_)), self._dest(bname, (N_,))
         from . import _lib as L
-        L.lib().wc_sum_slices(L.ptr(part, F32), L.ptr(out, F32), ns, N_ * K_, inv, L.stream())
-        return out
+        L.lib().wc_sum_slices_wb(L.ptr(part, F32), L.ptr(gw, F32), L.ptr(gb, F32), ns, N_, K_, inv, L.stream())
+        grads[wname], grads[bname] = gw, gb
 
     def _block_bwd(self, c, dx2, B, Lq, prefix, grads, inv):
         pk, blk = c["pk"], c["blk"]
         M, E, H, DH = B * Lq, pk.E, pk.H, pk.DH
         dev = dx2.device
         ex = pk.exact
-        wg = lambda dyT, xT, N_, K_, Kp: self._wgrad(dyT, xT, N_, K_, Kp, inv)
+        wg = lambda dyT, xT, N_, K_, Kp, wn, bn: self._wgrad(dyT, xT, N_, K_, Kp, inv, grads, wn, bn)
         # MLP
         _, dx2s = ops.colscale_split(dx2, None, M, want32=False, with_lo=ex)
         du = Split(torch.empty(M, 4 * E, device=dev, dtype=F16), torch.empty(M, 4 * E, device=dev, dtype=F16) if ex else None)
@@ -216,14 +220,12 @@ class HeadEngine:
                  ldaux=4 * E, rpg=1)
         dx2T, Kp = ops.transpose_f16(dx2, M, E)
         zT, _ = ops.transpose_f16(c["z"].hi, M, 4 * E, ones_row=True)
-        g = wg(dx2T, zT, E, 4 * E, Kp)
-        grads[prefix + "mlp.c_proj.weight"], grads[prefix + "mlp.c_proj.bias"] = g[:, :4 * E], g[:, 4 * E]
+        wg(dx2T, zT, E, 4 * E, Kp, prefix + "mlp.c_proj.weight", prefix + "mlp.c_proj.bias")
         da2 = torch.empty(M, E, device=dev, dtype=F32)
         ops.gemm(du, _wT(blk.mlp.c_fc.weight, ex), M, E, 4 * E, out32=da2)
         duT, _ = ops.transpose_f16(du.hi, M, 4 * E)
         a2T, _ = ops.transpose_f16(c["a2"].hi, M, E, ones_row=True)
-        g = wg(duT, a2T, 4 * E, E, Kp)
-        grads[prefix + "mlp.c_fc.weight"], grads[prefix + "mlp.c_fc.bias"] = g[:, :E], g[:, E]
+        wg(duT, a2T, 4 * E, E, Kp, prefix + "mlp.c_fc.weight", prefix + "mlp.c_fc.bias")
         dx1, g16, dgb2 = ops.layernorm_bwd(da2, c["x1"], pk.ln2_w, add=dx2, want32=True, want16=True, alpha=inv)
         grads[prefix + "ln_2.weight"], grads[prefix + "ln_2.bias"] = dgb2[0], dgb2[1]
         # forced-fp16 out-projection (clip/myAtt.py:321): gradient rounded to fp16 on both sides
@@ -231,16 +233,14 @@ class HeadEngine:
         ops.gemm(g16, _wT(blk.attn.out_proj.weight, False), M, E, E, out16=do16)
         g16T, _ = ops.transpose_f16(g16, M, E)
         o16T, _ = ops.transpose_f16(c["o16"], M, E, ones_row=True)
-        g = wg(g16T, o16T, E, E, Kp)
-        grads[prefix + "attn.out_proj.weight"], grads[prefix + "attn.out_proj.bias"] = g[:, :E], g[:, E]
+        wg(g16T, o16T, E, E, Kp, prefix + "attn.out_proj.weight", prefix + "attn.out_proj.bias")
         # attention + in-projection
         dqkv = ops.attention_bwd(c["qkv"], do16, c["o32"], c["lse"], B, Lq, H, DH, with_lo=ex)
         da = torch.empty(M, E, device=dev, dtype=F32)
         ops.gemm(dqkv, _wT(blk.attn.in_proj_weight, ex), M, E, 3 * E, out32=da)
         dqT, _ = ops.transpose_f16(dqkv.hi, M, 3 * E)
         aT, _ = ops.transpose_f16(c["a"].hi, M, E, ones_row=True)
-        g = wg(dqT, aT, 3 * E, E, Kp)
-        grads[prefix + "attn.in_proj_weight"], grads[prefix + "attn.in_proj_bias"] = g[:, :E], g[:, E]
+        wg(dqT, aT, 3 * E, E, Kp, prefix + "attn.in_proj_weight", prefix + "attn.in_proj_bias")
         dx, _, dgb1 = ops.layernorm_bwd(da, c["x"], pk.ln1_w, add=dx1, want32=True, alpha=inv)
         grads[prefix + "ln_1.weight"], grads[prefix + "ln_1.bias"] = dgb1[0], dgb1[1]
         return dx
@@ -260,6 +260,15 @@ class HeadFunction(torch.autograd.Function):
         eng = ctx.engine
         g = eng.backward(ctx.c, dseg.contiguous() if dseg is not None else None,
                          dap.contiguous() if dap is not None else None)
-        out = [g[n].reshape(p.shape) for n, p in zip(eng.param_names(), eng.params())]
         ctx.c = None
+        direct = eng.direct_grads
+        out = []
+        for n, p in zip(eng.param_names(), eng.params()):
+            d = direct.get(n) if direct else None
+            if d is None:
+                out.append(g[n].reshape(p.shape))
+                continue
+            if g[n].data_ptr() != d.data_ptr():      # produced outside _wgrad (LayerNorm, zero heads)
+                d.copy_(g[n].reshape(d.shape))
+            out.append(None)                          # already in the caller's buffer
         return (None,) * 7 + tuple(out)

@@ -97,7 +97,7 @@ def gemm(a, w, M, N, K, *, lda=None, ldw=None, bias=None, resid=None, ldr=None, 
                         L.ptr(rowmap, torch.int32, "rowmap"), rpg, ldaux, L.ptr(auxh, F16, "auxh"),
                         L.ptr(cscale, F32, "cscale"), sCS, L.stream())
     if t0 is not None:
-        plan = L.lib().wc_gemm_plan(M, N, K, len(segs), batch)
+        plan = L.lib().cdll.wc_gemm_plan(M, N, K, len(segs), batch)   # value-returning query, not an error code
         name = ("gemm_f16_kernel", "gemm_f16_pp_kernel", "gemm_f16_pp_kernel+tail")[plan]
         # algorithmic flops of ONE pass over K (split-precision segments are not counted as extra work)
         KernelTimer.stop(name, t0, 2.0 * M * N * K * batch, launches=2 if plan == 2 else 1)
@@ -176,7 +176,7 @@ def transpose_f16(src, R, C, *, ld=None, batch=1, sSrc=0, with_lo=False, scale=1
     K = (batch - 1) * oR + R
     Kp = (batch * oR + 63) // 64 * 64
     dev = src.device
-    alloc = torch.zeros if (Kp != K or ones_row) else torch.empty
+    alloc = torch.zeros if Kp != K else torch.empty      # only the K padding needs zeros
     rows = C + 1 if ones_row else C     # optional extra row of ones: dY^T [X | 1] yields the bias gradient too
     hi = alloc(rows, Kp, device=dev, dtype=F16)
     lo = alloc(rows, Kp, device=dev, dtype=F16) if with_lo else None
@@ -184,6 +184,8 @@ def transpose_f16(src, R, C, *, ld=None, batch=1, sSrc=0, with_lo=False, scale=1
         if oR != R:
             raise RuntimeError("ones_row needs densely packed batches")
         hi[C, :K] = 1.0
+        if lo is not None:
+            lo[C].zero_()
     f32 = src.dtype == F32
     L.lib().wc_transpose_f16(L.ptr(src, F32 if f32 else F16, "src"), 1 if f32 else 0, ld, sSrc, L.ptr(hi), L.ptr(lo),
                              Kp, oR, batch, R, C, float(scale), L.stream())

@@ -4,6 +4,8 @@ one RCCL all-reduce of the adapter+decoder gradients (5,985,045 fp32 = 23.9 MB i
 the frozen CLIP encoder is replicated and never reduced).  The reference itself is single-GPU
 (SURVEY.md §0-3); this is the DP launcher the build adds beside it.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -56,6 +58,11 @@ class TrainStep:
         self.radius, self.ignore = radius, ignore_index
         self._mask = {}
         self.bucket = GradBucket(model.get_param_groups()[3]) if bucket else None
+        eng = getattr(model, "head_engine", None)
+        if self.bucket is not None and eng is not None and os.environ.get("WECLIP_DIRECT_GRADS", "1") != "0":
+            # the HIP head writes every adapter/decoder gradient straight into the bucket views
+            # (the bucket is zeroed each step and each gradient is written exactly once per backward)
+            eng.direct_grads = {n: p.grad for n, p in zip(eng.param_names(), eng.params()) if p.grad is not None}
 
     def mask(self, h, w, device):
         key = (h, w, str(device))
