@@ -74,6 +74,12 @@ int wc_seg_loss_fwd(const float* seg, const int64_t* label, float* part, float* 
 int wc_seg_loss_bwd(const float* seg, const int64_t* label, const float* wts, float* ghr, int B, int nc, int h,
                     int w, int H, int W, int ignore, void* stream);
 
+/* One-pass form of the same backward: dseg (B, nc, h, w) = d loss / d low-res logits, without the (B, nc, H, W)
+ * high-res gradient workspace or the resize-backward passes (needs nc * w <= 2048 and the three low-res rows +
+ * one high-res row of statistics to fit 64 KiB of LDS; otherwise use wc_seg_loss_bwd + wc_bilinear_resize_bwd). */
+int wc_seg_loss_bwd_fused(const float* seg, const int64_t* label, const float* wts, float* dseg, int B, int nc,
+                          int h, int w, int H, int W, int ignore, void* stream);
+
 /* ---- MFMA GEMM ------------------------------------------------------------------------ */
 /* C[M,N] = epilogue(sum_{s<nseg} A_s[M,K] * W_s[N,K]^T), fp16 operands (K contiguous), fp32
  * accumulate on v_mfma_f32_32x32x16_f16.  Replaces F.linear / nn.Linear / 1x1 Conv2d / bmm at

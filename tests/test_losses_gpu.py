@@ -9,11 +9,12 @@ from oracle import weclip_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B,nc,h,w,scale", [(2, 21, 4, 6, 16), (1, 5, 7, 5, 16), (2, 21, 32, 32, 16)])
+@pytest.mark.parametrize("B,nc,h,w,scale", [(2, 21, 4, 6, 16), (1, 5, 7, 5, 16), (2, 21, 32, 32, 16),
+                                           (1, 4, 5, 7, 9.5), (1, 3, 12, 10, 1)])
 def test_fused_seg_loss_forward_backward(B, nc, h, w, scale):
     from weclip_vit_comer_amd.utils.losses import get_seg_loss_fused
     g = torch.Generator().manual_seed(h)
-    H, W = h * scale, w * scale
+    H, W = int(h * scale), int(w * scale)       # 9.5: non-integer ratio; 1: identity resize
     seg = torch.randn(B, nc, h, w, generator=g)
     lab = torch.randint(0, nc, (B, H, W), generator=g)
     lab[:, : H // 3] = 0
