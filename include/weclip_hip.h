@@ -57,7 +57,7 @@ int wc_bilinear_resize(const float* src, float* dst, int planes, int Hs, int Ws,
                        int align_corners, void* stream);
 /* backward of the same (up-sampling): gsrc (planes,Hs,Ws) = sum over destination pixels of their
  * gradient gdst (planes,Hd,Wd) times the interpolation weight; separable two-pass gather, no atomics
- * (tmp: planes*Hd*Ws f32 workspace)
+ * (tmp: planes*Hs*Wd f32 workspace)
  * (autograd of F.interpolate at scripts/dist_clip_voc.py:250). */
 int wc_bilinear_resize_bwd(const float* gdst, float* gsrc, float* tmp, int planes, int Hs, int Ws, int Hd,
                            int Wd, int align_corners, void* stream);
@@ -73,12 +73,6 @@ int wc_seg_loss_fwd(const float* seg, const int64_t* label, float* part, float* 
                     int H, int W, int ignore, void* stream);
 int wc_seg_loss_bwd(const float* seg, const int64_t* label, const float* wts, float* ghr, int B, int nc, int h,
                     int w, int H, int W, int ignore, void* stream);
-
-/* One-pass form of the same backward: dseg (B, nc, h, w) = d loss / d low-res logits, without the (B, nc, H, W)
- * high-res gradient workspace or the resize-backward passes (needs nc * w <= 2048 and the three low-res rows +
- * one high-res row of statistics to fit 64 KiB of LDS; otherwise use wc_seg_loss_bwd + wc_bilinear_resize_bwd). */
-int wc_seg_loss_bwd_fused(const float* seg, const int64_t* label, const float* wts, float* dseg, int B, int nc,
-                          int h, int w, int H, int W, int ignore, void* stream);
 
 /* ---- MFMA GEMM ------------------------------------------------------------------------ */
 /* C[M,N] = epilogue(sum_{s<nseg} A_s[M,K] * W_s[N,K]^T), fp16 operands (K contiguous), fp32

@@ -35,17 +35,40 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__
 
 // Backward of the bilinear up-sampling, separable and deterministic (ATen's backward scatters with
 // atomics): bilinear interpolation is R_y (x) R_x with two non-zeros per destination row, so
-//   pass X: tmp[p, y, xs]  = sum_x  wx(x -> xs) * gdst[p, y, x]          (Hd x Wd -> Hd x Ws)
-//   pass Y: gsrc[p, ys, xs] = sum_y wy(y -> ys) * tmp[p, y, xs]          (Hd x Ws -> Hs x Ws)
+//   pass Y: tmp[p, ys, x]   = sum_y wy(y -> ys) * gdst[p, y, x]          (Hd x Wd -> Hs x Wd)
+//   pass X: gsrc[p, ys, xs] = sum_x wx(x -> xs) * tmp[p, ys, x]          (Hs x Wd -> Hs x Ws)
 // each output sums the ~2*scale destinations that can touch it.
-__global__ __launch_bounds__(256) void bilinear_bwd_x_kernel(const float* __restrict__ gdst, float* __restrict__ tmp,
-                                                              int Ws, int Hd, int Wd, float sx, int align) {
+// Pass Y first: it runs on the big (Hd x Wd) gradient with lanes along x, so every read is a coalesced row
+// segment; the strided pass X then only sees the (Hs x Wd) intermediate.
+__global__ __launch_bounds__(256) void bilinear_bwd_y_kernel(const float* __restrict__ gdst, float* __restrict__ tmp,
+                                                              int Hs, int Hd, int Wd, float sy, int align) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ys = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= Wd || ys >= Hs) return;
+    const float* G = gdst + (long)blockIdx.z * Hd * Wd + x;
+    const float iy = 1.0f / sy;
+    // destinations whose source coordinate can fall in (ys-1, ys+1), either index convention
+    int y_lo = (int)floorf((ys - 1.5f) * iy) - 1, y_hi = (int)ceilf((ys + 1.5f) * iy) + 1;
+    if (y_lo < 0) y_lo = 0;
+    if (y_hi > Hd - 1) y_hi = Hd - 1;
+    float acc = 0.f;
+    for (int y = y_lo; y <= y_hi; ++y) {
+        int y0, y1;
+        float ly;
+        src_index(y, Hs, sy, align, y0, y1, ly);
+        const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);   // wave-uniform
+        if (wy != 0.f) acc = fmaf(wy, G[(long)y * Wd], acc);
+    }
+    tmp[((long)blockIdx.z * Hs + ys) * Wd + x] = acc;
+}
+
+__global__ __launch_bounds__(256) void bilinear_bwd_x_kernel(const float* __restrict__ tmp, float* __restrict__ gsrc,
+                                                              int Hs, int Ws, int Wd, float sx, int align) {
     const int xs = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (xs >= Ws || y >= Hd) return;
-    const float* G = gdst + ((long)blockIdx.z * Hd + y) * Wd;
+    const int ys = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xs >= Ws || ys >= Hs) return;
+    const float* T = tmp + ((long)blockIdx.z * Hs + ys) * Wd;
     const float ix = 1.0f / sx;
-    // destinations whose source coordinate can fall in (xs-1, xs+1), either index convention
     int x_lo = (int)floorf((xs - 1.5f) * ix) - 1, x_hi = (int)ceilf((xs + 1.5f) * ix) + 1;
     if (x_lo < 0) x_lo = 0;
     if (x_hi > Wd - 1) x_hi = Wd - 1;
@@ -55,33 +78,12 @@ __global__ __launch_bounds__(256) void bilinear_bwd_x_kernel(const float* __rest
         float lx;
         src_index(x, Ws, sx, align, x0, x1, lx);
         const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
-        acc = fmaf(wx, G[x], acc);
-    }
-    tmp[((long)blockIdx.z * Hd + y) * Ws + xs] = acc;
-}
-
-__global__ __launch_bounds__(256) void bilinear_bwd_y_kernel(const float* __restrict__ tmp, float* __restrict__ gsrc,
-                                                              int Hs, int Ws, int Hd, float sy, int align) {
-    const int xs = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ys = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (xs >= Ws || ys >= Hs) return;
-    const float* T = tmp + (long)blockIdx.z * Hd * Ws + xs;
-    const float iy = 1.0f / sy;
-    int y_lo = (int)floorf((ys - 1.5f) * iy) - 1, y_hi = (int)ceilf((ys + 1.5f) * iy) + 1;
-    if (y_lo < 0) y_lo = 0;
-    if (y_hi > Hd - 1) y_hi = Hd - 1;
-    float acc = 0.f;
-    for (int y = y_lo; y <= y_hi; ++y) {
-        int y0, y1;
-        float ly;
-        src_index(y, Hs, sy, align, y0, y1, ly);
-        const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
-        acc = fmaf(wy, T[(long)y * Ws], acc);
+        acc = fmaf(wx, T[x], acc);
     }
     gsrc[((long)blockIdx.z * Hs + ys) * Ws + xs] = acc;
 }
 
-// tmp: workspace planes*Hd*Ws floats.
+// tmp: workspace planes*Hs*Wd floats.
 extern "C" int wc_bilinear_resize_bwd(const float* gdst, float* gsrc, float* tmp, int planes, int Hs, int Ws, int Hd,
                                       int Wd, int align_corners, void* stream) {
     WC_CHECK_ARG(gdst && gsrc && tmp && planes > 0 && planes <= 65535 && Hs > 0 && Ws > 0 && Hd >= Hs && Wd >= Ws,
@@ -96,12 +98,12 @@ extern "C" int wc_bilinear_resize_bwd(const float* gdst, float* gsrc, float* tmp
         sx = (float)Ws / Wd;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bilinear_bwd_x_kernel, dim3(wc_cdiv(Ws, 64), wc_cdiv(Hd, 4), planes), dim3(256), 0, st, gdst, tmp, Ws,
-                       Hd, Wd, sx, align_corners ? 1 : 0);
-    WC_LAUNCH_CHECK("bilinear_bwd_x_kernel");
-    hipLaunchKernelGGL(bilinear_bwd_y_kernel, dim3(wc_cdiv(Ws, 64), wc_cdiv(Hs, 4), planes), dim3(256), 0, st, tmp, gsrc, Hs,
-                       Ws, Hd, sy, align_corners ? 1 : 0);
+    hipLaunchKernelGGL(bilinear_bwd_y_kernel, dim3(wc_cdiv(Wd, 64), wc_cdiv(Hs, 4), planes), dim3(256), 0, st, gdst, tmp, Hs,
+                       Hd, Wd, sy, align_corners ? 1 : 0);
     WC_LAUNCH_CHECK("bilinear_bwd_y_kernel");
+    hipLaunchKernelGGL(bilinear_bwd_x_kernel, dim3(wc_cdiv(Ws, 64), wc_cdiv(Hs, 4), planes), dim3(256), 0, st, tmp, gsrc, Hs,
+                       Ws, Wd, sx, align_corners ? 1 : 0);
+    WC_LAUNCH_CHECK("bilinear_bwd_x_kernel");
     return WC_OK;
 }
 

@@ -27,7 +27,7 @@ class _BilinearFn(torch.autograd.Function):
         (n, c, hs, ws), (hd, wd), ac = ctx.meta
         g = g.float().contiguous()
         out = torch.empty(n, c, hs, ws, device=g.device, dtype=torch.float32)
-        tmp = torch.empty(n * c * hd * ws, device=g.device, dtype=torch.float32)
+        tmp = torch.empty(n * c * hs * wd, device=g.device, dtype=torch.float32)
         L.lib().wc_bilinear_resize_bwd(L.ptr(g, torch.float32, "grad"), L.ptr(out), L.ptr(tmp), n * c, hs, ws, hd,
                                        wd, 1 if ac else 0, L.stream())
         return out, None, None

@@ -52,14 +52,10 @@ class _SegLossFn(torch.autograd.Function):
         H, W = label.shape[1:]
         wts = (0.5 * g / sums[[1, 3]]).float().contiguous()
         out = torch.empty_like(seg)
-        if nc * w <= 2048 and (3 * nc * w + 3 * W) * 4 <= 64 * 1024:
-            L.lib().wc_seg_loss_bwd_fused(L.ptr(seg), L.ptr(label), L.ptr(wts, torch.float32, "wts"), L.ptr(out), B, nc,
-                                          h, w, H, W, ctx.ignore, L.stream())
-            return out, None, None
         ghr = torch.empty(B, nc, H, W, device=seg.device, dtype=torch.float32)
         L.lib().wc_seg_loss_bwd(L.ptr(seg), L.ptr(label), L.ptr(wts, torch.float32, "wts"), L.ptr(ghr), B, nc, h, w, H, W,
                                 ctx.ignore, L.stream())
-        tmp = torch.empty(B * nc * H * w, device=seg.device, dtype=torch.float32)
+        tmp = torch.empty(B * nc * h * W, device=seg.device, dtype=torch.float32)
         L.lib().wc_bilinear_resize_bwd(L.ptr(ghr), L.ptr(out), L.ptr(tmp), B * nc, h, w, H, W, 0, L.stream())
         return out, None, None
 
