@@ -218,7 +218,7 @@ int wc_cam_upsample(const float* R, const int* nk, float* stats, float* cams, in
  *                    row stride ld, batch stride sSrc; out row stride ldo: operands of dW = dY^T X.
  * wc_colsum:         out[c] = alpha * sum_r src[r,c] (bias gradients); part: ceil(R/256)*C f32.
  * wc_layernorm_bwd:  dx = add + LN_bwd(dy; x, w) as f32 and/or fp16(dx*out_scale);
- *                    dgb (2,D) = alpha*[sum dy*xhat ; sum dy]; part: ceil(rows/64)*2*D f32.
+ *                    dgb (2,D) = alpha*[sum dy*xhat ; sum dy]; part: ceil(rows/16)*2*D f32.
  * wc_sigmoid_gram_bwd: S[b] = scale*(Z + Z^T), Z = dAP*AP*(1-AP) (fp16 hi[,lo], row stride ldo) so dF = S F.
  * wc_colscale_split: y = alpha * x * cs[row / rows_per_batch, col] (cs may be NULL) -> f32 (optional), fp16 hi[,lo]. */
 /* wc_attn_bwd: backward of clip/myAtt.py:21-64 without storing L x L tensors: from the packed qkv

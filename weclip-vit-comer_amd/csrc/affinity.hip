@@ -62,12 +62,15 @@ __global__ void aff_keep_kernel(const float* __restrict__ diff, float* __restric
 
 // out[b,j,k] = f( sum_i W[b,i,j] * X[b,i,k] * (sin ? sin[b,i] : 1) )      (W^T x)
 // f(v) = recip ? 1/v : alpha * v * (sout ? sout[b,j] : 1) + (add ? add[b,j,k] : 0)
-// block = 64 columns x 4 row-slices; X/out are (B, hw, K) with K <= MAXK per launch slice.
-__global__ __launch_bounds__(256) void matvec_cols_kernel(const float* __restrict__ W, const float* __restrict__ X,
+// block = 64 columns x MVC_SLICES row-slices (one wave each: 16 waves per CU keep enough 256-B row reads in
+// flight to stream W); X/out are (B, hw, K) with K <= MAXK per launch slice.
+#define MVC_SLICES 16
+__global__ __launch_bounds__(64 * MVC_SLICES) void matvec_cols_kernel(const float* __restrict__ W, const float* __restrict__ X,
                                                            const float* __restrict__ sin, const float* __restrict__ sout,
                                                            const float* __restrict__ add, float* __restrict__ out,
                                                            int hw, int K, int k0, int recip, float alpha) {
-    __shared__ float red[4][64][MAXK];
+    __shared__ float red[MVC_SLICES][64][MAXK];
+    constexpr int NS = MVC_SLICES;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + lane, b = blockIdx.y;
     const int kn = (K - k0 < MAXK) ? K - k0 : MAXK;
@@ -75,20 +78,20 @@ __global__ __launch_bounds__(256) void matvec_cols_kernel(const float* __restric
     if (j < hw) {
         const float* Wb = W + (long)b * hw * hw + j;
         int i = wv;
-        for (; i + 28 < hw; i += 32) {      // 8 rows per trip: their W loads are issued before the FMAs
+        for (; i + 7 * NS < hw; i += 8 * NS) {      // 8 rows per trip: their W loads are issued before the FMAs
             float wr[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                wr[u] = Wb[(long)(i + 4 * u) * hw] * (sin ? sin[(long)b * hw + i + 4 * u] : 1.f);
+                wr[u] = Wb[(long)(i + NS * u) * hw] * (sin ? sin[(long)b * hw + i + NS * u] : 1.f);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float* xr = X + ((long)b * hw + i + 4 * u) * K + k0;
+                const float* xr = X + ((long)b * hw + i + NS * u) * K + k0;
 #pragma unroll
                 for (int k = 0; k < MAXK; ++k)
                     if (k < kn) acc[k] = fmaf(wr[u], xr[k], acc[k]);
             }
         }
-        for (; i < hw; i += 4) {
+        for (; i < hw; i += NS) {
             const float wv_ = Wb[(long)i * hw] * (sin ? sin[(long)b * hw + i] : 1.f);
             const float* xr = X + ((long)b * hw + i) * K + k0;
 #pragma unroll
@@ -101,7 +104,9 @@ __global__ __launch_bounds__(256) void matvec_cols_kernel(const float* __restric
     __syncthreads();
     if (wv == 0 && j < hw) {
         for (int k = 0; k < kn; ++k) {
-            float v = red[0][lane][k] + red[1][lane][k] + red[2][lane][k] + red[3][lane][k];
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < MVC_SLICES; ++q) v += red[q][lane][k];
             const long o = ((long)b * hw + j) * K + k0 + k;
             if (recip) v = 1.0f / v;
             else {
@@ -124,7 +129,20 @@ __global__ __launch_bounds__(256) void matvec_rows_kernel(const float* __restric
     const int kn = (K - k0 < MAXK) ? K - k0 : MAXK;
     float acc[MAXK] = {0.f, 0.f, 0.f, 0.f};
     const float* Wr = W + ((long)b * hw + i) * hw;
-    for (int j = lane; j < hw; j += 64) {
+    int j = lane;
+    for (; j + 192 < hw; j += 256) {       // 4 row segments per trip, loads first
+        float wr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wr[u] = Wr[j + 64 * u] * (sin ? sin[(long)b * hw + j + 64 * u] : 1.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* xr = X + ((long)b * hw + j + 64 * u) * K + k0;
+#pragma unroll
+            for (int k = 0; k < MAXK; ++k)
+                if (k < kn) acc[k] = fmaf(wr[u], xr[k], acc[k]);
+        }
+    }
+    for (; j < hw; j += 64) {
         const float wv_ = Wr[j] * (sin ? sin[(long)b * hw + j] : 1.f);
         const float* xr = X + ((long)b * hw + j) * K + k0;
 #pragma unroll
@@ -337,7 +355,7 @@ extern "C" int wc_matvec(const float* W, const float* X, const float* sin, const
     hipStream_t st = (hipStream_t)stream;
     for (int k0 = 0; k0 < K; k0 += MAXK) {
         if (transpose)
-            hipLaunchKernelGGL(matvec_cols_kernel, dim3(wc_cdiv(hw, 64), B), dim3(256), 0, st, W, X, sin, sout, add,
+            hipLaunchKernelGGL(matvec_cols_kernel, dim3(wc_cdiv(hw, 64), B), dim3(64 * MVC_SLICES), 0, st, W, X, sin, sout, add,
                                out, hw, K, k0, recip, alpha);
         else
             hipLaunchKernelGGL(matvec_rows_kernel, dim3(wc_cdiv(hw, 4), B), dim3(256), 0, st, W, X, sin, sout, add,

@@ -45,17 +45,34 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                             int nblk, int C, float alpha, int round16) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(long)b * C + c];
-    s *= alpha;
-    out[c] = round16 ? __half2float(__float2half(s)) : s;
+    // 64 columns per block, the partial rows dealt over 4 waves (256-B coalesced reads, 4 loads in flight each)
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        int b = rg;
+        for (; b + 12 < nblk; b += 16) {
+            s0 += part[(long)b * C + c];
+            s1 += part[(long)(b + 4) * C + c];
+            s2 += part[(long)(b + 8) * C + c];
+            s3 += part[(long)(b + 12) * C + c];
+        }
+        for (; b < nblk; b += 4) s0 += part[(long)b * C + c];
+    }
+    red[rg][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        float s = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) * alpha;
+        out[c] = round16 ? __half2float(__float2half(s)) : s;
+    }
 }
 
 // LayerNorm backward.  dx = add + rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*w.
 // Outputs: dx32 (optional), dx16 = fp16(dx * out_scale) (optional); per-block partial sums of
-// dgamma = sum dy*xhat and dbeta = sum dy in part (nblk, 2, D).  One wave per row, 16 rows per wave.
+// dgamma = sum dy*xhat and dbeta = sum dy in part (nblk, 2, D).  One wave per row, LNB_ROWS rows per wave
+// (few rows per wave = many waves: the three dependent wave reductions per row are latency, hidden by occupancy).
+#define LNB_ROWS 4
 template <int NV>   // D <= 64*NV
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ w, const float* __restrict__ add,
@@ -66,8 +83,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     float ag[NV], ab[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) ag[i] = ab[i] = 0.f;
-    const long r0 = ((long)blockIdx.x * 4 + wv) * 16;
-    for (long row = r0; row < r0 + 16 && row < rows; ++row) {
+    const long r0 = ((long)blockIdx.x * 4 + wv) * LNB_ROWS;
+    for (long row = r0; row < r0 + LNB_ROWS && row < rows; ++row) {
         const float* xr = x + row * D;
         const float* dr = dy + row * D;
         float xv[NV], dv[NV];
@@ -194,18 +211,18 @@ extern "C" int wc_colsum(const void* src, int src_f32, long ld, float* part, flo
     else
         hipLaunchKernelGGL(colsum_partial_kernel<__half>, grid, dim3(256), 0, st, (const __half*)src, ld, part, R, C, rpb);
     WC_LAUNCH_CHECK("colsum_partial_kernel");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(wc_cdiv(C, 256)), dim3(256), 0, st, part, out, nblk, C, alpha, round16);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(wc_cdiv(C, 64)), dim3(256), 0, st, part, out, nblk, C, alpha, round16);
     WC_LAUNCH_CHECK("colsum_final_kernel");
     return WC_OK;
 }
 
-// part: workspace ceil(rows/64)*2*D floats; dgb (2,D) = alpha * [dgamma ; dbeta].
+// part: workspace ceil(rows/16)*2*D floats; dgb (2,D) = alpha * [dgamma ; dbeta].
 extern "C" int wc_layernorm_bwd(const float* dy, const float* x, const float* w, const float* add, float eps,
                                 float* dx32, void* dx16, float out_scale, float* part, float* dgb, float alpha,
                                 long rows, int D, void* stream) {
     WC_CHECK_ARG(dy && x && w && part && dgb && rows > 0 && D > 0 && D <= 1024 && (dx32 || dx16),
                  "wc_layernorm_bwd: bad argument (D <= 1024)");
-    const int nblk = wc_cdiv(rows, 64);
+    const int nblk = wc_cdiv(rows, 4 * LNB_ROWS);
     hipStream_t st = (hipStream_t)stream;
     const size_t sm = 8 * (size_t)D * sizeof(float);
     if (D <= 256)
@@ -215,7 +232,7 @@ extern "C" int wc_layernorm_bwd(const float* dy, const float* x, const float* w,
         hipLaunchKernelGGL(ln_bwd_kernel<16>, dim3(nblk), dim3(256), sm, st, dy, x, w, add, eps, dx32, (__half*)dx16,
                            out_scale, part, rows, D);
     WC_LAUNCH_CHECK("ln_bwd_kernel");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(wc_cdiv(2 * D, 256)), dim3(256), 0, st, part, dgb, nblk, 2 * D, alpha, 0);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(wc_cdiv(2 * D, 64)), dim3(256), 0, st, part, dgb, nblk, 2 * D, alpha, 0);
     WC_LAUNCH_CHECK("colsum_final_kernel");
     return WC_OK;
 }

@@ -209,7 +209,7 @@ def layernorm_bwd(dy, x, w, *, add=None, want32=True, want16=False, out_scale=1.
     dev = x.device
     dx32 = torch.empty(rows, D, device=dev, dtype=F32) if want32 else None
     dx16 = torch.empty(rows, D, device=dev, dtype=F16) if want16 else None
-    part = torch.empty(((rows + 63) // 64) * 2 * D, device=dev, dtype=F32)
+    part = torch.empty(((rows + 15) // 16) * 2 * D, device=dev, dtype=F32)
     dgb = torch.empty(2, D, device=dev, dtype=F32)
     L.lib().wc_layernorm_bwd(L.ptr(dy, F32, "dy"), L.ptr(x, F32, "x"), L.ptr(w, F32, "w"), L.ptr(add, F32, "add"), eps,
                              L.ptr(dx32), L.ptr(dx16), float(out_scale), L.ptr(part), L.ptr(dgb), float(alpha), rows,
