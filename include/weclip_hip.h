@@ -112,6 +112,16 @@ int wc_sum_slices(const float* part, float* out, int nslices, long n, float alph
  * .weight/.bias gradients of nn.Linear / 1x1 nn.Conv2d (reference WeCLIP_model/segformer_head.py:22-28). */
 int wc_sum_slices_wb(const float* part, float* out_w, float* out_b, int nslices, int rows, int cols,
                      float alpha, void* stream);
+
+/* Weight-gradient GEMM on row-major operands: part[z, n, k] = sum over the tokens m of slice z of dY[m, n] * X[m, k]
+ * (and, with bias != 0, one more column k = K holding sum_m dY[m, n]); z = 0 .. ceil(M / mslice) - 1, mslice a multiple
+ * of 64.  fp16 operands (M, lda) / (M, ldx), fp32 partials (nslices, N, K + bias) to be summed by wc_sum_slices(_wb).
+ * Replaces the autograd weight/bias gradients of nn.Linear / 1x1 nn.Conv2d (reference
+ * WeCLIP_model/segformer_head.py:22-28,69-80; Decoder/TransDecoder.py:98-125) without transposed operand copies.
+ * The X row of token m is (m / x_rpg) * x_gs + m % x_rpg + x_off (use x_rpg = M, x_gs = 0, x_off = 0 for a
+ * dense matrix) -- lets X be the patch rows of a (B, 1 + hw, C) token tensor.  zeros: >= 16 zero bytes. */
+int wc_gemm_km_f16(const void* dY, long lda, const void* X, long ldx, const void* zeros, int M, int N, int K,
+                   int x_rpg, int x_gs, int x_off, int mslice, int bias, float* part, void* stream);
 /* fp32 -> fp16 hi (+ lo = fp16(x - hi), may be NULL): `.half()` casts of weights/activations
  * (clip/model.py:457-478 convert_weights; clip/myAtt.py:321). */
 int wc_split_f16(const float* x, void* hi, void* lo, long n, void* stream);

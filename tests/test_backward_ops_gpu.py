@@ -117,3 +117,35 @@ def test_gemm_relu_grad_and_colscale_epilogues(ops):
              cscale=cs.cuda(), sCS=N)
     ref2 = ((a.double() @ w.double().t() + bias.double()).view(Bn, M, N) * cs.double()[:, None, :]).reshape(Bn * M, N)
     assert _rel(out.cpu(), ref2) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,lda,slices", [(1000, 21, 200, 64, 4), (4096, 256, 768, None, 8), (70, 130, 64, 136, 1)])
+def test_weight_gradient_gemm_row_major_operands(M, N, K, lda, slices):
+    """dW = dY^T X and db = dY^T 1 straight from row-major fp16 operands (transposing LDS reads):
+    ragged token count, ragged N / K tiles, padded dY rows, split-K slices."""
+    from weclip_vit_comer_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    lda = N if lda is None else lda
+    dy = torch.zeros(M, lda).half()
+    dy[:, :N] = torch.randn(M, N, generator=g).half()
+    x = torch.randn(M, K, generator=g).half()
+    part, ns = ops.wgrad_partials(dy.cuda(), x.cuda(), M, N, K, lda=lda, slices=slices, bias=True)
+    got = part.sum(0).cpu().double()
+    ref = dy[:, :N].double().t() @ x.double()
+    refb = dy[:, :N].double().sum(0)
+    scale = ref.abs().max()
+    assert (got[:, :K] - ref).abs().max() / scale < 2e-6
+    assert (got[:, K] - refb).abs().max() / refb.abs().max() < 2e-6
+
+
+def test_weight_gradient_gemm_skips_cls_rows():
+    """X = the patch rows of a (B, 1 + hw, C) token tensor, addressed through the row map."""
+    from weclip_vit_comer_amd import ops
+    B, hw, C, N = 3, 24, 64, 32
+    g = torch.Generator().manual_seed(5)
+    tok = torch.randn(B, 1 + hw, C, generator=g).half()
+    dy = torch.randn(B * hw, N, generator=g).half()
+    part, ns = ops.wgrad_partials(dy.cuda(), tok.view(-1, C).cuda(), B * hw, N, C, slices=1, bias=True, xmap=(hw, 1 + hw, 1))
+    ref = dy.double().t() @ tok[:, 1:].reshape(B * hw, C).double()
+    got = part.sum(0).cpu().double()
+    assert (got[:, :C] - ref).abs().max() / ref.abs().max() < 2e-6

@@ -590,6 +590,190 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
     gemm_epilogue<AUX>(g, acc[1], m0 + wr * 128 + 64, n0, 0, wc, lane, 0, smem + wave * 4096, bv, sc);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight-gradient GEMM on row-major operands ("KM" layout):  C[n, k] = sum_m dY[m, n] * X[m, k]
+// (reference: what autograd computes for nn.Linear / 1x1 nn.Conv2d weights, WeCLIP_model/segformer_head.py:22-28,
+//  Decoder/TransDecoder.py:98-125).  The contraction index m (tokens) is the ROW index of both operands, so the
+// K-contiguous kernels above would need dY^T and X^T materialised (one transpose kernel per operand per
+// layer).  Here both [64 tokens][128 columns] tiles are DMA'd as they lie in memory and the MFMA fragments
+// (8 consecutive tokens of one column) are fetched with gfx950's transposing LDS read ds_read_b64_tr_b16:
+// a 16-lane group reads a 4-row x 16-column block and each lane receives one column of it.
+// LDS image: 256-B rows, 16-B chunk ch of row r stored at chunk ch ^ (((r&3)<<2) | ((r>>2)&3)) (swizzle on the
+// DMA source address): the four rows of a block then sit in different bank quarters.
+// Split-K over blockIdx.z (token slices) into fp32 partials; optional extra output column K = sum_m dY[m, n]
+// (the bias gradient) from one more MFMA against a fragment of ones.
+struct KmArgs {
+    const __half* A;      // dY (M, lda)
+    const __half* X;      // X  (M, ldx)
+    const __half* zeros;  // >= 16 B of zeros: source of out-of-range rows / column chunks
+    int M, N, K;          // tokens, dY columns (output rows), X columns (output columns)
+    long lda, ldx;
+    int x_rpg, x_gs, x_off;   // X row of token m = (m / x_rpg) * x_gs + m % x_rpg + x_off  (skips CLS rows)
+    int mslice;           // tokens per slice (multiple of 64)
+    int bias;
+    int gx;
+    GemmArgs e;           // epilogue: M = N, N = K + bias, C32 = partials, ldc, sC
+};
+
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
+
+__global__ __launch_bounds__(256, 2) void gemm_km_kernel(KmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A tile 16 KiB | X tile 16 KiB]
+    constexpr int TILE = 64 * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ty = blockIdx.x / g.gx, tx = blockIdx.x - ty * g.gx;
+    const int n0 = ty * 128, k0 = tx * 128;
+    const int z = blockIdx.z;
+    const int mbeg = z * g.mslice;
+    const int mend = (mbeg + g.mslice < g.M) ? mbeg + g.mslice : g.M;
+    const int nt = (mend - mbeg + 63) / 64;
+
+    // DMA bookkeeping: chunk q = i*256 + tid -> tile row q>>4 (token), physical chunk q&15
+    int rowi[4], acol[4], xcol[4], xg[4], xr[4];
+    bool aok[4], xok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = i * 256 + tid;
+        const int row = q >> 4, pc = q & 15;
+        const int lc = pc ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        rowi[i] = row;
+        acol[i] = n0 + lc * 8;
+        xcol[i] = k0 + lc * 8;
+        aok[i] = acol[i] + 8 <= g.lda && acol[i] < g.N;
+        xok[i] = xcol[i] + 8 <= g.ldx && xcol[i] < g.K;
+        const int m = mbeg + row;
+        xg[i] = m / g.x_rpg;
+        xr[i] = m - xg[i] * g.x_rpg;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+#define KM_LOAD(t_, buf_)                                                                                       \
+    {                                                                                                            \
+        char* dst_ = smem + (buf_) * (2 * TILE) + wave * 1024;                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+            const int m_ = mbeg + (t_) * 64 + rowi[i];                                                           \
+            const bool in_ = m_ < mend;                                                                          \
+            const __half* pa_ = (in_ && aok[i]) ? g.A + (long)m_ * g.lda + acol[i] : g.zeros;                    \
+            const __half* px_ = (in_ && xok[i]) ? g.X + ((long)xg[i] * g.x_gs + xr[i] + g.x_off) * g.ldx + xcol[i] : g.zeros; \
+            __builtin_amdgcn_global_load_lds((gbl_ptr)pa_, (lds_ptr)(dst_ + i * 4096), 16, 0, 0);                \
+            __builtin_amdgcn_global_load_lds((gbl_ptr)px_, (lds_ptr)(dst_ + TILE + i * 4096), 16, 0, 0);         \
+            xr[i] += 64;                                                                                         \
+            while (xr[i] >= g.x_rpg) { xr[i] -= g.x_rpg; xg[i] += 1; }                                           \
+        }                                                                                                        \
+    }
+    // transposing fragment reads: lane = 16*grp + 4*q + p; grp = 2*hh + gi
+    const int hh = lane >> 5, gi = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+    int aaddr[2][2], baddr[2][2];      // [mi / ni][r]: byte offset inside an operand tile for k-step 0
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = 8 * hh + 4 * r + q;                       // + 16 * ks
+        const int f = (q << 2) | ((2 * hh + r) & 3);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int cha = wr * 8 + t * 4 + 2 * gi + (p >> 1);
+            const int chb = wc * 8 + t * 4 + 2 * gi + (p >> 1);
+            aaddr[t][r] = 256 * row + 16 * (cha ^ f) + 8 * (p & 1);
+            baddr[t][r] = 256 * row + 16 * (chb ^ f) + 8 * (p & 1);
+        }
+    }
+    typedef __attribute__((address_space(3))) s16x4* tr_ptr;
+#define KM_FRAG(base_, off_)                                                                                     \
+    __builtin_bit_cast(f16x8, __builtin_shufflevector(                                                           \
+        __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)((base_) + (off_)[0])),                                  \
+        __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)((base_) + (off_)[1])), 0, 1, 2, 3, 4, 5, 6, 7))
+
+    f32x16 acc[2][2], bacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bacc[i][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    // the wave whose 64 output columns contain column K (the bias column) also accumulates dY^T 1
+    const int kb = g.K - (k0 + wc * 64);
+    const bool own_bias = g.bias && kb >= 0 && kb < 64;
+    f16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
+
+    if (nt > 0) KM_LOAD(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) KM_LOAD(t + 1, buf ^ 1);
+        const char* As = smem + buf * (2 * TILE);
+        const char* Xs = As + TILE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f16x8 a0 = KM_FRAG(As + ks * 4096, aaddr[0]);
+            const f16x8 a1 = KM_FRAG(As + ks * 4096, aaddr[1]);
+            const f16x8 b0 = KM_FRAG(Xs + ks * 4096, baddr[0]);
+            const f16x8 b1 = KM_FRAG(Xs + ks * 4096, baddr[1]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+            if (own_bias) {
+                bacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, ones, bacc[0], 0, 0, 0);
+                bacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, ones, bacc[1], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef KM_FRAG
+#undef KM_LOAD
+    if (own_bias) {      // every column of bacc holds the row sums: drop them into output column K
+        const int ni = kb >> 5, cl = kb & 31;
+        if ((lane & 31) == cl) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (ni == 0) acc[mi][0][r] = bacc[mi][r];
+                    else acc[mi][1][r] = bacc[mi][r];
+                }
+        }
+    }
+    const float bv[2] = {0.f, 0.f}, sc[2] = {1.f, 1.f};
+    gemm_epilogue<false>(g.e, acc, n0, k0, wr, wc, lane, z, smem + wave * 4096, bv, sc);
+}
+
+// part: (nslices, N, K + bias) fp32 with nslices = ceil(M / mslice); zeros: device buffer of >= 16 zero bytes.
+extern "C" int wc_gemm_km_f16(const void* dY, long lda, const void* X, long ldx, const void* zeros, int M, int N, int K,
+                              int x_rpg, int x_gs, int x_off, int mslice, int bias, float* part, void* stream) {
+    WC_CHECK_ARG(dY && X && zeros && part && M > 0 && N > 0 && K > 0, "wc_gemm_km_f16: bad argument");
+    WC_CHECK_ARG(lda % 8 == 0 && ldx % 8 == 0 && lda >= N && ldx >= K && ((uintptr_t)dY | (uintptr_t)X | (uintptr_t)zeros) % 16 == 0,
+                 "wc_gemm_km_f16: operand rows must be 16-byte aligned (lda, ldx %% 8 == 0)");
+    WC_CHECK_ARG(mslice > 0 && mslice % 64 == 0, "wc_gemm_km_f16: mslice must be a positive multiple of 64");
+    WC_CHECK_ARG(x_rpg >= 1 && x_gs >= 0 && x_off >= 0, "wc_gemm_km_f16: bad row map");
+    const int ns = wc_cdiv(M, mslice);
+    WC_CHECK_ARG(ns <= 65535, "wc_gemm_km_f16: too many slices");
+    KmArgs g;
+    g.A = (const __half*)dY; g.X = (const __half*)X; g.zeros = (const __half*)zeros;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldx = ldx;
+    g.x_rpg = x_rpg; g.x_gs = x_gs; g.x_off = x_off; g.mslice = mslice; g.bias = bias ? 1 : 0;
+    const int K1 = K + g.bias;
+    g.gx = wc_cdiv(K1, 128);
+    GemmArgs& e = g.e;
+    e.A[0] = e.A[1] = e.A[2] = nullptr; e.W[0] = e.W[1] = e.W[2] = nullptr;
+    e.nseg = 1; e.M = N; e.N = K1; e.K = 0; e.lda = e.ldw = 0; e.sA = e.sW = 0;
+    e.sC = (long)N * K1; e.sR = 0; e.bias = nullptr; e.resid = nullptr; e.ldr = 0;
+    e.C32 = part; e.C16 = nullptr; e.C16lo = nullptr; e.ldc = K1; e.act = 0; e.round16 = 0; e.scale = 1.f; e.scale_cols = 0;
+    e.P32 = nullptr; e.aux = nullptr; e.rowmap = nullptr; e.rpg = 1; e.ldaux = 0; e.auxh = nullptr; e.cscale = nullptr;
+    e.sCS = 0; e.gx = g.gx; e.gy = wc_cdiv(N, 128); e.dbg = 0; e.vec = 0;
+    dim3 grid((unsigned)(g.gx * wc_cdiv(N, 128)), 1, ns);
+    hipLaunchKernelGGL(gemm_km_kernel, grid, dim3(256), 4 * 64 * 256, (hipStream_t)stream, g);
+    WC_LAUNCH_CHECK("gemm_km_kernel");
+    return WC_OK;
+}
+
 // out[i] = alpha * sum_s part[s*n + i]   (split-K reduction: slices are a batched GEMM over K ranges)
 __global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                           int nslices, long n, float alpha) {

@@ -123,20 +123,18 @@ class HeadEngine:
         dev = ctx["F32"].device
         GS, inv = GRAD_SCALE, 1.0 / GRAD_SCALE
         grads = {}
-        wg = lambda dyT, xT, N_, K_, Kp, wn, bn: self._wgrad(dyT, xT, N_, K_, Kp, inv, grads, wn, bn)
+        wg = lambda dy16, x16, N_, K_, wn, bn, **kw: self._wgrad(dy16, x16, M, N_, K_, inv, grads, wn, bn, **kw)
         # ---- linear_pred
         x3h = ctx["blocks"][-1]["x2h"]
         if dseg is not None:
             d = torch.zeros(M, 64, device=dev, dtype=F32)
             d[:, :nc] = dseg.permute(0, 2, 3, 1).reshape(M, nc)
-            d32, dS = ops.colscale_split(d, None, M, alpha=GS, with_lo=ex)
+            _, dS = ops.colscale_split(d, None, M, alpha=GS, want32=False, with_lo=ex)
             wpT = torch.zeros(E, 64, device=dev, dtype=F32)
             wpT[:, :nc] = self.dec.linear_pred.weight.detach().flatten(1).t()
             dx = torch.empty(M, E, device=dev, dtype=F32)
             ops.gemm(dS, ops.split_f16(wpT, ex), M, E, 64, out32=dx)
-            dT, Kp = ops.transpose_f16(d32, M, 64)
-            xT, _ = ops.transpose_f16(x3h.hi, M, E, ones_row=True)
-            wg(dT, xT, nc, E, Kp, "dec.linear_pred.weight", "dec.linear_pred.bias")
+            wg(dS.hi, x3h.hi, nc, E, "dec.linear_pred.weight", "dec.linear_pred.bias", lda=64)
         else:
             dx = torch.zeros(M, E, device=dev, dtype=F32)
             grads["dec.linear_pred.weight"] = torch.zeros(nc, E, 1, 1, device=dev)
@@ -154,13 +152,11 @@ class HeadEngine:
         else:
             dF = dx
         # ---- Dropout2d backward + fuse
-        dFp32, dFp = ops.colscale_split(dF, ctx["drop"], hw, with_lo=ex)
+        _, dFp = ops.colscale_split(dF, ctx["drop"], hw, want32=False, with_lo=ex)
         cat = ctx["cat"]
         dcat = Split(torch.empty(M, n * E, device=dev, dtype=F16), torch.empty(M, n * E, device=dev, dtype=F16) if ex else None)
         ops.gemm(dFp, _wT(self.fuse.linear_fuse.weight.detach().flatten(1), ex), M, n * E, E, out16=dcat.hi, out16lo=dcat.lo)
-        dFT, Kp = ops.transpose_f16(dFp32, M, E)
-        catT, _ = ops.transpose_f16(cat.hi, M, n * E, ones_row=True)
-        wg(dFT, catT, E, n * E, Kp, "fuse.linear_fuse.weight", "fuse.linear_fuse.bias")
+        wg(dFp.hi, cat.hi, E, n * E, "fuse.linear_fuse.weight", "fuse.linear_fuse.bias")
         # ---- adapters
         xs, Lq = ctx["xs"], ctx["L"]
         C = xs[0].hi.shape[1]
@@ -168,14 +164,11 @@ class HeadEngine:
             p = f"fuse.linears_modulelist.{l}."
             dt2 = Split(dcat.hi.view(-1)[l * E:], dcat.lo.view(-1)[l * E:] if ex else None)
             t1 = ctx["t1s"][l]
-            dt1_32 = torch.empty(M, E, device=dev, dtype=F32)
-            ops.gemm(dt2, _wT(mlp.proj_2.weight, ex), M, E, E, lda=n * E, out32=dt1_32, act=5, auxh=t1.hi, ldaux=E)
-            dt2T, Kp = ops.transpose_f16(dt2.hi, M, E, ld=n * E)
-            t1T, _ = ops.transpose_f16(t1.hi, M, E, ones_row=True)
-            wg(dt2T, t1T, E, E, Kp, p + "proj_2.weight", p + "proj_2.bias")
-            dt1T, _ = ops.transpose_f16(dt1_32, M, E)
-            xT, _ = ops.transpose_f16(xs[l].hi.view(-1)[C:], hw, C, ld=C, batch=B, sSrc=Lq * C, ones_row=True)
-            wg(dt1T, xT, E, C, Kp, p + "proj.weight", p + "proj.bias")
+            dt1_16 = torch.empty(M, E, device=dev, dtype=F16)
+            ops.gemm(dt2, _wT(mlp.proj_2.weight, ex), M, E, E, lda=n * E, out16=dt1_16, act=5, auxh=t1.hi, ldaux=E)
+            wg(dt2.hi, t1.hi, E, E, p + "proj_2.weight", p + "proj_2.bias", lda=n * E)
+            # X = the hw patch rows of every image of the (B, 1 + hw, C) encoder tokens (CLS rows skipped)
+            wg(dt1_16, xs[l].hi, E, C, p + "proj.weight", p + "proj.bias", xmap=(hw, Lq, 1))
         return grads
 
     def _dest(self, name, shape):
@@ -186,22 +179,16 @@ class HeadEngine:
             return d.view(shape)
         return torch.empty(shape, device=self.dec.linear_pred.weight.device, dtype=F32)
 
-    def _wgrad(self, dyT, xT, N_, K_, Kp, inv, grads, wname, bname):
-        """dW (N_, K_) = inv * dY^T X and db (N_) = inv * dY^T 1 from transposed operands (N_, Kp) and
-        (K_ + 1, Kp) -- the X^T operand carries a row of ones, so the bias gradient is one more output
-        column.  The output has few 128x128 tiles and a long K (all tokens), so K is split over `ns` slices
-        run as one batched GEMM (slice = z); wc_sum_slices_wb sums them straight into the (dense) weight
-        and bias gradient buffers."""
-        dev = dyT.hi.device
-        K1 = xT.hi.shape[0]
-        assert K1 == K_ + 1
-        tiles = ((N_ + 127) // 128) * ((K1 + 127) // 128)
+    def _wgrad(self, dy16, x16, M, N_, K_, inv, grads, wname, bname, lda=None, ldx=None, xmap=None):
+        """dW (N_, K_) = inv * dY^T X and db (N_) = inv * dY^T 1 from the row-major fp16 operands as they lie
+        in memory (csrc/gemm.hip gemm_km_kernel: transposing LDS reads, no operand transposes).  The output has
+        few 128x128 tiles and a long contraction (all tokens), so the tokens are split over `ns` slices
+        (blockIdx.z); wc_sum_slices_wb sums them straight into the dense weight / bias gradient buffers."""
+        tiles = ((N_ + 127) // 128) * ((K_ + 1 + 127) // 128)
         ns = 1
-        while ns * 2 * tiles <= 1024 and Kp % (ns * 2 * 64) == 0 and Kp // (ns * 2) >= 256:
+        while ns * 2 * tiles <= 1024 and M // (ns * 2) >= 256:
             ns *= 2
-        part = torch.empty(ns, N_, K1, device=dev, dtype=F32)
-        ks = Kp // ns
-        ops.gemm(dyT, xT, N_, K1, ks, lda=Kp, ldw=Kp, out32=part, batch=ns, sA=ks, sW=ks, sC=N_ * K1)
+        part, ns = ops.wgrad_partials(dy16, x16, M, N_, K_, lda=lda, ldx=ldx, slices=ns, bias=True, xmap=xmap)
         gw, gb = self._dest(wname, (N_, K_)), self._dest(bname, (N_,))
         from . import _lib as L
         L.lib().wc_sum_slices_wb(L.ptr(part, F32), L.ptr(gw, F32), L.ptr(gb, F32), ns, N_, K_, inv, L.stream())
@@ -212,35 +199,27 @@ class HeadEngine:
         M, E, H, DH = B * Lq, pk.E, pk.H, pk.DH
         dev = dx2.device
         ex = pk.exact
-        wg = lambda dyT, xT, N_, K_, Kp, wn, bn: self._wgrad(dyT, xT, N_, K_, Kp, inv, grads, wn, bn)
+        wg = lambda dy16, x16, N_, K_, wn, bn, **kw: self._wgrad(dy16, x16, M, N_, K_, inv, grads, wn, bn, **kw)
         # MLP
         _, dx2s = ops.colscale_split(dx2, None, M, want32=False, with_lo=ex)
         du = Split(torch.empty(M, 4 * E, device=dev, dtype=F16), torch.empty(M, 4 * E, device=dev, dtype=F16) if ex else None)
         ops.gemm(dx2s, _wT(blk.mlp.c_proj.weight, ex), M, 4 * E, E, out16=du.hi, out16lo=du.lo, act=4, aux=c["u32"],
                  ldaux=4 * E, rpg=1)
-        dx2T, Kp = ops.transpose_f16(dx2, M, E)
-        zT, _ = ops.transpose_f16(c["z"].hi, M, 4 * E, ones_row=True)
-        wg(dx2T, zT, E, 4 * E, Kp, prefix + "mlp.c_proj.weight", prefix + "mlp.c_proj.bias")
+        wg(dx2s.hi, c["z"].hi, E, 4 * E, prefix + "mlp.c_proj.weight", prefix + "mlp.c_proj.bias")
         da2 = torch.empty(M, E, device=dev, dtype=F32)
         ops.gemm(du, _wT(blk.mlp.c_fc.weight, ex), M, E, 4 * E, out32=da2)
-        duT, _ = ops.transpose_f16(du.hi, M, 4 * E)
-        a2T, _ = ops.transpose_f16(c["a2"].hi, M, E, ones_row=True)
-        wg(duT, a2T, 4 * E, E, Kp, prefix + "mlp.c_fc.weight", prefix + "mlp.c_fc.bias")
+        wg(du.hi, c["a2"].hi, 4 * E, E, prefix + "mlp.c_fc.weight", prefix + "mlp.c_fc.bias")
         dx1, g16, dgb2 = ops.layernorm_bwd(da2, c["x1"], pk.ln2_w, add=dx2, want32=True, want16=True, alpha=inv)
         grads[prefix + "ln_2.weight"], grads[prefix + "ln_2.bias"] = dgb2[0], dgb2[1]
         # forced-fp16 out-projection (clip/myAtt.py:321): gradient rounded to fp16 on both sides
         do16 = torch.empty(M, E, device=dev, dtype=F16)
         ops.gemm(g16, _wT(blk.attn.out_proj.weight, False), M, E, E, out16=do16)
-        g16T, _ = ops.transpose_f16(g16, M, E)
-        o16T, _ = ops.transpose_f16(c["o16"], M, E, ones_row=True)
-        wg(g16T, o16T, E, E, Kp, prefix + "attn.out_proj.weight", prefix + "attn.out_proj.bias")
+        wg(g16, c["o16"], E, E, prefix + "attn.out_proj.weight", prefix + "attn.out_proj.bias")
         # attention + in-projection
         dqkv = ops.attention_bwd(c["qkv"], do16, c["o32"], c["lse"], B, Lq, H, DH, with_lo=ex)
         da = torch.empty(M, E, device=dev, dtype=F32)
         ops.gemm(dqkv, _wT(blk.attn.in_proj_weight, ex), M, E, 3 * E, out32=da)
-        dqT, _ = ops.transpose_f16(dqkv.hi, M, 3 * E)
-        aT, _ = ops.transpose_f16(c["a"].hi, M, E, ones_row=True)
-        wg(dqT, aT, 3 * E, E, Kp, prefix + "attn.in_proj_weight", prefix + "attn.in_proj_bias")
+        wg(dqkv.hi, c["a"].hi, 3 * E, E, prefix + "attn.in_proj_weight", prefix + "attn.in_proj_bias")
         dx, _, dgb1 = ops.layernorm_bwd(da, c["x"], pk.ln1_w, add=dx1, want32=True, alpha=inv)
         grads[prefix + "ln_1.weight"], grads[prefix + "ln_1.bias"] = dgb1[0], dgb1[1]
         return dx

@@ -192,6 +192,32 @@ def transpose_f16(src, R, C, *, ld=None, batch=1, sSrc=0, with_lo=False, scale=1
     return Split(hi, lo), Kp
 
 
+_ZEROS = {}
+
+
+def wgrad_partials(dy16, x16, M, N, K, *, lda=None, ldx=None, slices=1, bias=True, xmap=None):
+    """Split-K partials of dW = dY^T X (and db = dY^T 1 as column K) from ROW-MAJOR fp16 operands
+    dy16 (M, lda), x16 (rows, ldx): -> (part (ns, N, K + bias) fp32, ns).  xmap = (rows_per_group, group_stride,
+    offset): token m reads X row (m // rpg) * stride + m % rpg + offset (patch rows of a (B, 1 + hw, C) tensor)."""
+    L.require_gpu()
+    lda = N if lda is None else lda
+    ldx = K if ldx is None else ldx
+    dev = dy16.device
+    z = _ZEROS.get(dev)
+    if z is None:
+        z = _ZEROS[dev] = torch.zeros(64, device=dev, dtype=F16)
+    mslice = (-(-M // slices) + 63) // 64 * 64
+    ns = -(-M // mslice)
+    K1 = K + (1 if bias else 0)
+    part = torch.empty(ns, N, K1, device=dev, dtype=F32)
+    rpg, gs, off = xmap if xmap is not None else (max(M, 64), 0, 0)
+    t0 = KernelTimer.start()
+    L.lib().wc_gemm_km_f16(L.ptr(dy16, F16, "dY"), lda, L.ptr(x16, F16, "X"), ldx, L.ptr(z), M, N, K, rpg, gs, off,
+                           mslice, 1 if bias else 0, L.ptr(part), L.stream())
+    KernelTimer.stop("gemm_km_kernel", t0, 2.0 * M * N * K1)
+    return part, ns
+
+
 def colsum(src, R, C, *, ld=None, alpha=1.0, round16=False, out=None):
     ld = C if ld is None else ld
     dev = src.device
