@@ -59,16 +59,28 @@ class PairPlan:
                 pi.append(i); pc.append(j); ps.append(j)
                 ti.append(rows + [0] * (self.Tmax - len(rows)))
                 nt.append(len(rows))
-        t = lambda v: torch.tensor(v, dtype=I32, device=device)
-        self.pair_img, self.pair_cls, self.pair_slot = t(pi), t(pc), t(ps)
-        self.text_idx, self.n_text = t(ti).contiguous(), t(nt)
-        self.nk = t([len(l) for l in self.label_lists])
-        self.P = len(pi)
+        # ONE pinned, asynchronous host->device copy for all the int32 index arrays (a pageable
+        # torch.tensor(..., device=cuda) per array is a synchronising copy: it stalls the launch queue)
+        nk = [len(l) for l in self.label_lists]
+        flat_ti = [v for row in ti for v in row]
+        parts = [pi, pc, ps, flat_ti, nt, nk, [k + 1 for k in nk]]
+        host = torch.tensor([v for part in parts for v in part], dtype=I32)
         vk = torch.zeros(self.B, self.K + 1, dtype=torch.int64)
         for i, ids in enumerate(self.label_lists):
             vk[i, 1:1 + len(ids)] = torch.tensor(ids) + 1
-        self.valid_key = vk.to(device)
-        self.nch = t([len(l) + 1 for l in self.label_lists])
+        if torch.device(device).type == "cuda":
+            dev_all = host.pin_memory().to(device, non_blocking=True)
+            self.valid_key = vk.pin_memory().to(device, non_blocking=True)
+        else:
+            dev_all = host.to(device)
+            self.valid_key = vk.to(device)
+        self.P = len(pi)
+        views, off = [], 0
+        for part in parts:
+            views.append(dev_all[off:off + len(part)])
+            off += len(part)
+        self.pair_img, self.pair_cls, self.pair_slot, text_idx, self.n_text, self.nk, self.nch = views
+        self.text_idx = text_idx.view(self.P, self.Tmax)
 
 
 def normalised_text(fg_text, bg_text, device):

@@ -11,6 +11,18 @@ from . import ops
 from .ops import F16, F32, Split
 from .clip import vit_engine as VE
 
+def _logit_scale(clip_model):
+    """exp(logit_scale) as a host float, read back from the device only when the (frozen) parameter changes
+    (a per-step .item() is a device->host synchronisation that stalls the launch queue)."""
+    p = clip_model.logit_scale
+    key = (p.data_ptr(), p._version)
+    cached = getattr(clip_model, "_logit_scale_host", None)
+    if cached is None or cached[0] != key:
+        cached = (key, float(p.detach().exp().item()))
+        clip_model._logit_scale_host = cached
+    return cached[1]
+
+
 GRAD_SCALE = 4096.0   # power of two carried by gradients stored as fp16 hi/lo MFMA operands
 
 
@@ -53,7 +65,7 @@ class LastLayerState:
                             L.ptr(v.proj.detach().float().contiguous(), F32), L.ptr(text_hat, F32),
                             L.ptr(text_idx, torch.int32), L.ptr(n_text, torch.int32),
                             L.ptr(pair_img, torch.int32), L.ptr(pair_cls, torch.int32),
-                            float(self.m.logit_scale.detach().exp().item()), L.ptr(partial), L.ptr(probs),
+                            _logit_scale(self.m), L.ptr(partial), L.ptr(probs),
                             L.ptr(df), B, P, Lq, E, Ed, Tmax, L.stream())
         return probs, df
 

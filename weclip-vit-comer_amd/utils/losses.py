@@ -50,7 +50,7 @@ class _SegLossFn(torch.autograd.Function):
         seg, label, sums = ctx.saved_tensors
         B, nc, h, w = seg.shape
         H, W = label.shape[1:]
-        wts = (0.5 * g / sums[[1, 3]]).float().contiguous()
+        wts = (0.5 * g / torch.stack((sums[1], sums[3]))).float().contiguous()   # no index tensor: no host sync
         out = torch.empty_like(seg)
         ghr = torch.empty(B, nc, H, W, device=seg.device, dtype=torch.float32)
         L.lib().wc_seg_loss_bwd(L.ptr(seg), L.ptr(label), L.ptr(wts, torch.float32, "wts"), L.ptr(ghr), B, nc, h, w, H, W,
