@@ -135,15 +135,13 @@ int wc_layernorm(const float* x, long ldx, const float* w, const float* b, float
 /* ---- multi-head attention -------------------------------------------------------------- */
 /* Packed in-projection output qkv (B*L, 3E) fp16, E = H*DH, q pre-scaled by log2(e)/sqrt(DH)
  * (wc_gemm_f16 scale/scale_cols).  DH in {32, 64}.
- * wc_attn_vt:   V^T (B,H,DH,Lp) fp16, keys contiguous, zero padded to Lp (Lp % 64 == 0).
  * wc_attn_fwd:  clip/myAtt.py:21-64 without materialising the scores: out (B*L, E) fp16 =
  *               softmax(QK^T)V with heads merged (the `.half()` input of the out-projection,
  *               myAtt.py:319-321); out32 (optional) the same before fp16 rounding;
- *               lse (B,H,L) f32 = log2-sum-exp2 of each score row.
+ *               lse (B,H,L) f32 = log2-sum-exp2 of each score row.  V is read row-major from qkv.
  * wc_attn_mean: clip/myAtt.py:325-326: mean (B,L,L) f32 = (1/H) sum_h softmax_h. */
-int wc_attn_vt(const void* qkv, void* vt, int B, int L, int Lp, int H, int DH, void* stream);
-int wc_attn_fwd(const void* qkv, const void* vt, void* out, float* out32, float* lse, int B, int L,
-                int Lp, int H, int DH, void* stream);
+int wc_attn_fwd(const void* qkv, void* out, float* out32, float* lse, int B, int L, int H, int DH,
+                void* stream);
 int wc_attn_mean(const void* qkv, const float* lse, float* mean, int B, int L, int H, int DH,
                  void* stream);
 

@@ -153,7 +153,7 @@ def test_layernorm(ops, D):
 
 
 @pytest.mark.parametrize("B,L,H,DH", [(2, 25, 1, 64), (1, 197, 12, 64), (2, 1025, 12, 64), (2, 1024, 8, 32),
-                                      (1, 130, 8, 32)])
+                                      (1, 130, 8, 32), (1, 257, 2, 32), (2, 136, 3, 64), (1, 137, 2, 64)])
 def test_attention_vs_reference(ops, B, L, H, DH):
     """Same arithmetic as clip/myAtt.py:21-64,325-326 on fp16-rounded q,k,v."""
     E = H * DH

@@ -10,8 +10,11 @@
 //   attn_mean_kernel : mean_h P_h = (1/H) sum_h exp2(Q_h K_h^T - LSE_h) for a 128x128 tile,
 //                      the H-head sum held in MFMA accumulators, written once, coalesced
 //                      (the returned `attn_output_weights.sum(dim=1) / num_heads`).
-//   vt_kernel        : V^T (B,H,dh,Lp) from the packed qkv buffer (keys contiguous, zero padded)
-//                      so PV fragments are 8-byte LDS reads.
+//   attn_rows_kernel / attn_mean_edge_kernel : the first L % 128 query rows (and key columns) when that
+//                      remainder is tiny (the CLS token of a 1 + 32*32 sequence): a 129th row must not cost
+//                      a whole 128-row tile, so the tiled kernels start at row L % 128 and these finish the rest.
+// V stays row-major [key][dh] (as the in-projection wrote it); the O^T = V^T P^T fragments (8 consecutive keys
+// of one dh column) come from gfx950's transposing LDS read ds_read_b64_tr_b16 -- no V^T copy in HBM.
 //
 // Input `qkv` is the in-projection GEMM output (B*L, 3E) fp16 with q pre-multiplied by
 // log2(e)/sqrt(dh) (wc_gemm_f16 scale/scale_cols), so every exponential is a bare v_exp_f32.
@@ -29,52 +32,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define NEG_BIG (-1.0e30f)
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void vt_kernel(const __half* __restrict__ qkv,
-                                                  __half* __restrict__ vt, int L, int Lp, int H,
-                                                  int DH, int E) {
-    // block: 64 tokens x 64 dims of one (b, h-slice); grid (Lp/64, E/64, B)
-    __shared__ __half tile[64][66];
-    const int l0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const int l = l0 + r;
-        tile[r][c] = (l < L) ? qkv[((long)b * L + l) * 3 * E + 2 * E + c0 + c] : __float2half(0.f);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int c = i >> 6, r = i & 63;      // c: dim within slice, r: token
-        const int e = c0 + c;                  // column in E = h*DH + d
-        const int h = e / DH, d = e - h * DH;
-        vt[(((long)b * H + h) * DH + d) * Lp + l0 + r] = tile[r][c];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const __half* __restrict__ qkv,
-                                                        const __half* __restrict__ vt,
                                                         __half* __restrict__ out,
                                                         float* __restrict__ out32,
-                                                        float* __restrict__ lse, int L, int Lp, int H,
-                                                        int E) {
+                                                        float* __restrict__ lse, int L, int H,
+                                                        int E, int q_origin) {
     constexpr int KS = DH / 16;          // k-steps of QK^T
     constexpr int DT = DH / 32;          // 32-row tiles of O^T
     constexpr int KROW = DH * 2 + 16;    // bytes per K row in LDS (padded)
-    constexpr int VROW = 136;            // bytes per V^T row in LDS (64 keys + 8 B pad)
-    constexpr int KBUF = 64 * KROW, VBUF = DH * VROW;
+    constexpr int VROW = DH * 2;         // bytes per V row in LDS ([key][dh], 16-B chunks XOR-swizzled)
+    constexpr int KBUF = 64 * KROW, VBUF = 64 * VROW;
     constexpr int KCH = DH / 8;          // 16-B chunks per K row
     constexpr int NKC = 64 * KCH / 256;  // K chunks per thread (2 for DH=64, 1 for DH=32)
-    constexpr int NVC = DH * 8 / 256;    // V chunks per thread
+    constexpr int NVC = NKC;             // V chunks per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][KBUF + VBUF]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, l31 = lane & 31;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+    const int qrow = q_origin + blockIdx.x * 128 + wave * 32 + l31;
     const int qr = qrow < L ? qrow : L - 1;
     const long ldq = 3L * E;
     const __half* base = qkv + (long)b * L * ldq + (long)h * DH;
-    const __half* vbase = vt + ((long)b * H + h) * DH * Lp;
 
     f16x8 qf[KS];
 #pragma unroll
@@ -82,6 +62,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __half* __restrict_
         qf[s] = *reinterpret_cast<const f16x8*>(base + (long)qr * ldq + 16 * s + 8 * hh);
 
     u32x4 rk[NKC], rv[NVC];
+    // V tile swizzle: with 128-B rows, keys q and q+2 of a 4-key block would share banks; flip the 64-B half
+    // of every second key pair (64-B rows need nothing: four keys already cover the 64 banks)
+#define VSWZ(key_) (DH == 64 ? ((((key_) >> 1) & 1) << 2) : 0)
+    // transposing read of the PV A-operand: lane = 32*hh + 16*gi + 4*q + p supplies key row 4*hh + q (+ 8 for the
+    // second read, + 16 per k-step) and dh columns 16*gi + 4*p .. +3; it receives column 16*gi + (lane & 15)
+    int vaddr[2];
+    {
+        const int gi = (lane >> 4) & 1, q4 = (lane >> 2) & 3, p4 = lane & 3;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int key = 8 * r + 4 * hh + q4;                 // + 16 * s2: does not change VSWZ
+            vaddr[r] = key * VROW + (((2 * gi + (p4 >> 1)) ^ VSWZ(key)) << 4) + 8 * (p4 & 1);
+        }
+    }
+    typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+    typedef __attribute__((address_space(3))) s16x4* tr_ptr;
 #undef GLOAD
 #define GLOAD(t_) \
     { \
@@ -96,7 +92,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __half* __restrict_
         _Pragma("unroll") \
         for (int i = 0; i < NVC; ++i) { \
             const int c = tid + 256 * i; \
-            rv[i] = *reinterpret_cast<const u32x4*>(vbase + (long)(c >> 3) * Lp + t__ * 64 + (c & 7) * 8); \
+            int key = t__ * 64 + c / KCH; \
+            if (key > L - 1) key = L - 1; \
+            rv[i] = *reinterpret_cast<const u32x4*>(base + 2 * E + (long)key * ldq + (c % KCH) * 8); \
         } \
     }
 #undef LSTORE
@@ -113,9 +111,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __half* __restrict_
         _Pragma("unroll") \
         for (int i = 0; i < NVC; ++i) { \
             const int c = tid + 256 * i; \
-            u32x2* p = reinterpret_cast<u32x2*>(vb + (c >> 3) * VROW + (c & 7) * 16); \
-            p[0] = rv[i].xy; \
-            p[1] = rv[i].zw; \
+            const int key__ = c / KCH; \
+            *reinterpret_cast<u32x4*>(vb + key__ * VROW + (((c % KCH) ^ VSWZ(key__)) << 4)) = rv[i]; \
         } \
     }
 
@@ -186,12 +183,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __half* __restrict_
             for (int j = 0; j < 8; ++j) pb[j] = (_Float16)s[s2 >> 1][(s2 & 1) * 8 + j];
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
-                const char* vr = vb + (d * 32 + l31) * VROW + (16 * s2 + 4 * hh) * 2;
-                const f16x4 v0 = *reinterpret_cast<const f16x4*>(vr);
-                const f16x4 v1 = *reinterpret_cast<const f16x4*>(vr + 16);
-                f16x8 va;
-                va[0] = v0[0]; va[1] = v0[1]; va[2] = v0[2]; va[3] = v0[3];
-                va[4] = v1[0]; va[5] = v1[1]; va[6] = v1[2]; va[7] = v1[3];
+                // dh tile d = chunks 4*d .. 4*d+3 of a row: XOR-ing the chunk index with 4*d adds d*64 B
+                const char* vr = vb + s2 * 16 * VROW;
+                const f16x8 va = __builtin_bit_cast(f16x8, __builtin_shufflevector(
+                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(vr + (vaddr[0] ^ (d << 6)))),
+                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(vr + (vaddr[1] ^ (d << 6)))), 0, 1, 2, 3, 4, 5, 6, 7));
                 o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb, o[d], 0, 0, 0);
             }
         }
@@ -222,7 +218,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __half* __restrict_
 template <int DH>
 __global__ __launch_bounds__(256) void attn_mean_kernel(const __half* __restrict__ qkv,
                                                          const float* __restrict__ lse,
-                                                         float* __restrict__ mean, int L, int H, int E) {
+                                                         float* __restrict__ mean, int L, int H, int E, int origin) {
     constexpr int KS = DH / 16;
     constexpr int ROW = DH * 2 + 16;
     constexpr int TB = 128 * ROW;        // bytes of one 128-row operand tile
@@ -234,7 +230,7 @@ __global__ __launch_bounds__(256) void attn_mean_kernel(const __half* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, l31 = lane & 31;
     const int wr = wave >> 1, wc = wave & 1;
-    const int k0 = blockIdx.x * 128, q0 = blockIdx.y * 128, b = blockIdx.z;
+    const int k0 = origin + blockIdx.x * 128, q0 = origin + blockIdx.y * 128, b = blockIdx.z;
     const long ldq = 3L * E;
     const __half* base = qkv + (long)b * L * ldq;
 
@@ -337,34 +333,120 @@ __global__ __launch_bounds__(256) void attn_mean_kernel(const __half* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int wc_attn_vt(const void* qkv, void* vt, int B, int L, int Lp, int H, int DH, void* stream) {
-    const int E = H * DH;
-    WC_CHECK_ARG(qkv && vt && B > 0 && L > 0 && Lp >= L && Lp % 64 == 0 && E % 64 == 0,
-                 "wc_attn_vt: need Lp %% 64 == 0, Lp >= L, (H*DH) %% 64 == 0");
-    dim3 grid(Lp / 64, E / 64, B);
-    hipLaunchKernelGGL(vt_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const __half*)qkv,
-                       (__half*)vt, L, Lp, H, DH, E);
-    WC_LAUNCH_CHECK("vt_kernel");
-    return WC_OK;
+// The first `nrows` query rows of every (b, h): one workgroup per row.  scores -> LDS, block max / sum,
+// P rounded to fp16 like the MFMA operand of the tiled kernel, O = P V with lanes along dh.
+template <int DH>
+__global__ __launch_bounds__(256) void attn_rows_kernel(const __half* __restrict__ qkv, __half* __restrict__ out,
+                                                         float* __restrict__ out32, float* __restrict__ lse, int L, int H,
+                                                         int E) {
+    extern __shared__ float sc[];            // [L] scores, then probabilities
+    __shared__ float red[16];
+    __shared__ float part[256 / DH][DH];
+    const int tid = threadIdx.x, q = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const long ldq = 3L * E;
+    const __half* base = qkv + (long)b * L * ldq + (long)h * DH;
+    f16x8 qv[DH / 8];
+#pragma unroll
+    for (int c = 0; c < DH / 8; ++c) qv[c] = *reinterpret_cast<const f16x8*>(base + (long)q * ldq + c * 8);
+    float mx = NEG_BIG;
+    for (int key = tid; key < L; key += 256) {
+        const __half* kr = base + E + (long)key * ldq;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH / 8; ++c) {
+            const f16x8 kv = *reinterpret_cast<const f16x8*>(kr + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s = fmaf((float)qv[c][j], (float)kv[j], s);
+        }
+        sc[key] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = block_max(mx, red);
+    float sum = 0.f;
+    for (int key = tid; key < L; key += 256) {
+        const float pr = __builtin_amdgcn_exp2f(sc[key] - mx);
+        sum += pr;
+        sc[key] = (float)(_Float16)pr;
+    }
+    sum = block_sum(sum, red);               // (its barriers also publish sc[])
+    const int d = tid % DH, pt = tid / DH;
+    float o = 0.f;
+    for (int key = pt; key < L; key += 256 / DH) o = fmaf(sc[key], __half2float(base[2 * E + (long)key * ldq + d]), o);
+    part[pt][d] = o;
+    __syncthreads();
+    if (tid < DH) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 256 / DH; ++k) v += part[k][tid];
+        v /= sum;
+        const long oi = ((long)b * L + q) * E + (long)h * DH + tid;
+        out[oi] = __float2half(v);
+        if (out32) out32[oi] = v;
+        if (tid == 0) lse[((long)b * H + h) * L + q] = mx + log2f(sum);
+    }
 }
 
-extern "C" int wc_attn_fwd(const void* qkv, const void* vt, void* out, float* out32, float* lse, int B,
-                           int L, int Lp, int H, int DH, void* stream) {
+// mean_h P_h for the entries the origin-shifted tiles leave out: rows q < r (all keys) and columns k < r (q >= r).
+template <int DH>
+__global__ __launch_bounds__(256) void attn_mean_edge_kernel(const __half* __restrict__ qkv, const float* __restrict__ lse,
+                                                              float* __restrict__ mean, int L, int H, int E, int r) {
+    const int b = blockIdx.y;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const long nrow = (long)r * L;                    // entries of the first r rows
+    const long ncol = (long)r * (L - r);              // remaining entries of the first r columns
+    if (e >= nrow + ncol) return;
+    int q, k;
+    if (e < nrow) { q = (int)(e / L); k = (int)(e - (long)q * L); }
+    else { const long f = e - nrow; k = (int)(f / (L - r)); q = r + (int)(f - (long)k * (L - r)); }
+    const long ldq = 3L * E;
+    const __half* qr = qkv + ((long)b * L + q) * ldq;
+    const __half* kr = qkv + ((long)b * L + k) * ldq + E;
+    float acc = 0.f;
+    for (int h = 0; h < H; ++h) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH / 8; ++c) {
+            const f16x8 a = *reinterpret_cast<const f16x8*>(qr + h * DH + c * 8);
+            const f16x8 w = *reinterpret_cast<const f16x8*>(kr + h * DH + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s = fmaf((float)a[j], (float)w[j], s);
+        }
+        acc += __builtin_amdgcn_exp2f(s - lse[((long)b * H + h) * L + q]);
+    }
+    mean[(long)b * L * L + (long)q * L + k] = acc / H;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A remainder of at most ATT_EDGE_MAX rows (L % 128) is finished by the row kernels; the tiles then start at it.
+#define ATT_EDGE_MAX 8
+static int attn_origin(int L) {
+    const int r = L % 128;
+    return (L >= 128 && r > 0 && r <= ATT_EDGE_MAX) ? r : 0;
+}
+
+extern "C" int wc_attn_fwd(const void* qkv, void* out, float* out32, float* lse, int B, int L, int H, int DH,
+                           void* stream) {
     const int E = H * DH;
-    WC_CHECK_ARG(qkv && vt && out && lse && B > 0 && L > 0 && Lp >= L && Lp % 64 == 0,
-                 "wc_attn_fwd: bad argument");
+    WC_CHECK_ARG(qkv && out && lse && B > 0 && L > 0, "wc_attn_fwd: bad argument");
     WC_CHECK_ARG(DH == 64 || DH == 32, "wc_attn_fwd: head dim must be 32 or 64 (got %d)", DH);
-    WC_CHECK_ARG(E % 8 == 0 && B <= 65535 && H <= 65535, "wc_attn_fwd: bad shape");
-    dim3 grid(wc_cdiv(L, 128), H, B);
+    WC_CHECK_ARG(E % 8 == 0 && B <= 65535 && H <= 65535 && (long)L * 4 <= 60 * 1024, "wc_attn_fwd: bad shape");
+    const int r = attn_origin(L);
+    dim3 grid(wc_cdiv(L - r, 128), H, B);
     hipStream_t st = (hipStream_t)stream;
     if (DH == 64) {
-        const size_t lds = 2 * (64 * (64 * 2 + 16) + 64 * 136);
-        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), lds, st, (const __half*)qkv,
-                           (const __half*)vt, (__half*)out, out32, lse, L, Lp, H, E);
+        const size_t lds = 2 * (64 * (64 * 2 + 16) + 64 * 128);
+        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), lds, st, (const __half*)qkv, (__half*)out, out32, lse, L, H,
+                           E, r);
+        if (r)
+            hipLaunchKernelGGL(attn_rows_kernel<64>, dim3(r, H, B), dim3(256), (size_t)L * 4, st, (const __half*)qkv,
+                               (__half*)out, out32, lse, L, H, E);
     } else {
-        const size_t lds = 2 * (64 * (32 * 2 + 16) + 32 * 136);
-        hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), lds, st, (const __half*)qkv,
-                           (const __half*)vt, (__half*)out, out32, lse, L, Lp, H, E);
+        const size_t lds = 2 * (64 * (32 * 2 + 16) + 64 * 64);
+        hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), lds, st, (const __half*)qkv, (__half*)out, out32, lse, L, H,
+                           E, r);
+        if (r)
+            hipLaunchKernelGGL(attn_rows_kernel<32>, dim3(r, H, B), dim3(256), (size_t)L * 4, st, (const __half*)qkv,
+                               (__half*)out, out32, lse, L, H, E);
     }
     WC_LAUNCH_CHECK("attn_fwd_kernel");
     return WC_OK;
@@ -375,17 +457,25 @@ extern "C" int wc_attn_mean(const void* qkv, const float* lse, float* mean, int 
     const int E = H * DH;
     WC_CHECK_ARG(qkv && lse && mean && B > 0 && L > 0 && H > 0, "wc_attn_mean: bad argument");
     WC_CHECK_ARG(DH == 64 || DH == 32, "wc_attn_mean: head dim must be 32 or 64 (got %d)", DH);
-    const int nt = wc_cdiv(L, 128);
+    const int r = attn_origin(L);
+    const int nt = wc_cdiv(L - r, 128);
     dim3 grid(nt, nt, B);
+    const long nedge = (long)r * L + (long)r * (L - r);
     hipStream_t st = (hipStream_t)stream;
     if (DH == 64) {
         const size_t lds = 2 * (2 * 128 * (64 * 2 + 16) + 512);
         hipLaunchKernelGGL(attn_mean_kernel<64>, grid, dim3(256), lds, st, (const __half*)qkv, lse, mean,
-                           L, H, E);
+                           L, H, E, r);
+        if (r)
+            hipLaunchKernelGGL(attn_mean_edge_kernel<64>, dim3(wc_cdiv(nedge, 256), B), dim3(256), 0, st, (const __half*)qkv,
+                               lse, mean, L, H, E, r);
     } else {
         const size_t lds = 2 * (2 * 128 * (32 * 2 + 16) + 512);
         hipLaunchKernelGGL(attn_mean_kernel<32>, grid, dim3(256), lds, st, (const __half*)qkv, lse, mean,
-                           L, H, E);
+                           L, H, E, r);
+        if (r)
+            hipLaunchKernelGGL(attn_mean_edge_kernel<32>, dim3(wc_cdiv(nedge, 256), B), dim3(256), 0, st, (const __half*)qkv,
+                               lse, mean, L, H, E, r);
     }
     WC_LAUNCH_CHECK("attn_mean_kernel");
     return WC_OK;

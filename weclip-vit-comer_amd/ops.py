@@ -124,16 +124,12 @@ def attention(qkv16, B, Lq, H, DH, want_mean=True, want_o32=False):
     Returns (o16 (B*L, E) fp16, lse (B,H,L) f32, mean (B,L,L) f32 or None)."""
     E = H * DH
     dev = qkv16.device
-    Lp = (Lq + 63) // 64 * 64
-    vt = torch.empty(B, H, DH, Lp, device=dev, dtype=F16)
     lib = L.lib()
-    lib.wc_attn_vt(L.ptr(qkv16, F16, "qkv"), L.ptr(vt), B, Lq, Lp, H, DH, L.stream())
     o16 = torch.empty(B * Lq, E, device=dev, dtype=F16)
     lse = torch.empty(B, H, Lq, device=dev, dtype=F32)
     o32 = torch.empty(B * Lq, E, device=dev, dtype=F32) if want_o32 else None
     t0 = KernelTimer.start()
-    lib.wc_attn_fwd(L.ptr(qkv16), L.ptr(vt), L.ptr(o16), L.ptr(o32), L.ptr(lse), B, Lq, Lp, H, DH,
-                    L.stream())
+    lib.wc_attn_fwd(L.ptr(qkv16, F16, "qkv"), L.ptr(o16), L.ptr(o32), L.ptr(lse), B, Lq, H, DH, L.stream())
     KernelTimer.stop("attn_fwd_kernel", t0, 4.0 * B * H * Lq * Lq * DH)
     mean = None
     if want_mean:
