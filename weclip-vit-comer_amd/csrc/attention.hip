@@ -341,19 +341,21 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(const __half* __restrict
                                                          int E) {
     extern __shared__ float sc[];            // [L] scores, then probabilities
     __shared__ float red[16];
-    __shared__ float part[256 / DH][DH];
+    constexpr int NCH = DH / 8;              // 16-B chunks per row
+    constexpr int NPT = 256 / NCH;           // key slices in the P V pass
+    __shared__ float part[NPT][DH];
     const int tid = threadIdx.x, q = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const long ldq = 3L * E;
     const __half* base = qkv + (long)b * L * ldq + (long)h * DH;
-    f16x8 qv[DH / 8];
+    f16x8 qv[NCH];
 #pragma unroll
-    for (int c = 0; c < DH / 8; ++c) qv[c] = *reinterpret_cast<const f16x8*>(base + (long)q * ldq + c * 8);
+    for (int c = 0; c < NCH; ++c) qv[c] = *reinterpret_cast<const f16x8*>(base + (long)q * ldq + c * 8);
     float mx = NEG_BIG;
     for (int key = tid; key < L; key += 256) {
         const __half* kr = base + E + (long)key * ldq;
         float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < DH / 8; ++c) {
+        for (int c = 0; c < NCH; ++c) {
             const f16x8 kv = *reinterpret_cast<const f16x8*>(kr + c * 8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) s = fmaf((float)qv[c][j], (float)kv[j], s);
@@ -369,15 +371,36 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(const __half* __restrict
         sc[key] = (float)(_Float16)pr;
     }
     sum = block_sum(sum, red);               // (its barriers also publish sc[])
-    const int d = tid % DH, pt = tid / DH;
-    float o = 0.f;
-    for (int key = pt; key < L; key += 256 / DH) o = fmaf(sc[key], __half2float(base[2 * E + (long)key * ldq + d]), o);
-    part[pt][d] = o;
+    // O = P V: thread = (16-B dh chunk, key slice); 4 row loads in flight per thread
+    const int ch = tid % NCH, pt = tid / NCH;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    const __half* vcol = base + 2 * E + ch * 8;
+    int key = pt;
+    for (; key + 3 * NPT < L; key += 4 * NPT) {
+        f16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(vcol + (long)(key + u * NPT) * ldq);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float pr = sc[key + u * NPT];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = fmaf(pr, (float)v[u][j], o[j]);
+        }
+    }
+    for (; key < L; key += NPT) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(vcol + (long)key * ldq);
+        const float pr = sc[key];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaf(pr, (float)v[j], o[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[pt][ch * 8 + j] = o[j];
     __syncthreads();
     if (tid < DH) {
         float v = 0.f;
-#pragma unroll
-        for (int k = 0; k < 256 / DH; ++k) v += part[k][tid];
+        for (int k = 0; k < NPT; ++k) v += part[k][tid];
         v /= sum;
         const long oi = ((long)b * L + q) * E + (long)h * DH + tid;
         out[oi] = __float2half(v);
@@ -390,19 +413,23 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(const __half* __restrict
 template <int DH>
 __global__ __launch_bounds__(256) void attn_mean_edge_kernel(const __half* __restrict__ qkv, const float* __restrict__ lse,
                                                               float* __restrict__ mean, int L, int H, int E, int r) {
+    // 16 lanes per entry, one head each (heads 16, 32, .. loop); the 16-lane group sums the heads
     const int b = blockIdx.y;
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const int hl = threadIdx.x & 15;
+    const long e = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const long nrow = (long)r * L;                    // entries of the first r rows
     const long ncol = (long)r * (L - r);              // remaining entries of the first r columns
-    if (e >= nrow + ncol) return;
-    int q, k;
-    if (e < nrow) { q = (int)(e / L); k = (int)(e - (long)q * L); }
-    else { const long f = e - nrow; k = (int)(f / (L - r)); q = r + (int)(f - (long)k * (L - r)); }
+    const bool live = e < nrow + ncol;
+    int q = 0, k = 0;
+    if (live) {
+        if (e < nrow) { q = (int)(e / L); k = (int)(e - (long)q * L); }
+        else { const long f = e - nrow; k = (int)(f / (L - r)); q = r + (int)(f - (long)k * (L - r)); }
+    }
     const long ldq = 3L * E;
     const __half* qr = qkv + ((long)b * L + q) * ldq;
     const __half* kr = qkv + ((long)b * L + k) * ldq + E;
     float acc = 0.f;
-    for (int h = 0; h < H; ++h) {
+    for (int h = hl; h < H; h += 16) {
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < DH / 8; ++c) {
@@ -413,7 +440,9 @@ __global__ __launch_bounds__(256) void attn_mean_edge_kernel(const __half* __res
         }
         acc += __builtin_amdgcn_exp2f(s - lse[((long)b * H + h) * L + q]);
     }
-    mean[(long)b * L * L + (long)q * L + k] = acc / H;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (live && hl == 0) mean[(long)b * L * L + (long)q * L + k] = acc / H;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -467,14 +496,14 @@ extern "C" int wc_attn_mean(const void* qkv, const float* lse, float* mean, int 
         hipLaunchKernelGGL(attn_mean_kernel<64>, grid, dim3(256), lds, st, (const __half*)qkv, lse, mean,
                            L, H, E, r);
         if (r)
-            hipLaunchKernelGGL(attn_mean_edge_kernel<64>, dim3(wc_cdiv(nedge, 256), B), dim3(256), 0, st, (const __half*)qkv,
+            hipLaunchKernelGGL(attn_mean_edge_kernel<64>, dim3(wc_cdiv(nedge, 16), B), dim3(256), 0, st, (const __half*)qkv,
                                lse, mean, L, H, E, r);
     } else {
         const size_t lds = 2 * (2 * 128 * (32 * 2 + 16) + 512);
         hipLaunchKernelGGL(attn_mean_kernel<32>, grid, dim3(256), lds, st, (const __half*)qkv, lse, mean,
                            L, H, E, r);
         if (r)
-            hipLaunchKernelGGL(attn_mean_edge_kernel<32>, dim3(wc_cdiv(nedge, 256), B), dim3(256), 0, st, (const __half*)qkv,
+            hipLaunchKernelGGL(attn_mean_edge_kernel<32>, dim3(wc_cdiv(nedge, 16), B), dim3(256), 0, st, (const __half*)qkv,
                                lse, mean, L, H, E, r);
     }
     WC_LAUNCH_CHECK("attn_mean_kernel");
