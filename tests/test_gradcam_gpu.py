@@ -65,3 +65,25 @@ def test_vitb_224_gradcam_matches_reference(golden, precision):
             assert ep < 1e-2 and ec < 5e-2
     finally:
         config.precision = "fast"
+
+
+def test_gradcam_cls_remainder_path_matches_oracle():
+    """1 + 11*12 = 133 tokens: L % 128 = 5, so the attention forward/mean and the GradCAM column-sum kernels
+    run their origin-shifted tiles plus the row/edge kernels (the 1 + 32*32 production case has remainder 1).
+    Checked against the CPU oracle (itself pinned to the reference goldens at the other sizes)."""
+    from oracle import weclip_oracle as O
+    H, W = 176, 192
+    sd = synth.make_clip_state_dict(**synth.TINY)
+    img = synth.make_images(1, H, W, seed=3)
+    labels = [[3, 7]]
+    out = _run(sd, img, synth.TINY["embed_dim"], labels, H, W)
+    xs, maps = O.encode_image(img, sd, heads=1)
+    bg, fg = synth.make_text_features(20, 25, synth.TINY["embed_dim"])
+    text = torch.cat([fg[labels[0]], bg], 0)
+    for j, (cam, probs, attn) in enumerate(out):
+        rcam, rprobs, rpm, _ = O.grad_cam(xs[-1][:, 0:1], text, j, sd, 1, H // 16, W // 16)
+        ep = np.abs(probs - rprobs.numpy()[0]).max() / rprobs.numpy().max()
+        ec = np.abs(cam - rcam).max()
+        ea = np.abs(attn - rpm.numpy()[0]).max() / rpm.numpy().max()
+        print(f"L=133 class {j}: probs rel {ep:.2e}  cam abs {ec:.2e}  attn rel {ea:.2e}")
+        assert ep < 5e-3 and ea < 5e-3 and ec < 3e-2

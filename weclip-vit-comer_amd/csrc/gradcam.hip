@@ -245,7 +245,8 @@ __global__ __launch_bounds__(256) void attn_bwd_colsum_kernel(const __half* __re
                                                                const float* __restrict__ delta,
                                                                const int* __restrict__ pair_img,
                                                                float* __restrict__ u, float* __restrict__ dS0,
-                                                               float* __restrict__ P0, int L, int H, int E) {
+                                                               float* __restrict__ P0, int L, int H, int E, int origin,
+                                                               int nkt, int PH) {
     constexpr int KS = DH / 16;
     constexpr int ROW = DH * 2 + 16;
     constexpr int TB = 128 * ROW;
@@ -255,7 +256,13 @@ __global__ __launch_bounds__(256) void attn_bwd_colsum_kernel(const __half* __re
     extern __shared__ __attribute__((aligned(16))) char smem[];   // K | V | 2 x QBUF | red[2][128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, l31 = lane & 31, wr = wave >> 1, wc = wave & 1;
-    const int k0 = blockIdx.x * 128, h = blockIdx.y, p = blockIdx.z, img = pair_img[p];
+    // XCD-aware order: the key tiles of one (pair, head) run back to back on one XCD, which then streams that
+    // head's Q / dO tiles from its own L2 (they were re-fetched from HBM by every key tile before: 5x traffic).
+    // Tiles cover keys and queries [origin, L); attn_bwd_colsum_edge_kernel adds the first `origin` of both.
+    const int slot = blockIdx.x >> 3;
+    const int ph = (slot / nkt) * 8 + (blockIdx.x & 7);
+    if (ph >= PH) return;
+    const int k0 = origin + (slot - (slot / nkt) * nkt) * 128, h = ph % H, p = ph / H, img = pair_img[p];
     const long ldq = 3L * E;
     const __half* qb = qkv + (long)img * L * ldq + (long)h * DH;
     const __half* dob = dO + (long)p * L * E + (long)h * DH;
@@ -286,13 +293,13 @@ __global__ __launch_bounds__(256) void attn_bwd_colsum_kernel(const __half* __re
         _Pragma("unroll") \
         for (int i = 0; i < NC; ++i) { \
             const int c = tid + 256 * i; \
-            int qr = t__ * 128 + c / CH; \
+            int qr = origin + t__ * 128 + c / CH; \
             if (qr > L - 1) qr = L - 1; \
             rq[i] = *reinterpret_cast<const u32x4*>(qb + (long)qr * ldq + (c % CH) * 8); \
             rd[i] = *reinterpret_cast<const u32x4*>(dob + (long)qr * E + (c % CH) * 8); \
         } \
         if (tid < 128) { \
-            const int qr = t__ * 128 + tid; \
+            const int qr = origin + t__ * 128 + tid; \
             rl = qr < L ? lseb[qr] : 1.0e30f; \
             rdl = qr < L ? delb[qr] : 0.f; \
         } \
@@ -314,11 +321,11 @@ __global__ __launch_bounds__(256) void attn_bwd_colsum_kernel(const __half* __re
         } \
     }
     float usum[2] = {0.f, 0.f};
-    const int nt = (L + 127) / 128;
+    const int nt = (L - origin + 127) / 128;
     GLOAD(0);
     LSTORE(0);
     __syncthreads();
-    const bool col0 = (blockIdx.x == 0 && wc == 0 && l31 == 0);
+    const bool col0 = (k0 == 0 && wc == 0 && l31 == 0);
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         if (t + 1 < nt) GLOAD(t + 1);
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(256) void attn_bwd_colsum_kernel(const __half* __re
                     const float ds = pr * dp[mi][ni][r];
                     usum[ni] += ds;
                     if (ni == 0 && col0) {
-                        const int q = t * 128 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        const int q = origin + t * 128 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                         if (q < L) {
                             dS0[((long)p * H + h) * L + q] = ds;
                             P0[((long)p * H + h) * L + q] = pr;
@@ -386,6 +393,69 @@ __global__ __launch_bounds__(256) void attn_bwd_colsum_kernel(const __half* __re
     if (tid < 128) {
         const int key = k0 + tid;
         if (key < L) u[((long)p * H + h) * L + key] = red[tid] + red[128 + tid];
+    }
+}
+
+// Edge part of (i) when the tiles start at `r` = L % 128 (the CLS token): one workgroup per (pair, head).
+//   keys l < r, every query q:   dS[q,l] -> dS0 / P0 (l == 0) and u[l] = sum_q dS[q,l]
+//   queries q < r, keys l >= r:  u[l] += dS[q,l]        (runs after the tiled kernel on the same stream)
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_colsum_edge_kernel(const __half* __restrict__ qkv, const __half* __restrict__ dO,
+                                                                    const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                    const int* __restrict__ pair_img, float* __restrict__ u,
+                                                                    float* __restrict__ dS0, float* __restrict__ P0, int L, int H,
+                                                                    int E, int r) {
+    __shared__ float red[16];
+    const int tid = threadIdx.x, h = blockIdx.x, p = blockIdx.y, img = pair_img[p];
+    const long ldq = 3L * E;
+    const __half* qb = qkv + (long)img * L * ldq + (long)h * DH;
+    const __half* dob = dO + (long)p * L * E + (long)h * DH;
+    const float* lseb = lse + ((long)img * H + h) * L;
+    const float* delb = delta + ((long)p * H + h) * L;
+    const long ob = ((long)p * H + h) * L;
+    for (int l = 0; l < r; ++l) {                      // key l, thread per query
+        float usum = 0.f;
+        for (int q = tid; q < L; q += 256) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH / 8; ++c) {
+                const f16x8 qv = *reinterpret_cast<const f16x8*>(qb + (long)q * ldq + c * 8);
+                const f16x8 kv = *reinterpret_cast<const f16x8*>(qb + (long)l * ldq + E + c * 8);
+                const f16x8 dv = *reinterpret_cast<const f16x8*>(dob + (long)q * E + c * 8);
+                const f16x8 vv = *reinterpret_cast<const f16x8*>(qb + (long)l * ldq + 2 * E + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    s = fmaf((float)qv[j], (float)kv[j], s);
+                    dp = fmaf((float)dv[j], (float)vv[j], dp);
+                }
+            }
+            const float pr = __builtin_amdgcn_exp2f(s - lseb[q]);
+            const float ds = pr * (dp - delb[q]);
+            usum += ds;
+            if (l == 0) { dS0[ob + q] = ds; P0[ob + q] = pr; }
+        }
+        usum = block_sum(usum, red);
+        if (tid == 0) u[ob + l] = usum;
+    }
+    for (int l = r + tid; l < L; l += 256) {           // thread per key, the first r queries
+        float add = 0.f;
+        for (int q = 0; q < r; ++q) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH / 8; ++c) {
+                const f16x8 qv = *reinterpret_cast<const f16x8*>(qb + (long)q * ldq + c * 8);
+                const f16x8 kv = *reinterpret_cast<const f16x8*>(qb + (long)l * ldq + E + c * 8);
+                const f16x8 dv = *reinterpret_cast<const f16x8*>(dob + (long)q * E + c * 8);
+                const f16x8 vv = *reinterpret_cast<const f16x8*>(qb + (long)l * ldq + 2 * E + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    s = fmaf((float)qv[j], (float)kv[j], s);
+                    dp = fmaf((float)dv[j], (float)vv[j], dp);
+                }
+            }
+            add += __builtin_amdgcn_exp2f(s - lseb[q]) * (dp - delb[q]);
+        }
+        u[ob + l] += add;
     }
 }
 
@@ -522,15 +592,24 @@ extern "C" int wc_attn_bwd_colsum(const void* qkv, const void* dO, const float* 
     hipLaunchKernelGGL(attn_delta_kernel, dim3(wc_cdiv(total, 4)), dim3(256), 0, st, (const __half*)dO, o32,
                        pair_img, delta, L, H, DH, total);
     WC_LAUNCH_CHECK("attn_delta_kernel");
-    dim3 grid(wc_cdiv(L, 128), H, P);
+    const int rr = L % 128;
+    const int origin = (L >= 128 && rr > 0 && rr <= 8) ? rr : 0;   // tiny remainder (CLS row): tiles start behind it
+    const int nkt = wc_cdiv(L - origin, 128), PH = P * H;
+    dim3 grid((unsigned)(nkt * ((PH + 7) / 8 * 8)));
     if (DH == 64) {
         const size_t lds = 2 * 128 * (64 * 2 + 16) + 2 * (2 * 128 * (64 * 2 + 16) + 1024) + 1024;
         hipLaunchKernelGGL(attn_bwd_colsum_kernel<64>, grid, dim3(256), lds, st, (const __half*)qkv,
-                           (const __half*)dO, lse, delta, pair_img, u, dS0, P0, L, H, E);
+                           (const __half*)dO, lse, delta, pair_img, u, dS0, P0, L, H, E, origin, nkt, PH);
+        if (origin)
+            hipLaunchKernelGGL(attn_bwd_colsum_edge_kernel<64>, dim3(H, P), dim3(256), 0, st, (const __half*)qkv,
+                               (const __half*)dO, lse, delta, pair_img, u, dS0, P0, L, H, E, origin);
     } else {
         const size_t lds = 2 * 128 * (32 * 2 + 16) + 2 * (2 * 128 * (32 * 2 + 16) + 1024) + 1024;
         hipLaunchKernelGGL(attn_bwd_colsum_kernel<32>, grid, dim3(256), lds, st, (const __half*)qkv,
-                           (const __half*)dO, lse, delta, pair_img, u, dS0, P0, L, H, E);
+                           (const __half*)dO, lse, delta, pair_img, u, dS0, P0, L, H, E, origin, nkt, PH);
+        if (origin)
+            hipLaunchKernelGGL(attn_bwd_colsum_edge_kernel<32>, dim3(H, P), dim3(256), 0, st, (const __half*)qkv,
+                               (const __half*)dO, lse, delta, pair_img, u, dS0, P0, L, H, E, origin);
     }
     WC_LAUNCH_CHECK("attn_bwd_colsum_kernel");
     hipLaunchKernelGGL(qkv_colsum_kernel, dim3(H, P), dim3(256), 0, st, (const __half*)qkv, (const __half*)dO, u,
