@@ -12,6 +12,8 @@ fp16 (hi[+lo]); parameter gradients are unscaled in the last epilogue.
 Weight gradients dW = dY^T X use the same TN GEMM on transposed fp16 copies of dY and X
 (tokens become the K dimension, zero padded to a multiple of 64).
 """
+import os
+
 import torch
 
 from . import config, ops
@@ -19,6 +21,7 @@ from .clip import vit_engine as VE
 from .ops import F16, F32, Split
 
 GRAD_SCALE = 4096.0
+_WGRAD_WGS = int(os.environ.get("WECLIP_WGRAD_WGS", "512"))   # workgroups a split-K weight-gradient GEMM may use
 
 
 def _f(p):
@@ -186,7 +189,7 @@ class HeadEngine:
         (blockIdx.z); wc_sum_slices_wb sums them straight into the dense weight / bias gradient buffers."""
         tiles = ((N_ + 127) // 128) * ((K_ + 1 + 127) // 128)
         ns = 1
-        while ns * 2 * tiles <= 1024 and M // (ns * 2) >= 256:
+        while ns * 2 * tiles <= _WGRAD_WGS and M // (ns * 2) >= 256:
             ns *= 2
         part, ns = ops.wgrad_partials(dy16, x16, M, N_, K_, lda=lda, ldx=ldx, slices=ns, bias=True, xmap=xmap)
         gw, gb = self._dest(wname, (N_, K_)), self._dest(bname, (N_,))
