@@ -66,11 +66,11 @@ struct GemmArgs {
 #define WC_EPI_ACT(v_, n_)                                                                        \
     if (act == 1) {                                                                               \
         _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_)                                       \
-            (v_)[e_] = (v_)[e_] * (1.0f / (1.0f + __expf(-1.702f * (v_)[e_])));                   \
+            (v_)[e_] = (v_)[e_] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * (v_)[e_]));                   \
     } else if (act == 2) {                                                                        \
         _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_) (v_)[e_] = fmaxf((v_)[e_], 0.f);      \
     } else if (act == 3) {                                                                        \
-        _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_) (v_)[e_] = 1.0f / (1.0f + __expf(-(v_)[e_])); \
+        _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_) (v_)[e_] = __builtin_amdgcn_rcpf(1.0f + __expf(-(v_)[e_])); \
     }
 
 // Per-column epilogue constants of a lane's two output columns (bias, scale): fetched BEFORE the K loop of a
@@ -100,7 +100,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         // stores per lane, store-issue bound).  Each wave instead drops 16 finished rows at a time into
         // its own 4 KiB of LDS scratch and re-reads them row-major, 4 columns per lane: residual / aux
         // side inputs are one 16-B (8-B) load, outputs one 8-B store per 4 values.
-        float* tile = reinterpret_cast<float*>(scratch);
+        float* tile0 = reinterpret_cast<float*>(scratch);     // two 4-KiB buffers per wave, alternated by chunk
         const int c4 = (lane & 15) * 4;
         const int gcol = n0 + wc * 64 + c4;
         const bool full = gcol + 3 < g.N;
@@ -108,6 +108,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
 #pragma unroll
         for (int c = 0; c < 4; ++c) {            // rows [16c, 16c+16) of the wave's 64x64 sub-tile
             const int mi = c >> 1, rq0 = (c & 1) * 8;
+            float* tile = tile0 + (c & 1) * 1024;
             float v[16];
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
@@ -151,7 +152,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                         else for (int k = 0; k < 4 && gcol + k < g.N; ++k) u[k] = up[k];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            const float sg = 1.0f / (1.0f + __expf(-1.702f * u[k]));
+                            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u[k]));
                             f[it][k] *= sg * (1.0f + 1.702f * u[k] * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
                         }
                     } else {
@@ -239,7 +240,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                     if (act == 4) {
                         const long arow = g.rowmap ? (long)g.rowmap[row / g.rpg] * g.rpg + row % g.rpg : row;
                         const float u = g.aux[arow * g.ldaux + colc];
-                        const float sg = 1.0f / (1.0f + __expf(-1.702f * u));
+                        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u));
                         uv[r] = sg * (1.0f + 1.702f * u * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
                     } else {
                         uv[r] = __half2float(g.auxh[(long)row * g.ldaux + colc]) > 0.f ? 1.f : 0.f;   // ReLU'
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
         __syncthreads();
     }
 #undef GLDS
-    gemm_epilogue<AUX>(g, acc, m0, n0, wr, wc, lane, zb, smem + wave * 4096, bv, sc);
+    gemm_epilogue<AUX>(g, acc, m0, n0, wr, wc, lane, zb, smem + wave * 8192, bv, sc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -586,8 +587,8 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
     if (wr == 0) __builtin_amdgcn_s_barrier();       // re-align the two row groups
     __syncthreads();                                 // every wave is done with the operand slots: epilogue scratch
     if (g.dbg & 1) return;
-    gemm_epilogue<AUX>(g, acc[0], m0 + wr * 128, n0, 0, wc, lane, 0, smem + wave * 4096, bv, sc);
-    gemm_epilogue<AUX>(g, acc[1], m0 + wr * 128 + 64, n0, 0, wc, lane, 0, smem + wave * 4096, bv, sc);
+    gemm_epilogue<AUX>(g, acc[0], m0 + wr * 128, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc);
+    gemm_epilogue<AUX>(g, acc[1], m0 + wr * 128 + 64, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -742,7 +743,7 @@ __global__ __launch_bounds__(256, 2) void gemm_km_kernel(KmArgs g) {
         }
     }
     const float bv[2] = {0.f, 0.f}, sc[2] = {1.f, 1.f};
-    gemm_epilogue<false>(g.e, acc, n0, k0, wr, wc, lane, z, smem + wave * 4096, bv, sc);
+    gemm_epilogue<false>(g.e, acc, n0, k0, wr, wc, lane, z, smem + wave * 8192, bv, sc);
 }
 
 // part: (nslices, N, K + bias) fp32 with nslices = ceil(M / mslice); zeros: device buffer of >= 16 zero bytes.
