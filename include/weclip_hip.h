@@ -74,6 +74,17 @@ int wc_seg_loss_fwd(const float* seg, const int64_t* label, float* part, float* 
 int wc_seg_loss_bwd(const float* seg, const int64_t* label, const float* wts, float* ghr, int B, int nc, int h,
                     int w, int H, int W, int ignore, void* stream);
 
+/* Affinity loss fused with the affinity-label construction (reference utils/camutils.py:226-247 +
+ * scripts/dist_clip_voc.py:116-133 radius mask + utils/losses.py:11-22): attn_pred (B,hw,hw) f32, cam_label (B,H,W)
+ * int64 pseudo labels (nearest down-sampled to h x w inside), Chebyshev `radius`.
+ * fwd: sums (4) = [sum_pos(1-p), n_pos, sum_neg(p), n_neg]  (loss = 0.5*s0/(s1+1) + 0.5*s2/(s3+1));
+ *      part: workspace 4*B*ceil(hw/8) f32.
+ * bwd: dap (B,hw,hw) = coef[0] on positive pairs, coef[1] on negative pairs, 0 elsewhere (coef: 2 device floats). */
+int wc_aff_loss_fwd(const float* attn_pred, const int64_t* cam_label, float* part, float* sums, int B, int h,
+                    int w, int H, int W, int radius, int ignore, void* stream);
+int wc_aff_loss_bwd(const int64_t* cam_label, const float* coef, float* dap, int B, int h, int w, int H, int W,
+                    int radius, int ignore, void* stream);
+
 /* ---- MFMA GEMM ------------------------------------------------------------------------ */
 /* C[M,N] = epilogue(sum_{s<nseg} A_s[M,K] * W_s[N,K]^T), fp16 operands (K contiguous), fp32
  * accumulate on v_mfma_f32_32x32x16_f16.  Replaces F.linear / nn.Linear / 1x1 Conv2d / bmm at

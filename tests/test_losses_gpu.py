@@ -40,3 +40,24 @@ def test_bilinear_upsample_backward(align):
     xc = x.cuda().requires_grad_(True)
     (bilinear_upsample(xc, (40, 61), align) * gy.cuda()).sum().backward()
     np.testing.assert_allclose(xc.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,h,w,radius", [(2, 4, 6, 8), (1, 32, 32, 8), (2, 10, 7, 2)])
+def test_fused_affinity_loss_forward_backward(B, h, w, radius):
+    """label -> affinity label (nearest /16, radius mask, ignore) + get_aff_loss, one pass, vs the oracle."""
+    from weclip_vit_comer_amd.utils.losses import get_aff_loss_fused
+    g = torch.Generator().manual_seed(h * w)
+    H, W = 16 * h, 16 * w
+    cam = torch.randint(0, 4, (B, H, W), generator=g)
+    cam[:, :, : W // 5] = 255                      # ignored stripe
+    ap = torch.rand(B, h * w, h * w, generator=g)
+    ref_in = ap.double().requires_grad_(True)
+    aff_label = O.cams_to_affinity_label(cam, O.radius_mask(h, w, radius), ignore_index=255)
+    ref = O.aff_loss(ref_in, aff_label)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    ref.backward()
+    x = ap.cuda().requires_grad_(True)
+    out = get_aff_loss_fused(x, cam.cuda(), radius=radius, ignore_index=255)
+    (0.1 * out).backward()
+    assert abs(out.item() - ref.item()) < 1e-5
+    np.testing.assert_allclose(x.grad.cpu().numpy(), 0.1 * ref_in.grad.numpy(), rtol=1e-4, atol=1e-10)

@@ -110,3 +110,92 @@ extern "C" int wc_seg_loss_bwd(const float* seg, const int64_t* label, const flo
     return WC_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Affinity loss of the training step, fused with the label -> affinity-label construction.
+// reference utils/camutils.py:226-247 (cams_to_affinity_label: nearest down-sampling of the pseudo labels by 16,
+// pairwise equality, ignore where either token is ignored or the pair is outside the radius mask of
+// scripts/dist_clip_voc.py:116-133) + utils/losses.py:11-22 (get_aff_loss):
+//   loss = 0.5 * sum_pos(1 - p) / (n_pos + 1) + 0.5 * sum_neg(p) / (n_neg + 1)
+// The reference materialises the (B, hw, hw) affinity label, the two masks and their products (six passes over
+// 67 MB at hw = 1024); here one pass reads attn_pred and the hw low-res labels of the image (LDS).
+__device__ __forceinline__ int aff_lowres_label(const long* __restrict__ cam, int b, int t, int h, int w, int H, int W) {
+    const int y = t / w, x = t - y * w;
+    // F.interpolate(mode="nearest"): src = min(floor(dst * in / out), in - 1)
+    int sy = (int)floorf(y * ((float)H / h)), sx = (int)floorf(x * ((float)W / w));
+    sy = sy > H - 1 ? H - 1 : sy;
+    sx = sx > W - 1 ? W - 1 : sx;
+    return (int)cam[((long)b * H + sy) * W + sx];
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void aff_loss_kernel(const float* __restrict__ ap, const long* __restrict__ cam,
+                                                        float* __restrict__ part, const float* __restrict__ coef,
+                                                        float* __restrict__ dap, int h, int w, int H, int W, int radius,
+                                                        int ignore) {
+    extern __shared__ int lab[];          // [hw] low-res labels of image b
+    __shared__ float red[16];
+    const int hw = h * w, b = blockIdx.y;
+    for (int t = threadIdx.x; t < hw; t += 256) lab[t] = aff_lowres_label(cam, b, t, h, w, H, W);
+    __syncthreads();
+    // block = ROWS rows i of the (hw, hw) matrix, threads sweep j
+    constexpr int ROWS = 8;
+    float ps = 0.f, pc = 0.f, ns = 0.f, nc = 0.f;
+    float cp = 0.f, cn = 0.f;
+    if (BWD) { cp = coef[0]; cn = coef[1]; }
+    for (int r = 0; r < ROWS; ++r) {
+        const int i = blockIdx.x * ROWS + r;
+        if (i >= hw) break;
+        const int li = lab[i], yi = i / w, xi = i - yi * w;
+        const float* row = ap + ((long)b * hw + i) * hw;
+        for (int j = threadIdx.x; j < hw; j += 256) {
+            const int lj = lab[j], yj = j / w, xj = j - yj * w;
+            const int dy = yi - yj, dx = xi - xj;
+            const bool ok = li != ignore && lj != ignore && dy <= radius && -dy <= radius && dx <= radius && -dx <= radius;
+            const bool pos = ok && li == lj, neg = ok && li != lj;
+            if (BWD) {
+                dap[((long)b * hw + i) * hw + j] = pos ? cp : (neg ? cn : 0.f);
+            } else {
+                const float p = row[j];
+                if (pos) { ps += 1.f - p; pc += 1.f; }
+                if (neg) { ns += p; nc += 1.f; }
+            }
+        }
+    }
+    if (!BWD) {
+        const float a0 = block_sum(ps, red), a1 = block_sum(pc, red), a2 = block_sum(ns, red), a3 = block_sum(nc, red);
+        if (threadIdx.x == 0) {
+            const long blk = (long)blockIdx.y * gridDim.x + blockIdx.x;
+            part[blk * 4] = a0; part[blk * 4 + 1] = a1; part[blk * 4 + 2] = a2; part[blk * 4 + 3] = a3;
+        }
+    }
+}
+
+// sums (4) = [sum_pos(1-p), n_pos, sum_neg(p), n_neg]; part: workspace 4 * B * ceil(hw/8) floats.
+extern "C" int wc_aff_loss_fwd(const float* attn_pred, const int64_t* cam_label, float* part, float* sums, int B, int h,
+                               int w, int H, int W, int radius, int ignore, void* stream) {
+    WC_CHECK_ARG(attn_pred && cam_label && part && sums && B > 0 && h > 0 && w > 0 && H >= h && W >= w && radius >= 0,
+                 "wc_aff_loss_fwd: bad argument");
+    WC_CHECK_ARG((size_t)h * w * 4 <= 64 * 1024 && B <= 65535, "wc_aff_loss_fwd: h*w <= 16384");
+    dim3 grid(wc_cdiv(h * w, 8), B);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(aff_loss_kernel<false>, grid, dim3(256), (size_t)h * w * 4, st, attn_pred, (const long*)cam_label, part,
+                       nullptr, nullptr, h, w, H, W, radius, ignore);
+    WC_LAUNCH_CHECK("aff_loss_kernel<fwd>");
+    hipLaunchKernelGGL(seg_loss_reduce_kernel, dim3(1), dim3(256), 0, st, part, sums, (long)grid.x * grid.y);
+    WC_LAUNCH_CHECK("seg_loss_reduce_kernel");
+    return WC_OK;
+}
+
+// dap (B, hw, hw) = coef[0] on positive pairs, coef[1] on negative pairs, 0 elsewhere (coef: 2 device floats,
+// = upstream gradient * [-0.5 / (n_pos + 1), 0.5 / (n_neg + 1)]).
+extern "C" int wc_aff_loss_bwd(const int64_t* cam_label, const float* coef, float* dap, int B, int h, int w, int H, int W,
+                               int radius, int ignore, void* stream) {
+    WC_CHECK_ARG(cam_label && coef && dap && B > 0 && h > 0 && w > 0 && H >= h && W >= w && radius >= 0,
+                 "wc_aff_loss_bwd: bad argument");
+    WC_CHECK_ARG((size_t)h * w * 4 <= 64 * 1024 && B <= 65535, "wc_aff_loss_bwd: h*w <= 16384");
+    hipLaunchKernelGGL(aff_loss_kernel<true>, dim3(wc_cdiv(h * w, 8), B), dim3(256), (size_t)h * w * 4, (hipStream_t)stream,
+                       nullptr, (const long*)cam_label, nullptr, coef, dap, h, w, H, W, radius, ignore);
+    WC_LAUNCH_CHECK("aff_loss_kernel<bwd>");
+    return WC_OK;
+}

@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from .utils.camutils import cams_to_affinity_label, get_mask_by_radius
-from .utils.losses import get_aff_loss, get_seg_loss, get_seg_loss_fused
+from .utils.losses import get_aff_loss, get_aff_loss_fused, get_seg_loss, get_seg_loss_fused
 from .utils.optimizer import PolyWarmupAdamW
 
 
@@ -72,11 +72,12 @@ class TrainStep:
 
     def losses(self, seg, cam, attn_pred):
         h, w = cam.shape[1] // 16, cam.shape[2] // 16
-        aff_label = cams_to_affinity_label(cam, mask=self.mask(h, w, cam.device), ignore_index=self.ignore)
-        attn_loss, _, _ = get_aff_loss(attn_pred, aff_label)
-        if seg.is_cuda:     # up-sampling + both CE terms fused (csrc/losses.hip)
+        if seg.is_cuda:     # label->affinity-label + affinity loss, and up-sampling + both CE terms, fused (csrc/losses.hip)
+            attn_loss = get_aff_loss_fused(attn_pred, cam, radius=self.radius, ignore_index=self.ignore)
             seg_loss = get_seg_loss_fused(seg, cam, ignore_index=self.ignore)
         else:
+            aff_label = cams_to_affinity_label(cam, mask=self.mask(h, w, cam.device), ignore_index=self.ignore)
+            attn_loss, _, _ = get_aff_loss(attn_pred, aff_label)
             segs = F.interpolate(seg, size=cam.shape[1:], mode="bilinear", align_corners=False)
             seg_loss = get_seg_loss(segs, cam.long(), ignore_index=self.ignore)
         return seg_loss + 0.1 * attn_loss, seg_loss, attn_loss

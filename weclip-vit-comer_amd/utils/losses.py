@@ -63,3 +63,42 @@ class _SegLossFn(torch.autograd.Function):
 def get_seg_loss_fused(seg_lowres, label, ignore_index=255):
     """== get_seg_loss(F.interpolate(seg_lowres, label.shape[1:], 'bilinear', align_corners=False), label)."""
     return _SegLossFn.apply(seg_lowres, label, ignore_index)
+
+
+class _AffLossFn(torch.autograd.Function):
+    """get_aff_loss(attn_pred, cams_to_affinity_label(cam_label, radius mask)) in one pass (csrc/losses.hip),
+    without the (B, hw, hw) label / mask tensors."""
+
+    @staticmethod
+    def forward(ctx, attn_pred, cam_label, radius, ignore_index):
+        from .. import _lib as L
+        ap = attn_pred.float().contiguous()
+        lab = cam_label.long().contiguous()
+        B, hw, _ = ap.shape
+        H, W = lab.shape[1:]
+        h, w = H // 16, W // 16
+        if h * w != hw:
+            raise RuntimeError("attn_pred does not match the 1/16 token grid of the labels")
+        part = torch.empty(4 * B * ((hw + 7) // 8), device=ap.device, dtype=torch.float32)
+        sums = torch.empty(4, device=ap.device, dtype=torch.float32)
+        L.lib().wc_aff_loss_fwd(L.ptr(ap, torch.float32, "attn_pred"), L.ptr(lab, torch.int64, "cam_label"), L.ptr(part),
+                                L.ptr(sums), B, h, w, H, W, int(radius), int(ignore_index), L.stream())
+        ctx.save_for_backward(lab, sums)
+        ctx.meta = (B, h, w, H, W, int(radius), int(ignore_index))
+        return 0.5 * sums[0] / (sums[1] + 1) + 0.5 * sums[2] / (sums[3] + 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _lib as L
+        lab, sums = ctx.saved_tensors
+        B, h, w, H, W, radius, ignore = ctx.meta
+        coef = (g * torch.stack((-0.5 / (sums[1] + 1), 0.5 / (sums[3] + 1)))).float().contiguous()
+        dap = torch.empty(B, h * w, h * w, device=lab.device, dtype=torch.float32)
+        L.lib().wc_aff_loss_bwd(L.ptr(lab), L.ptr(coef, torch.float32, "coef"), L.ptr(dap), B, h, w, H, W, radius, ignore,
+                                L.stream())
+        return dap, None, None, None
+
+
+def get_aff_loss_fused(attn_pred, cam_label, radius=8, ignore_index=255):
+    """== get_aff_loss(attn_pred, cams_to_affinity_label(cam_label, get_mask_by_radius(h, w, radius)))[0]."""
+    return _AffLossFn.apply(attn_pred, cam_label, radius, ignore_index)
