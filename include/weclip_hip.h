@@ -137,6 +137,11 @@ int wc_gemm_km_f16(const void* dY, long lda, const void* X, long ldx, const void
  * (clip/model.py:457-478 convert_weights; clip/myAtt.py:321). */
 int wc_split_f16(const float* x, void* hi, void* lo, long n, void* stream);
 
+/* Many fp32 weight matrices -> fp16 operands in one launch: row-major hi[,lo] (R,C) and transposed hiT[,loT]
+ * (C, ldT >= R; padding columns are left untouched -- keep them zero).  table (device): count rows of 8 int64
+ * {src, hi, lo|0, hiT|0, loT|0, R, C, ldT}.  Replaces the per-layer `.half()` / `.t()` of the trainable weights. */
+int wc_convert_weights(const int64_t* table, int count, int blocks_per_tensor, void* stream);
+
 /* ---- LayerNorm ------------------------------------------------------------------------ */
 /* clip/model.py:177-183 (`LayerNorm.forward`, fp32 math).  x (rows, D) f32 with row stride ldx;
  * outputs (each optional): y32 f32, y16 fp16 hi, y16lo fp16 residual; all dense (rows, D). */

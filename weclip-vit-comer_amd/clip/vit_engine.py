@@ -16,8 +16,11 @@ from ..ops import F16, F32, Split
 class BlockPack:
     """fp16 MFMA operands + fp32 vectors of one residual attention block."""
 
-    def __init__(self, blk, exact=None):
+    def __init__(self, blk, exact=None, pre=None):
+        """pre: optional dict of ready fp16 operands (in_w, out_w, fc_w, pj_w) -- the trainable decoder converts
+        all its weights in one launch per step (ops.WeightCache)."""
         exact = config.exact() if exact is None else exact
+        pre = pre or {}
         at = blk.attn
         self.E = at.embed_dim
         self.H = at.num_heads
@@ -26,14 +29,14 @@ class BlockPack:
         f = lambda p: p.detach().float().contiguous()
         self.ln1_w, self.ln1_b = f(blk.ln_1.weight), f(blk.ln_1.bias)
         self.ln2_w, self.ln2_b = f(blk.ln_2.weight), f(blk.ln_2.bias)
-        self.in_w = ops.split_f16(at.in_proj_weight, with_lo=exact)
+        self.in_w = pre.get("in_w") or ops.split_f16(at.in_proj_weight, with_lo=exact)
         self.in_b = f(at.in_proj_bias)
         # reference forces this GEMM to fp16 on every device (myAtt.py:321)
-        self.out_w = ops.split_f16(at.out_proj.weight, with_lo=False)
+        self.out_w = pre.get("out_w") or ops.split_f16(at.out_proj.weight, with_lo=False)
         self.out_b = f(at.out_proj.bias).half().float()
-        self.fc_w = ops.split_f16(blk.mlp.c_fc.weight, with_lo=exact and blk.fp32_mlp)
+        self.fc_w = pre.get("fc_w") or ops.split_f16(blk.mlp.c_fc.weight, with_lo=exact and blk.fp32_mlp)
         self.fc_b = f(blk.mlp.c_fc.bias)
-        self.pj_w = ops.split_f16(blk.mlp.c_proj.weight, with_lo=exact and blk.fp32_mlp)
+        self.pj_w = pre.get("pj_w") or ops.split_f16(blk.mlp.c_proj.weight, with_lo=exact and blk.fp32_mlp)
         self.pj_b = f(blk.mlp.c_proj.bias)
 
 

@@ -254,3 +254,55 @@ extern "C" int wc_colscale_split(const float* x, const float* cs, float* out32, 
     WC_LAUNCH_CHECK("colscale_split_kernel");
     return WC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// All trainable weight matrices of the head -> fp16 MFMA operands in ONE launch per step: row-major (the
+// forward's W, K-contiguous) and transposed (the backward's W^T for dX = dY W).  Replaces the per-layer
+// `.half()` / `.t().contiguous()` conversions (reference: implicit in F.linear and its autograd).
+// table: count rows of 8 int64 = {src f32 (R,C), hi (R,C), lo or 0, hiT (C,ldT), loT or 0, R, C, ldT}.
+__global__ __launch_bounds__(256) void convert_weights_kernel(const long* __restrict__ table, int count) {
+    __shared__ float tile[64][65];
+    const long* e = table + (long)blockIdx.y * 8;
+    const float* src = reinterpret_cast<const float*>(e[0]);
+    __half* hi = reinterpret_cast<__half*>(e[1]);
+    __half* lo = reinterpret_cast<__half*>(e[2]);
+    __half* hiT = reinterpret_cast<__half*>(e[3]);
+    __half* loT = reinterpret_cast<__half*>(e[4]);
+    const int R = (int)e[5], C = (int)e[6];
+    const long ldT = e[7];
+    const int tc = (C + 63) / 64, tr = (R + 63) / 64;
+    for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+        const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+        for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+            const int r = i >> 6, c = i & 63;
+            float v = 0.f;
+            if (r0 + r < R && c0 + c < C) {
+                v = src[(long)(r0 + r) * C + c0 + c];
+                const __half h = __float2half(v);
+                hi[(long)(r0 + r) * C + c0 + c] = h;
+                if (lo) lo[(long)(r0 + r) * C + c0 + c] = __float2half(v - __half2float(h));
+            }
+            tile[r][c] = v;
+        }
+        __syncthreads();
+        if (hiT)
+            for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+                const int c = i >> 6, r = i & 63;
+                if (c0 + c < C && r0 + r < R) {
+                    const float v = tile[r][c];
+                    const __half h = __float2half(v);
+                    hiT[(long)(c0 + c) * ldT + r0 + r] = h;
+                    if (loT) loT[(long)(c0 + c) * ldT + r0 + r] = __float2half(v - __half2float(h));
+                }
+            }
+        __syncthreads();
+    }
+}
+
+extern "C" int wc_convert_weights(const int64_t* table, int count, int blocks_per_tensor, void* stream) {
+    WC_CHECK_ARG(table && count > 0 && count <= 65535 && blocks_per_tensor > 0, "wc_convert_weights: bad argument");
+    hipLaunchKernelGGL(convert_weights_kernel, dim3(blocks_per_tensor, count), dim3(256), 0, (hipStream_t)stream,
+                       (const long*)table, count);
+    WC_LAUNCH_CHECK("convert_weights_kernel");
+    return WC_OK;
+}

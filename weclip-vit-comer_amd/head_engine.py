@@ -28,11 +28,6 @@ def _f(p):
     return p.detach().float().contiguous()
 
 
-def _wT(w, with_lo):
-    """fp16 operand of W^T (K-contiguous for dX = dY W)."""
-    return ops.split_f16(w.detach().float().t().contiguous(), with_lo=with_lo)
-
-
 class HeadEngine:
     def __init__(self, fuse, dec):
         self.fuse, self.dec = fuse, dec
@@ -42,6 +37,7 @@ class HeadEngine:
         # name -> fp32 buffer the gradient of that parameter is written INTO (not accumulated) by backward();
         # set by TrainStep to views of its flat all-reduce bucket so no per-parameter copy/add kernels run
         self.direct_grads = None
+        self.wcache = ops.WeightCache()     # fp16 (row-major + transposed) copies of every weight matrix, one launch per step
 
     def params(self):
         return list(self.fuse.parameters()) + list(self.dec.parameters())
@@ -49,6 +45,18 @@ class HeadEngine:
     def param_names(self):
         return ["fuse." + n for n, _ in self.fuse.named_parameters()] + \
                ["dec." + n for n, _ in self.dec.named_parameters()]
+
+    def _weight_matrices(self):
+        out = []
+        for l, mlp in enumerate(self.fuse.linears_modulelist):
+            out.append((f"ad{l}.proj", mlp.proj.weight.detach()))
+            out.append((f"ad{l}.proj_2", mlp.proj_2.weight.detach()))
+        out.append(("fuse", self.fuse.linear_fuse.weight.detach().flatten(1)))
+        out.append(("pred", self.dec.linear_pred.weight.detach().flatten(1)))
+        for i, blk in enumerate(self.dec.transformer.resblocks):
+            out += [(f"b{i}.in", blk.attn.in_proj_weight.detach()), (f"b{i}.out", blk.attn.out_proj.weight.detach()),
+                    (f"b{i}.fc", blk.mlp.c_fc.weight.detach()), (f"b{i}.pj", blk.mlp.c_proj.weight.detach())]
+        return [(n, t if t.dtype == F32 and t.is_contiguous() else t.float().contiguous()) for n, t in out]
 
     # ------------------------------------------------------------------------------ forward
     def forward(self, xs, B, Lq, h, w, drop_scale=None):
@@ -60,37 +68,40 @@ class HeadEngine:
         dev = xs[0].hi.device
         n = self.index
         ctx = dict(B=B, L=Lq, h=h, w=w, xs=xs, drop=drop_scale, ex=ex)
+        wc = self.wcache
+        wc.refresh(self._weight_matrices(), ex)
         # adapters: t1 = relu(X W1^T + b1); cat[:, l] = t1 W2^T + b2
         cat = Split(torch.empty(M, n * E, device=dev, dtype=F16), torch.empty(M, n * E, device=dev, dtype=F16) if ex else None)
         t1s = []
         for l, mlp in enumerate(self.fuse.linears_modulelist):
             a = Split(xs[l].hi.view(-1)[C:], xs[l].lo.view(-1)[C:] if (ex and xs[l].lo is not None) else None)
             t1 = Split(torch.empty(M, E, device=dev, dtype=F16), torch.empty(M, E, device=dev, dtype=F16) if ex else None)
-            ops.gemm(a, ops.split_f16(mlp.proj.weight, ex), hw, E, C, bias=_f(mlp.proj.bias), out16=t1.hi, out16lo=t1.lo,
+            ops.gemm(a, wc.w(f"ad{l}.proj"), hw, E, C, bias=_f(mlp.proj.bias), out16=t1.hi, out16lo=t1.lo,
                      act=2, batch=B, sA=Lq * C, sW=0, sC=hw * E)
-            ops.gemm(t1, ops.split_f16(mlp.proj_2.weight, ex), M, E, E, bias=_f(mlp.proj_2.bias),
+            ops.gemm(t1, wc.w(f"ad{l}.proj_2"), M, E, E, bias=_f(mlp.proj_2.bias),
                      out16=cat.hi.view(-1)[l * E:], out16lo=cat.lo.view(-1)[l * E:] if ex else None, ldc=n * E)
             t1s.append(t1)
         # fuse (1x1 conv) + Dropout2d
         F32_ = torch.empty(M, E, device=dev, dtype=F32)
         Fh = Split(torch.empty(M, E, device=dev, dtype=F16), torch.empty(M, E, device=dev, dtype=F16) if ex else None)
-        wf = ops.split_f16(self.fuse.linear_fuse.weight.detach().flatten(1), ex)
+        wf = wc.w("fuse")
         ops.gemm(cat, wf, hw, E, n * E, bias=_f(self.fuse.linear_fuse.bias), out32=F32_, out16=Fh.hi, out16lo=Fh.lo,
                  batch=B, sA=hw * n * E, sW=0, sC=hw * E, cscale=drop_scale, sCS=E)
         ctx.update(cat=cat, t1s=t1s, F32=F32_, Fh=Fh)
         # decoder blocks
         x = F32_
         blocks = []
-        for blk in self.dec.transformer.resblocks:
-            pk = VE.BlockPack(blk, exact=ex)
+        for i, blk in enumerate(self.dec.transformer.resblocks):
+            pk = VE.BlockPack(blk, exact=ex, pre=dict(in_w=wc.w(f"b{i}.in"), out_w=Split(wc.w(f"b{i}.out").hi, None),
+                                                      fc_w=wc.w(f"b{i}.fc"), pj_w=wc.w(f"b{i}.pj")))
             x, bc = self._block_fwd(pk, x, B, hw)
-            bc["pk"], bc["blk"] = pk, blk
+            bc["pk"], bc["blk"], bc["i"] = pk, blk, i
             blocks.append(bc)
         ctx["blocks"] = blocks
         # linear_pred (1x1 conv) on the fp16 copy of the last block output
         x3 = blocks[-1]["x2h"]
         seg_rows = torch.empty(M, self.nc, device=dev, dtype=F32)
-        ops.gemm(x3, ops.split_f16(self.dec.linear_pred.weight.detach().flatten(1), ex), M, self.nc, E,
+        ops.gemm(x3, wc.w("pred"), M, self.nc, E,
                  bias=_f(self.dec.linear_pred.bias), out32=seg_rows)
         seg = seg_rows.view(B, h, w, self.nc).permute(0, 3, 1, 2).contiguous()
         # attn_pred = sigmoid(F^T F) per image
@@ -133,10 +144,9 @@ class HeadEngine:
             d = torch.zeros(M, 64, device=dev, dtype=F32)
             d[:, :nc] = dseg.permute(0, 2, 3, 1).reshape(M, nc)
             _, dS = ops.colscale_split(d, None, M, alpha=GS, want32=False, with_lo=ex)
-            wpT = torch.zeros(E, 64, device=dev, dtype=F32)
-            wpT[:, :nc] = self.dec.linear_pred.weight.detach().flatten(1).t()
+            wpT, ldT = self.wcache.wT("pred")          # (E, 64): the nc class columns, zero padded
             dx = torch.empty(M, E, device=dev, dtype=F32)
-            ops.gemm(dS, ops.split_f16(wpT, ex), M, E, 64, out32=dx)
+            ops.gemm(dS, wpT, M, E, ldT, out32=dx)
             wg(dS.hi, x3h.hi, nc, E, "dec.linear_pred.weight", "dec.linear_pred.bias", lda=64)
         else:
             dx = torch.zeros(M, E, device=dev, dtype=F32)
@@ -158,7 +168,7 @@ class HeadEngine:
         _, dFp = ops.colscale_split(dF, ctx["drop"], hw, want32=False, with_lo=ex)
         cat = ctx["cat"]
         dcat = Split(torch.empty(M, n * E, device=dev, dtype=F16), torch.empty(M, n * E, device=dev, dtype=F16) if ex else None)
-        ops.gemm(dFp, _wT(self.fuse.linear_fuse.weight.detach().flatten(1), ex), M, n * E, E, out16=dcat.hi, out16lo=dcat.lo)
+        ops.gemm(dFp, self.wcache.wT("fuse")[0], M, n * E, E, out16=dcat.hi, out16lo=dcat.lo)
         wg(dFp.hi, cat.hi, E, n * E, "fuse.linear_fuse.weight", "fuse.linear_fuse.bias")
         # ---- adapters
         xs, Lq = ctx["xs"], ctx["L"]
@@ -168,7 +178,7 @@ class HeadEngine:
             dt2 = Split(dcat.hi.view(-1)[l * E:], dcat.lo.view(-1)[l * E:] if ex else None)
             t1 = ctx["t1s"][l]
             dt1_16 = torch.empty(M, E, device=dev, dtype=F16)
-            ops.gemm(dt2, _wT(mlp.proj_2.weight, ex), M, E, E, lda=n * E, out16=dt1_16, act=5, auxh=t1.hi, ldaux=E)
+            ops.gemm(dt2, self.wcache.wT(f"ad{l}.proj_2")[0], M, E, E, lda=n * E, out16=dt1_16, act=5, auxh=t1.hi, ldaux=E)
             wg(dt2.hi, t1.hi, E, E, p + "proj_2.weight", p + "proj_2.bias", lda=n * E)
             # X = the hw patch rows of every image of the (B, 1 + hw, C) encoder tokens (CLS rows skipped)
             wg(dt1_16, xs[l].hi, E, C, p + "proj.weight", p + "proj.bias", xmap=(hw, Lq, 1))
@@ -206,22 +216,23 @@ class HeadEngine:
         # MLP
         _, dx2s = ops.colscale_split(dx2, None, M, want32=False, with_lo=ex)
         du = Split(torch.empty(M, 4 * E, device=dev, dtype=F16), torch.empty(M, 4 * E, device=dev, dtype=F16) if ex else None)
-        ops.gemm(dx2s, _wT(blk.mlp.c_proj.weight, ex), M, 4 * E, E, out16=du.hi, out16lo=du.lo, act=4, aux=c["u32"],
+        wT = lambda k: self.wcache.wT(f"b{c['i']}.{k}")[0]
+        ops.gemm(dx2s, wT("pj"), M, 4 * E, E, out16=du.hi, out16lo=du.lo, act=4, aux=c["u32"],
                  ldaux=4 * E, rpg=1)
         wg(dx2s.hi, c["z"].hi, E, 4 * E, prefix + "mlp.c_proj.weight", prefix + "mlp.c_proj.bias")
         da2 = torch.empty(M, E, device=dev, dtype=F32)
-        ops.gemm(du, _wT(blk.mlp.c_fc.weight, ex), M, E, 4 * E, out32=da2)
+        ops.gemm(du, wT("fc"), M, E, 4 * E, out32=da2)
         wg(du.hi, c["a2"].hi, 4 * E, E, prefix + "mlp.c_fc.weight", prefix + "mlp.c_fc.bias")
         dx1, g16, dgb2 = ops.layernorm_bwd(da2, c["x1"], pk.ln2_w, add=dx2, want32=True, want16=True, alpha=inv)
         grads[prefix + "ln_2.weight"], grads[prefix + "ln_2.bias"] = dgb2[0], dgb2[1]
         # forced-fp16 out-projection (clip/myAtt.py:321): gradient rounded to fp16 on both sides
         do16 = torch.empty(M, E, device=dev, dtype=F16)
-        ops.gemm(g16, _wT(blk.attn.out_proj.weight, False), M, E, E, out16=do16)
+        ops.gemm(g16, Split(wT("out").hi, None), M, E, E, out16=do16)
         wg(g16, c["o16"], E, E, prefix + "attn.out_proj.weight", prefix + "attn.out_proj.bias")
         # attention + in-projection
         dqkv = ops.attention_bwd(c["qkv"], do16, c["o32"], c["lse"], B, Lq, H, DH, with_lo=ex)
         da = torch.empty(M, E, device=dev, dtype=F32)
-        ops.gemm(dqkv, _wT(blk.attn.in_proj_weight, ex), M, E, 3 * E, out32=da)
+        ops.gemm(dqkv, wT("in"), M, E, 3 * E, out32=da)
         wg(dqkv.hi, c["a"].hi, 3 * E, E, prefix + "attn.in_proj_weight", prefix + "attn.in_proj_bias")
         dx, _, dgb1 = ops.layernorm_bwd(da, c["x"], pk.ln1_w, add=dx1, want32=True, alpha=inv)
         grads[prefix + "ln_1.weight"], grads[prefix + "ln_1.bias"] = dgb1[0], dgb1[1]

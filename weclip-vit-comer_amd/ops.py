@@ -259,3 +259,53 @@ def colscale_split(x, cs, rows_per_batch, want32=True, with_lo=True, alpha=1.0):
     L.lib().wc_colscale_split(L.ptr(x, F32, "x"), L.ptr(cs, F32, "cs"), L.ptr(out32), L.ptr(s.hi), L.ptr(s.lo), rows, C,
                               rows_per_batch, float(alpha), L.stream())
     return out32, s
+
+
+class WeightCache:
+    """fp16 MFMA operands (row-major and transposed, hi[+lo]) of a set of fp32 weight matrices, refreshed by ONE
+    kernel launch when any of them changed (`Tensor._version`, bumped by the optimizer's in-place update)."""
+
+    def __init__(self):
+        self.key = None
+        self.versions = None
+        self.views = {}
+
+    def refresh(self, named, exact):
+        """named: list of (name, 2-D contiguous fp32 CUDA tensor)."""
+        L.require_gpu()
+        key = tuple((n, t.data_ptr(), tuple(t.shape)) for n, t in named) + (bool(exact),)
+        if key != self.key:
+            dev = named[0][1].device
+            tot = sum(t.numel() for _, t in named)
+            totT = sum(t.shape[1] * ((t.shape[0] + 63) // 64 * 64) for _, t in named)
+            self.hi = torch.empty(tot, device=dev, dtype=F16)
+            self.lo = torch.empty(tot, device=dev, dtype=F16) if exact else None
+            self.hiT = torch.zeros(totT, device=dev, dtype=F16)          # K padding of the transposed copies stays 0
+            self.loT = torch.zeros(totT, device=dev, dtype=F16) if exact else None
+            rows, self.views, o, oT = [], {}, 0, 0
+            for n, t in named:
+                R, C = t.shape
+                ldT = (R + 63) // 64 * 64
+                hi, hiT = self.hi[o:o + R * C].view(R, C), self.hiT[oT:oT + C * ldT].view(C, ldT)
+                lo = self.lo[o:o + R * C].view(R, C) if exact else None
+                loT = self.loT[oT:oT + C * ldT].view(C, ldT) if exact else None
+                rows.append([t.data_ptr(), hi.data_ptr(), lo.data_ptr() if exact else 0, hiT.data_ptr(),
+                             loT.data_ptr() if exact else 0, R, C, ldT])
+                self.views[n] = (Split(hi, lo), Split(hiT, loT), ldT)
+                o += R * C
+                oT += C * ldT
+            self.table = torch.tensor(rows, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
+            self.count = len(rows)
+            self.key, self.versions = key, None
+        versions = tuple(t._version for _, t in named)
+        if versions != self.versions:
+            L.lib().wc_convert_weights(L.ptr(self.table, torch.int64, "table"), self.count, 32, L.stream())
+            self.versions = versions
+
+    def w(self, name):
+        """Split (R, C): the forward's W operand (K = C contiguous)."""
+        return self.views[name][0]
+
+    def wT(self, name):
+        """(Split (C, ldT), ldT): the backward's W^T operand (K = R contiguous, zero padded to ldT)."""
+        return self.views[name][1], self.views[name][2]
