@@ -1,0 +1,103 @@
+"""Size-independent properties at BASELINE's full size (ViT-B/16, 512x512, 1025 tokens), where the CPU oracle is too
+slow to be the checker: row-stochastic attention, fast vs exact precision agreement, PAR's linear-operator
+identities on 512x512 images, determinism and finiteness of a whole training step."""
+import pytest
+import torch
+
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vitb():
+    from weclip_vit_comer_amd import clip
+    sd = synth.make_clip_state_dict(seed=0, with_text=False)
+    model, _ = clip.load(sd, device="cuda")
+    return model
+
+
+def test_head_mean_attention_rows_sum_to_one_at_1025_tokens(vitb):
+    img = synth.make_images(2, 512, 512, seed=11).cuda()
+    fts, attns = vitb.encode_image(img, 512, 512, require_all_fts=True)
+    assert len(fts) == 11 and fts[-1].shape[0] == 1025
+    for a in attns[-3:]:
+        assert tuple(a.shape) == (2, 1025, 1025)
+        s = a.sum(-1)
+        assert (s - 1).abs().max().item() < 2e-3          # P rows of every head sum to 1 (fp16 operands, fp32 softmax)
+        assert a.min().item() >= 0
+    assert all(torch.isfinite(f).all().item() for f in fts)
+
+
+def test_fast_and_exact_precision_agree_at_full_size(vitb):
+    """CAM logits of the two precision modes within the north-star tolerance of each other (1e-3 relative)."""
+    from weclip_vit_comer_amd import config
+    from weclip_vit_comer_amd.pytorch_grad_cam import GradCAM
+    img = synth.make_images(1, 512, 512, seed=12).cuda()
+    bg, fg = synth.make_text_features(20, 25, 512)
+    text = torch.cat([fg[[0, 1]], bg], 0).cuda()
+
+    class T:
+        category = 0
+
+    res = {}
+    for mode in ("fast", "exact"):
+        config.precision = mode
+        try:
+            from weclip_vit_comer_amd import clip
+            model, _ = clip.load(synth.make_clip_state_dict(seed=0, with_text=False), device="cuda")
+            fts, _ = model.encode_image(img, 512, 512, require_all_fts=True)
+            cam = GradCAM(model=model, target_layers=[model.visual.transformer.resblocks[-1].ln_1])
+            g, p, a = cam(input_tensor=[fts[-1], text, 512, 512], targets=[T()])
+            res[mode] = (torch.as_tensor(g[0]), p.float().cpu())
+        finally:
+            config.precision = "fast"
+    pf, pe = res["fast"][1], res["exact"][1]
+    rel = ((pf - pe).abs() / pe.abs().clamp_min(1e-6)).max().item()
+    cam_err = (res["fast"][0] - res["exact"][0]).abs().max().item()
+    print(f"512^2 fast vs exact: CAM-logit rel {rel:.2e}, CAM map abs {cam_err:.2e}")
+    assert rel < 1e-3 and cam_err < 2e-2
+
+
+def test_par_operator_identities_at_512():
+    """PAR is a linear operator with row sums 1.01 (softmax + 0.01 * positional softmax): constants scale by
+    1.01^20, superposition holds, and the label map is invariant under a positive rescaling of the masks."""
+    from weclip_vit_comer_amd.WeCLIP_model.PAR import PAR
+    par = PAR([1, 2, 4, 8, 12, 24], 20).cuda()
+    g = torch.Generator().manual_seed(5)
+    img = synth.make_images(2, 512, 512, seed=13).cuda()
+    a = torch.rand(2, 3, 512, 512, generator=g).cuda()
+    b = torch.rand(2, 3, 512, 512, generator=g).cuda()
+    ones = torch.ones(2, 3, 512, 512, device="cuda")
+    assert (par(img, ones) - 1.01 ** 20).abs().max().item() < 2e-4
+    lin = par(img, 2.0 * a + 0.5 * b) - (2.0 * par(img, a) + 0.5 * par(img, b))
+    assert lin.abs().max().item() < 2e-4
+    assert torch.equal(par(img, a).argmax(1), par(img, 4.0 * a).argmax(1))
+
+
+def test_training_step_is_deterministic_and_finite_at_512():
+    from weclip_vit_comer_amd.WeCLIP_model.model_attn_aff_voc import WeCLIP
+    from weclip_vit_comer_amd.train_step import TrainStep
+    img = synth.make_images(2, 512, 512, seed=14).cuda()
+    labels = synth.make_label_lists(2, 2, seed=3)
+
+    def run():
+        torch.manual_seed(0)
+        sd = synth.make_clip_state_dict(seed=0, with_text=False)
+        bg, fg = synth.make_text_features(20, 25, 512)
+        fuse, dec = synth.make_head_state_dicts()
+        m = WeCLIP(num_classes=21, clip_model=sd, embedding_dim=256, in_channels=[768] * 4, dataset_root_path=None,
+                   device="cuda", text_features=(bg.cuda(), fg.cuda()))
+        m.decoder_fts_fuse.load_state_dict(fuse)
+        m.decoder.load_state_dict(dec)
+        m.train()
+        step = TrainStep(m)
+        torch.manual_seed(1)
+        out = [step(img, labels=labels)[0].item() for _ in range(2)]
+        return out, step.bucket.flat.clone()
+
+    l0, g0 = run()
+    l1, g1 = run()
+    assert all(map(lambda v: v == v and abs(v) < 1e4, l0))        # finite
+    assert l0 == l1 and torch.equal(g0, g1)                       # no atomics / races anywhere in the step
+    assert g0.abs().max().item() > 0
