@@ -69,7 +69,7 @@ class HeadEngine:
         n = self.index
         ctx = dict(B=B, L=Lq, h=h, w=w, xs=xs, drop=drop_scale, ex=ex)
         wc = self.wcache
-        wc.refresh(self._weight_matrices(), ex)
+        wc.refresh(self._weight_matrices(), ex, force=self.fuse.training or self.dec.training)
         # adapters: t1 = relu(X W1^T + b1); cat[:, l] = t1 W2^T + b2
         cat = Split(torch.empty(M, n * E, device=dev, dtype=F16), torch.empty(M, n * E, device=dev, dtype=F16) if ex else None)
         t1s = []

@@ -270,8 +270,9 @@ class WeightCache:
         self.versions = None
         self.views = {}
 
-    def refresh(self, named, exact):
-        """named: list of (name, 2-D contiguous fp32 CUDA tensor)."""
+    def refresh(self, named, exact, force=False):
+        """named: list of (name, 2-D contiguous fp32 CUDA tensor).  force: convert even if no version counter moved
+        (training: an update through `param.data` does not bump `param._version`)."""
         L.require_gpu()
         key = tuple((n, t.data_ptr(), tuple(t.shape)) for n, t in named) + (bool(exact),)
         if key != self.key:
@@ -298,7 +299,7 @@ class WeightCache:
             self.count = len(rows)
             self.key, self.versions = key, None
         versions = tuple(t._version for _, t in named)
-        if versions != self.versions:
+        if force or versions != self.versions:
             L.lib().wc_convert_weights(L.ptr(self.table, torch.int64, "table"), self.count, 32, L.stream())
             self.versions = versions
 
