@@ -53,7 +53,6 @@ struct GemmArgs {
     const float* cscale;  // optional per-batch column scale after bias: v *= cscale[z*sCS + n] (Dropout2d)
     long sCS;
     int gx, gy;           // tile grid (N tiles, M tiles); the launch is 1-D over gx * roundup8(gy)
-    int dbg;              // WECLIP_GEMM_DBG experiment bits (0 in production)
     int vec;              // outputs / residual are 16-byte addressable per 4 columns: LDS-transposed wide epilogue
 };
 
@@ -586,7 +585,6 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
 #undef PP_STAGE
     if (wr == 0) __builtin_amdgcn_s_barrier();       // re-align the two row groups
     __syncthreads();                                 // every wave is done with the operand slots: epilogue scratch
-    if (g.dbg & 1) return;
     gemm_epilogue<AUX>(g, acc[0], m0 + wr * 128, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc);
     gemm_epilogue<AUX>(g, acc[1], m0 + wr * 128 + 64, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc);
 }
@@ -768,7 +766,7 @@ extern "C" int wc_gemm_km_f16(const void* dY, long lda, const void* X, long ldx,
     e.sC = (long)N * K1; e.sR = 0; e.bias = nullptr; e.resid = nullptr; e.ldr = 0;
     e.C32 = part; e.C16 = nullptr; e.C16lo = nullptr; e.ldc = K1; e.act = 0; e.round16 = 0; e.scale = 1.f; e.scale_cols = 0;
     e.P32 = nullptr; e.aux = nullptr; e.rowmap = nullptr; e.rpg = 1; e.ldaux = 0; e.auxh = nullptr; e.cscale = nullptr;
-    e.sCS = 0; e.gx = g.gx; e.gy = wc_cdiv(N, 128); e.dbg = 0; e.vec = 0;
+    e.sCS = 0; e.gx = g.gx; e.gy = wc_cdiv(N, 128); e.vec = 0;
     dim3 grid((unsigned)(g.gx * wc_cdiv(N, 128)), 1, ns);
     hipLaunchKernelGGL(gemm_km_kernel, grid, dim3(256), 4 * 64 * 256, (hipStream_t)stream, g);
     WC_LAUNCH_CHECK("gemm_km_kernel");
@@ -873,8 +871,6 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
              (act != 4 || (ldaux % 4 == 0 && (uintptr_t)aux % 16 == 0)))
                 ? 1 : 0;
     g.gx = wc_cdiv(N, BN);
-    static const int dbg = getenv("WECLIP_GEMM_DBG") ? atoi(getenv("WECLIP_GEMM_DBG")) : 0;
-    g.dbg = dbg;
     const int plan = gemm_plan(M, N, K, nseg, batch, act == 4 && rowmap);
     if (plan) {   // tall GEMM: 256x256 ping-pong kernel
         g.gx = wc_cdiv(N, 256);

@@ -206,65 +206,6 @@ __global__ __launch_bounds__(256) void par_iter_kernel(const float* __restrict__
     }
 }
 
-// Wide variant (W % 4 == 0): one thread = 4 consecutive pixels, so the aff stream is read as aligned
-// 16-B vectors (1 KiB per wave-instruction) and each neighbour gather is one dword-aligned dwordx4 load
-// (global memory only needs dword alignment); pixels whose tap crosses the left/right border fall back
-// to per-element clamped loads.  4x fewer memory instructions than par_iter_kernel for the same bytes.
-struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
-
-template <int CG>
-__global__ __launch_bounds__(256) void par_iter4_kernel(const float* __restrict__ aff, const float* __restrict__ min,
-                                                         float* __restrict__ mout, int C, int H, int W, ParTaps taps) {
-    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x0 >= W || y >= H) return;
-    const long HW = (long)H * W;
-    const long p = (long)y * W + x0;
-    const int T = taps.n;
-    const float* A = aff + (long)blockIdx.z * T * HW + p;
-    const float* M = min + (long)blockIdx.z * C * HW;
-    float* O = mout + (long)blockIdx.z * C * HW + p;
-    for (int cb = 0; cb < C; cb += CG) {
-        float acc[CG][4];
-        const float* Mc[CG];
-#pragma unroll
-        for (int k = 0; k < CG; ++k) {
-            acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.f;
-            Mc[k] = M + (long)(cb + k < C ? cb + k : C - 1) * HW;
-        }
-        for (int t = 0; t < T; ++t) {
-            const float4 a = *reinterpret_cast<const float4*>(A + (long)t * HW);
-            const long rowo = (long)clampi(y + taps.dy[t], H - 1) * W;
-            const int xs = x0 + taps.dx[t];
-            if (xs >= 0 && xs + 3 <= W - 1) {
-#pragma unroll
-                for (int k = 0; k < CG; ++k) {
-                    const f4u m = *reinterpret_cast<const f4u*>(Mc[k] + rowo + xs);
-                    acc[k][0] = fmaf(a.x, m.x, acc[k][0]);
-                    acc[k][1] = fmaf(a.y, m.y, acc[k][1]);
-                    acc[k][2] = fmaf(a.z, m.z, acc[k][2]);
-                    acc[k][3] = fmaf(a.w, m.w, acc[k][3]);
-                }
-            } else {
-                const int c0 = clampi(xs, W - 1), c1 = clampi(xs + 1, W - 1), c2 = clampi(xs + 2, W - 1),
-                          c3 = clampi(xs + 3, W - 1);
-#pragma unroll
-                for (int k = 0; k < CG; ++k) {
-                    const float* r = Mc[k] + rowo;
-                    acc[k][0] = fmaf(a.x, r[c0], acc[k][0]);
-                    acc[k][1] = fmaf(a.y, r[c1], acc[k][1]);
-                    acc[k][2] = fmaf(a.z, r[c2], acc[k][2]);
-                    acc[k][3] = fmaf(a.w, r[c3], acc[k][3]);
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < CG; ++k)
-            if (cb + k < C)
-                *reinterpret_cast<float4*>(O + (long)(cb + k) * HW) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
-    }
-}
-
 // labels[b,y,x] = valid_key[b, argmax_c masks[b,c,y,x]] over the first nch[b] channels
 // (first maximum wins like torch.argmax).  model_attn_aff_voc.py:49-57.
 __global__ __launch_bounds__(256) void par_labels_kernel(const float* __restrict__ masks,
@@ -328,18 +269,6 @@ extern "C" int wc_par_affinity(const float* img, float* aff, int B, int H, int W
 
 static int launch_iter(const float* aff, const float* src, float* dst, int B, int C, int H, int W,
                        const ParTaps& tp, hipStream_t st, bool tiled) {
-    static const bool wide = getenv("WECLIP_PAR_WIDE") != nullptr;   // experiment: slower than the scalar kernel
-    if (wide && W % 4 == 0 && (((uintptr_t)aff | (uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
-        dim3 g4(wc_cdiv(W, 256), wc_cdiv(H, 4), B);
-        if (C <= 2)
-            hipLaunchKernelGGL(par_iter4_kernel<2>, g4, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
-        else if (C == 3)
-            hipLaunchKernelGGL(par_iter4_kernel<3>, g4, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
-        else
-            hipLaunchKernelGGL(par_iter4_kernel<4>, g4, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
-        WC_LAUNCH_CHECK("par_iter4_kernel");
-        return WC_OK;
-    }
     dim3 grid(wc_cdiv(W, 64), wc_cdiv(H, 4), B);
 #define PAR_ITER_LAUNCH(CG_) \
     if (tiled) hipLaunchKernelGGL((par_iter_kernel<CG_, true>), grid, dim3(256), 0, st, aff, src, dst, C, H, W, tp); \
