@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--classes-per-image", type=int, default=2)
     ap.add_argument("--precision", default=None, choices=[None, "fast", "exact"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timer-stride", type=int, default=7,
+                    help="HIP-event pair around 1 of every n instrumented kernel launches (0: none, roofline = null)")
     ap.add_argument("--cpu-images", type=int, default=2, help="images in the bounded CPU-oracle sample")
     return ap.parse_args()
 
@@ -102,8 +104,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    ops.KernelTimer.enabled = True
-    ops.KernelTimer.reset()
+    ops.KernelTimer.enable(args.timer_stride)       # HIP-event pair around every launch of the dominant kernels (csrc/core.hip)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -113,7 +114,6 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    ops.KernelTimer.enabled = False
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -124,31 +124,30 @@ def main():
         return
 
     summ = ops.KernelTimer.summary()
-    peaks = {"gemm_f16_kernel": ("mfma", 2500.0, "TFLOP/s"), "gemm_f16_pp_kernel": ("mfma", 2500.0, "TFLOP/s"),
-             "gemm_f16_pp_kernel+tail": ("mfma", 2500.0, "TFLOP/s"), "gemm_km_kernel": ("mfma", 2500.0, "TFLOP/s"),
-             "attn_fwd_kernel": ("mfma", 2500.0, "TFLOP/s"),
-             "attn_mean_kernel": ("mfma", 2500.0, "TFLOP/s"), "par_iter_kernel": ("hbm", 8000.0, "GB/s")}
+    ops.KernelTimer.enable(0)
+    stride = max(args.timer_stride, 1)
+    # peaks from guides/MI355X_MICROARCH.md: dense fp16 MFMA 2.5 PFLOP/s, HBM3E 8 TB/s
+    def peak_of(name):
+        return ("hbm", 8000.0, "GB/s") if name.startswith("par_") else ("mfma", 2500.0, "TFLOP/s")
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
-    # (tools/pmc_traffic.py -> profiles/r01_traffic.json; 2*FETCH_SIZE + WRITE_SIZE, KiB, per the MI355X guide)
+    # (tools/refresh_profiles.sh + tools/pmc_traffic.py -> profiles/r01_traffic.json; 2*FETCH_SIZE + WRITE_SIZE, KiB,
+    # per the MI355X guide); keyed by the same kernel names
     traffic = {}
     tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
     if os.path.exists(tpath) and B == 16 and S == 512 and K == 2:
-        t = json.load(open(tpath))
-        for short, full in (("gemm_f16_kernel", "gemm_f16_kernel<false>"),
-                            ("gemm_f16_pp_kernel", "gemm_f16_pp_kernel<false>"), ("gemm_km_kernel", "gemm_km_kernel"),
-                            ("par_iter_kernel", "par_iter_kernel<3, true>"),
-                            ("attn_fwd_kernel", "attn_fwd_kernel<64>"), ("attn_mean_kernel", "attn_mean_kernel<64>")):
-            if full in t:
-                traffic[short] = round(t[full]["hbm_bytes_per_launch"])
+        traffic = {k: round(v["hbm_bytes_per_launch"]) for k, v in json.load(open(tpath)).items()}
     roofs = []
     for name, r in summ.items():
-        bound, peak, unit = peaks.get(name, ("mfma", 2500.0, "TFLOP/s"))
+        bound, peak, unit = peak_of(name)
         sec = r["ms"] * 1e-3
+        if sec <= 0:
+            continue
         ach = r["work"] / sec / (1e12 if bound == "mfma" else 1e9)
         roofs.append({"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                      "frac": round(ach / peak, 4), "traffic": traffic.get(name), "launches": r["launches"],
+                      "frac": round(ach / peak, 4), "traffic": traffic.get(name), "launches_timed": r["launches"],
+                      "sampling": f"1 of {stride} launches",
                       "avg_launch_us": round(r["ms"] * 1e3 / max(r["launches"], 1), 2),
-                      "share_of_step": round(r["ms"] * 1e-3 / dt, 4)})
+                      "share_of_step": round(r["ms"] * stride * 1e-3 / dt, 4)})
     roofs.sort(key=lambda x: -x["share_of_step"])
     out = {
         "metric": "images/sec (train fwd+bwd) ViT-B/16 512x512 VOC",

@@ -28,6 +28,13 @@ const char* wc_last_error(void);
 int wc_device_count(void);
 int wc_device_arch(int dev, char* buf, int buflen);
 
+/* Per-kernel HIP-event timing of the dominant kernels (GEMMs, attention, PAR), for bench.py's roofline leg.
+ * wc_prof_enable(n) clears the records and records one of every n instrumented launches (n = 1: all; an event pair
+ * fences its launch, ~6 us), (0) stops.  wc_prof_report synchronises the device and
+ * writes one "kernel name \t launches \t total ms \t algorithmic work (flop or bytes)" line per kernel. */
+void wc_prof_enable(int stride);
+int wc_prof_report(char* buf, int cap);
+
 /* ---- PAR: pixel-adaptive refinement -------------------------------------------------- */
 /* WeCLIP_model/PAR.py:64-88 (`PAR.forward` up to `aff`, incl. get_dilated_neighbors :39-49 and
  * get_pos :51-62).  img (B,3,H,W) f32 -> aff (B, 8*n_dil, H, W) f32. */

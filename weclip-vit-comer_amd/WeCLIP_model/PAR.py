@@ -61,15 +61,9 @@ class PAR(nn.Module):
         tmp = torch.empty_like(masks)
         aff = torch.empty(group * T * h * ((w + 63) // 64 * 64), device=masks.device, dtype=torch.float32)
         d = L.int_array(self.dilations)
-        from ..ops import KernelTimer
-        t0 = KernelTimer.start()
         L.lib().wc_par_forward(L.ptr(imgs, torch.float32, "imgs"), L.ptr(masks), L.ptr(out),
                                L.ptr(tmp), L.ptr(aff), b, C, h, w, d, len(self.dilations),
                                self.num_iter, group, L.stream())
-        # algorithmic bytes: (T + 2C) planes per iteration + (3 + T) planes for the affinity set-up
-        KernelTimer.stop("par_iter_kernel", t0,
-                         4.0 * b * h * w * ((T + 2 * C) * self.num_iter + 3 + T),
-                         launches=self.num_iter * ((b + group - 1) // group))
         return out
 
 

@@ -481,18 +481,26 @@ extern "C" int wc_attn_fwd(const void* qkv, void* out, float* out32, float* lse,
     hipStream_t st = (hipStream_t)stream;
     if (DH == 64) {
         const size_t lds = 2 * (64 * (64 * 2 + 16) + 64 * 128);
+        { const int pr = wc_prof_begin(stream);
         hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), lds, st, (const __half*)qkv, (__half*)out, out32, lse, L, H,
                            E, r, nqb, B);
+        wc_prof_end(pr, "attn_fwd_kernel<64>", 4.0 * B * H * (double)L * L * DH, stream); }
         if (r)
+            { const int pr = wc_prof_begin(stream);
             hipLaunchKernelGGL(attn_rows_kernel<64>, dim3(r, H, B), dim3(256), (size_t)L * 4, st, (const __half*)qkv,
                                (__half*)out, out32, lse, L, H, E);
+            wc_prof_end(pr, "attn_rows_kernel<64>", 4.0 * B * H * (double)r * L * DH, stream); }
     } else {
         const size_t lds = 2 * (64 * (32 * 2 + 16) + 64 * 64);
+        { const int pr = wc_prof_begin(stream);
         hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), lds, st, (const __half*)qkv, (__half*)out, out32, lse, L, H,
                            E, r, nqb, B);
+        wc_prof_end(pr, "attn_fwd_kernel<32>", 4.0 * B * H * (double)L * L * DH, stream); }
         if (r)
+            { const int pr = wc_prof_begin(stream);
             hipLaunchKernelGGL(attn_rows_kernel<32>, dim3(r, H, B), dim3(256), (size_t)L * 4, st, (const __half*)qkv,
                                (__half*)out, out32, lse, L, H, E);
+            wc_prof_end(pr, "attn_rows_kernel<32>", 4.0 * B * H * (double)r * L * DH, stream); }
     }
     WC_LAUNCH_CHECK("attn_fwd_kernel");
     return WC_OK;
@@ -510,18 +518,26 @@ extern "C" int wc_attn_mean(const void* qkv, const float* lse, float* mean, int 
     hipStream_t st = (hipStream_t)stream;
     if (DH == 64) {
         const size_t lds = 2 * (2 * 128 * (64 * 2 + 16) + 512);
+        { const int pr = wc_prof_begin(stream);
         hipLaunchKernelGGL(attn_mean_kernel<64>, grid, dim3(256), lds, st, (const __half*)qkv, lse, mean,
                            L, H, E, r, nt, B);
+        wc_prof_end(pr, "attn_mean_kernel<64>", 2.0 * B * H * (double)L * L * DH, stream); }
         if (r)
+            { const int pr = wc_prof_begin(stream);
             hipLaunchKernelGGL(attn_mean_edge_kernel<64>, dim3(wc_cdiv(nedge, 16), B), dim3(256), 0, st, (const __half*)qkv,
                                lse, mean, L, H, E, r);
+            wc_prof_end(pr, "attn_mean_edge_kernel<64>", 2.0 * H * DH * (double)nedge * B, stream); }
     } else {
         const size_t lds = 2 * (2 * 128 * (32 * 2 + 16) + 512);
+        { const int pr = wc_prof_begin(stream);
         hipLaunchKernelGGL(attn_mean_kernel<32>, grid, dim3(256), lds, st, (const __half*)qkv, lse, mean,
                            L, H, E, r, nt, B);
+        wc_prof_end(pr, "attn_mean_kernel<32>", 2.0 * B * H * (double)L * L * DH, stream); }
         if (r)
+            { const int pr = wc_prof_begin(stream);
             hipLaunchKernelGGL(attn_mean_edge_kernel<32>, dim3(wc_cdiv(nedge, 16), B), dim3(256), 0, st, (const __half*)qkv,
                                lse, mean, L, H, E, r);
+            wc_prof_end(pr, "attn_mean_edge_kernel<32>", 2.0 * H * DH * (double)nedge * B, stream); }
     }
     WC_LAUNCH_CHECK("attn_mean_kernel");
     return WC_OK;

@@ -34,6 +34,10 @@ extern "C" void wc_set_error(const char* fmt, ...);
 
 static inline int wc_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// optional HIP-event timing of a launch (core.hip; no-ops unless wc_prof_enable(1))
+int wc_prof_begin(void* stream);
+void wc_prof_end(int idx, const char* name, double work, void* stream);
+
 // 64-lane wavefront reductions (DPP/shuffle based).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -2,6 +2,9 @@
 #include "common.h"
 #include <stdarg.h>
 #include <string.h>
+#include <map>
+#include <string>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -38,4 +41,72 @@ extern "C" int wc_device_arch(int dev, char* buf, int buflen) {
     strncpy(buf, p.gcnArchName, buflen - 1);
     buf[buflen - 1] = 0;
     return WC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg): the launch sites of
+// the dominant kernels bracket themselves with wc_prof_begin / wc_prof_end.  Off by default (one branch per launch).
+// An event pair around a launch costs ~6 us of GPU time (it fences the neighbouring kernels), so bench.py records a
+// regular 1-in-n sample of the instrumented launches rather than all ~290 per step (which costs 10 % throughput).
+struct ProfRec { const char* name; hipEvent_t e0, e1; double work; };
+static int g_prof_stride = 0;          // 0 = off; n = record one of every n instrumented launches
+static unsigned long g_prof_ctr = 0;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_pool;
+
+static hipEvent_t prof_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+extern "C" void wc_prof_enable(int stride) {
+    for (auto& r : g_prof) { g_pool.push_back(r.e0); g_pool.push_back(r.e1); }
+    g_prof.clear();
+    g_prof_stride = stride > 0 ? stride : 0;
+    g_prof_ctr = 0;
+}
+
+int wc_prof_begin(void* stream) {
+    if (!g_prof_stride || (g_prof_ctr++ % g_prof_stride) != 0) return -1;
+    ProfRec r;
+    r.name = "";
+    r.e0 = prof_event();
+    r.e1 = prof_event();
+    r.work = 0.0;
+    hipEventRecord(r.e0, (hipStream_t)stream);
+    g_prof.push_back(r);
+    return (int)g_prof.size() - 1;
+}
+
+void wc_prof_end(int idx, const char* name, double work, void* stream) {
+    if (idx < 0) return;
+    g_prof[idx].name = name;          // string literals only
+    g_prof[idx].work = work;
+    hipEventRecord(g_prof[idx].e1, (hipStream_t)stream);
+}
+
+// Aggregated records after a device synchronisation: returns the number of distinct kernel names and writes
+// "name\tlaunches\tms\twork\n" lines into buf (truncated at cap).
+extern "C" int wc_prof_report(char* buf, int cap) {
+    hipDeviceSynchronize();
+    std::map<std::string, std::pair<double, std::pair<double, long>>> agg;   // name -> (ms, (work, launches))
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+        auto& a = agg[r.name];
+        a.first += ms;
+        a.second.first += r.work;
+        a.second.second += 1;
+    }
+    int off = 0;
+    if (cap > 0) buf[0] = 0;
+    for (auto& kv : agg) {
+        const int n = snprintf(buf + off, off < cap ? cap - off : 0, "%s\t%ld\t%.6f\t%.6e\n", kv.first.c_str(),
+                               kv.second.second.second, kv.second.first, kv.second.second.first);
+        if (n < 0 || off + n >= cap) break;
+        off += n;
+    }
+    return (int)agg.size();
 }

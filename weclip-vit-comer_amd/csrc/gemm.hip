@@ -768,7 +768,9 @@ extern "C" int wc_gemm_km_f16(const void* dY, long lda, const void* X, long ldx,
     e.P32 = nullptr; e.aux = nullptr; e.rowmap = nullptr; e.rpg = 1; e.ldaux = 0; e.auxh = nullptr; e.cscale = nullptr;
     e.sCS = 0; e.gx = g.gx; e.gy = wc_cdiv(N, 128); e.vec = 0;
     dim3 grid((unsigned)(g.gx * wc_cdiv(N, 128)), 1, ns);
+    const int pr = wc_prof_begin(stream);
     hipLaunchKernelGGL(gemm_km_kernel, grid, dim3(256), 4 * 64 * 256, (hipStream_t)stream, g);
+    wc_prof_end(pr, "gemm_km_kernel", 2.0 * M * N * K1, stream);
     WC_LAUNCH_CHECK("gemm_km_kernel");
     return WC_OK;
 }
@@ -893,10 +895,12 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
             g.gy -= 1;
             gridp.x = (unsigned)(g.gx * (g.gy >= 16 ? (g.gy + 7) / 8 * 8 : g.gy));
         }
+        const int pr = wc_prof_begin(stream);
         if (act >= 4)
             hipLaunchKernelGGL(gemm_f16_pp_kernel<true>, gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
         else
             hipLaunchKernelGGL(gemm_f16_pp_kernel<false>, gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
+        wc_prof_end(pr, act >= 4 ? "gemm_f16_pp_kernel<true>" : "gemm_f16_pp_kernel<false>", 2.0 * g.M * N * K, stream);
         WC_LAUNCH_CHECK("gemm_f16_pp_kernel");
         if (!split) return WC_OK;
         for (int i = 0; i < nseg; ++i) g.A[i] += (long)m_main * lda;
@@ -913,10 +917,12 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
     g.gy = wc_cdiv(M, BM);
     dim3 grid((unsigned)(g.gx * ((g.gy + 7) / 8 * 8)), 1, batch);
     const size_t lds = 2 * 2 * BM * BK * 2;
+    const int pr = wc_prof_begin(stream);
     if (act >= 4)
         hipLaunchKernelGGL(gemm_f16_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, g);
     else
         hipLaunchKernelGGL(gemm_f16_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, g);
+    wc_prof_end(pr, act >= 4 ? "gemm_f16_kernel<true>" : "gemm_f16_kernel<false>", 2.0 * g.M * N * K * batch, stream);
     WC_LAUNCH_CHECK("gemm_f16_kernel");
     return WC_OK;
 }

@@ -139,12 +139,16 @@ __global__ __launch_bounds__(256) void par_affinity_reg_kernel(const float* __re
 static void launch_affinity(const float* img, float* aff, int nb, int H, int W, const ParTaps& tp,
                             hipStream_t st, bool tiled) {
     dim3 grid(wc_cdiv(W, 64), wc_cdiv(H, 4), nb);
+    const int pr = wc_prof_begin(st);
     if (tp.n == 48 && tiled)
         hipLaunchKernelGGL((par_affinity_reg_kernel<6, true>), grid, dim3(256), 0, st, img, aff, H, W, 0.3f, tp);
     else if (tp.n == 48)
         hipLaunchKernelGGL((par_affinity_reg_kernel<6, false>), grid, dim3(256), 0, st, img, aff, H, W, 0.3f, tp);
     else
         hipLaunchKernelGGL(par_affinity_kernel, grid, dim3(256), 0, st, img, aff, H, W, 0.3f, tp);
+    // algorithmic bytes: 3 image planes read + T affinity planes written
+    wc_prof_end(pr, tp.n == 48 ? (tiled ? "par_affinity_reg_kernel<6, true>" : "par_affinity_reg_kernel<6, false>") : "par_affinity_kernel",
+                4.0 * nb * (double)H * W * (3 + tp.n), st);
 }
 
 // One PAR iteration.  Thread = one pixel, CG channels at a time (aff value reused across the
@@ -273,9 +277,14 @@ static int launch_iter(const float* aff, const float* src, float* dst, int B, in
 #define PAR_ITER_LAUNCH(CG_) \
     if (tiled) hipLaunchKernelGGL((par_iter_kernel<CG_, true>), grid, dim3(256), 0, st, aff, src, dst, C, H, W, tp); \
     else hipLaunchKernelGGL((par_iter_kernel<CG_, false>), grid, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
+    const int pr = wc_prof_begin(st);
     if (C <= 2) { PAR_ITER_LAUNCH(2) }
     else if (C == 3) { PAR_ITER_LAUNCH(3) }
     else { PAR_ITER_LAUNCH(4) }
+    // algorithmic bytes of one sweep: T affinity planes + C mask planes read, C written
+    static const char* names[2][3] = {{"par_iter_kernel<2, false>", "par_iter_kernel<3, false>", "par_iter_kernel<4, false>"},
+                                      {"par_iter_kernel<2, true>", "par_iter_kernel<3, true>", "par_iter_kernel<4, true>"}};
+    wc_prof_end(pr, names[tiled ? 1 : 0][C <= 2 ? 0 : (C == 3 ? 1 : 2)], 4.0 * B * (double)H * W * (tp.n + 2 * C), st);
     WC_LAUNCH_CHECK("par_iter_kernel");
     return WC_OK;
 }

@@ -13,39 +13,25 @@ LOG2E = 1.4426950408889634
 
 
 class KernelTimer:
-    """Optional HIP-event timing of kernel families on the current stream (bench.py roofline leg).
-    `work` is the algorithmic work (flops or bytes) of the bracketed launch(es)."""
-    enabled = False
-    records = {}
+    """Per-kernel HIP-event timing of the dominant kernels (bench.py roofline leg).  The events are recorded by
+    the C library at its own launch sites (csrc/core.hip wc_prof_*), one pair per kernel launch on the launch
+    stream, under the kernel names rocprofv3 reports; `work` is the algorithmic work (flops or bytes) of a launch."""
 
-    @classmethod
-    def reset(cls):
-        cls.records = {}
+    @staticmethod
+    def enable(stride=1):
+        """Record one of every `stride` instrumented launches (clearing earlier records); 0 / False stops."""
+        L.lib().cdll.wc_prof_enable(int(stride))
 
-    @classmethod
-    def start(cls):
-        if not cls.enabled:
-            return None
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        return e
-
-    @classmethod
-    def stop(cls, name, e0, work, launches=1):
-        if e0 is None:
-            return
-        e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
-        cls.records.setdefault(name, []).append((e0, e1, work, launches))
-
-    @classmethod
-    def summary(cls):
-        """name -> dict(ms total, launches, work) after a device sync."""
-        torch.cuda.synchronize()
+    @staticmethod
+    def summary():
+        """kernel name -> dict(ms total, launches, work) after a device sync."""
+        import ctypes
+        buf = ctypes.create_string_buffer(1 << 16)
+        L.lib().cdll.wc_prof_report(buf, len(buf))
         out = {}
-        for name, recs in cls.records.items():
-            out[name] = dict(ms=sum(a.elapsed_time(b) for a, b, _, _ in recs),
-                             launches=sum(n for _, _, _, n in recs), work=sum(w for _, _, w, _ in recs))
+        for line in buf.value.decode().splitlines():
+            name, n, ms, work = line.split("\t")
+            out[name] = {"ms": float(ms), "launches": int(n), "work": float(work)}
         return out
 
 
@@ -88,7 +74,6 @@ def gemm(a, w, M, N, K, *, lda=None, ldw=None, bias=None, resid=None, ldr=None, 
     wp = [L.ptr(s[1], F16, "W") for s in segs] + [None] * (3 - len(segs))
     ldr = ldc if ldr is None else ldr
     sR = sC if sR is None else sR
-    t0 = KernelTimer.start()
     L.lib().wc_gemm_f16(ap[0], ap[1], ap[2], wp[0], wp[1], wp[2], len(segs), M, N, K, lda, ldw,
                         batch, sA, sW, sC, L.ptr(bias, F32, "bias"), L.ptr(resid, F32, "resid"),
                         ldr, sR, L.ptr(out32, F32, "out32"), L.ptr(out16, F16, "out16"),
@@ -96,11 +81,6 @@ def gemm(a, w, M, N, K, *, lda=None, ldw=None, bias=None, resid=None, ldr=None, 
                         float(scale), scale_cols, L.ptr(pre32, F32, "pre32"), L.ptr(aux, F32, "aux"),
                         L.ptr(rowmap, torch.int32, "rowmap"), rpg, ldaux, L.ptr(auxh, F16, "auxh"),
                         L.ptr(cscale, F32, "cscale"), sCS, L.stream())
-    if t0 is not None:
-        plan = L.lib().cdll.wc_gemm_plan(M, N, K, len(segs), batch)   # value-returning query, not an error code
-        name = ("gemm_f16_kernel", "gemm_f16_pp_kernel", "gemm_f16_pp_kernel+tail")[plan]
-        # algorithmic flops of ONE pass over K (split-precision segments are not counted as extra work)
-        KernelTimer.stop(name, t0, 2.0 * M * N * K * batch, launches=2 if plan == 2 else 1)
 
 
 def layernorm(x, weight, bias, *, eps=1e-5, want32=False, want16=True, with_lo=False, rows=None,
@@ -128,15 +108,11 @@ def attention(qkv16, B, Lq, H, DH, want_mean=True, want_o32=False):
     o16 = torch.empty(B * Lq, E, device=dev, dtype=F16)
     lse = torch.empty(B, H, Lq, device=dev, dtype=F32)
     o32 = torch.empty(B * Lq, E, device=dev, dtype=F32) if want_o32 else None
-    t0 = KernelTimer.start()
     lib.wc_attn_fwd(L.ptr(qkv16, F16, "qkv"), L.ptr(o16), L.ptr(o32), L.ptr(lse), B, Lq, H, DH, L.stream())
-    KernelTimer.stop("attn_fwd_kernel", t0, 4.0 * B * H * Lq * Lq * DH)
     mean = None
     if want_mean:
         mean = torch.empty(B, Lq, Lq, device=dev, dtype=F32)
-        t0 = KernelTimer.start()
         lib.wc_attn_mean(L.ptr(qkv16), L.ptr(lse), L.ptr(mean), B, Lq, H, DH, L.stream())
-        KernelTimer.stop("attn_mean_kernel", t0, 2.0 * B * H * Lq * Lq * DH)
     if want_o32:
         return o16, lse, mean, o32
     return o16, lse, mean
@@ -207,10 +183,8 @@ def wgrad_partials(dy16, x16, M, N, K, *, lda=None, ldx=None, slices=1, bias=Tru
     K1 = K + (1 if bias else 0)
     part = torch.empty(ns, N, K1, device=dev, dtype=F32)
     rpg, gs, off = xmap if xmap is not None else (max(M, 64), 0, 0)
-    t0 = KernelTimer.start()
     L.lib().wc_gemm_km_f16(L.ptr(dy16, F16, "dY"), lda, L.ptr(x16, F16, "X"), ldx, L.ptr(z), M, N, K, rpg, gs, off,
                            mslice, 1 if bias else 0, L.ptr(part), L.stream())
-    KernelTimer.stop("gemm_km_kernel", t0, 2.0 * M * N * K1)
     return part, ns
 
 
