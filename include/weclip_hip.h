@@ -184,7 +184,7 @@ int wc_cls_rows(float* x, const float* cls, const float* pos0, int B, int L, int
  * wc_cam_head: x2 (B,L,E) f32 block output -> ln_post, mean over patch tokens, @proj (E,Ed),
  *   cosine logits against pre-normalised text rows text[text_idx[p,t]] (t < n_text[p], row
  *   stride Tmax), softmax -> probs (P,Tmax); df (P,E) = d probs[p,cls] / d pooled feature.
- *   partial: workspace B*ceil(L/64)*E f32.  logit_scale = exp(CLIP.logit_scale).
+ *   partial: workspace B*ceil(L/16)*E f32.  logit_scale = exp(CLIP.logit_scale).
  * wc_lnpost_bwd: dx2 (P,L,E) = gs * backward of ln_post+mean-pool (token 0 gets 0);
  *   written as f32 and as fp16 hi/lo GEMM operands.
  * wc_ln2_bwd_add: g16 = fp16((dx2 + LN2_bwd(da2; x1)) / gs): the gradient arriving at the fp16

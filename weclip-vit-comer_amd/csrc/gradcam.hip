@@ -22,6 +22,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------
 // (a) partial[b, chunk, :] = sum over tokens l in chunk, l >= 1, of ln_post(x2[b, l, :])
+//     chunk = LNP_ROWS token rows (one per wave iteration, the row held in registers: one read of x2)
+#define LNP_ROWS 16
+template <int NV>   // E <= 64 * NV
 __global__ __launch_bounds__(256) void lnpost_pool_kernel(const float* __restrict__ x2,
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ bb, float eps,
@@ -29,20 +32,41 @@ __global__ __launch_bounds__(256) void lnpost_pool_kernel(const float* __restric
                                                            int nchunk) {
     extern __shared__ float sm[];   // [4][E]
     const int b = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float* acc = sm + wv * E;
-    for (int e = lane; e < E; e += 64) acc[e] = 0.f;
-    const int l0 = chunk * 64;
-    for (int l = l0 + wv; l < l0 + 64 && l < L; l += 4) {
+    float acc[NV], wv_[NV], bv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = lane + 64 * i;
+        acc[i] = 0.f;
+        wv_[i] = e < E ? w[e] : 0.f;
+        bv[i] = e < E ? bb[e] : 0.f;
+    }
+    const int l0 = chunk * LNP_ROWS;
+    for (int l = l0 + wv; l < l0 + LNP_ROWS && l < L; l += 4) {
         if (l == 0) continue;
         const float* xr = x2 + ((long)b * L + l) * E;
+        float xv[NV];
         float s = 0.f;
-        for (int e = lane; e < E; e += 64) s += xr[e];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = lane + 64 * i;
+            xv[i] = e < E ? xr[e] : 0.f;
+            s += xv[i];
+        }
         const float mean = wave_sum(s) / E;
         float q = 0.f;
-        for (int e = lane; e < E; e += 64) { const float d = xr[e] - mean; q += d * d; }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float d = (lane + 64 * i < E) ? xv[i] - mean : 0.f;
+            q += d * d;
+        }
         const float rstd = rsqrtf(wave_sum(q) / E + eps);
-        for (int e = lane; e < E; e += 64) acc[e] += (xr[e] - mean) * rstd * w[e] + bb[e];
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < E) acc[i] += (xv[i] - mean) * rstd * wv_[i] + bv[i];
     }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < E) sm[wv * E + lane + 64 * i] = acc[i];
     __syncthreads();
     for (int e = threadIdx.x; e < E; e += 256)
         partial[((long)b * nchunk + chunk) * E + e] = sm[e] + sm[E + e] + sm[2 * E + e] + sm[3 * E + e];
@@ -67,15 +91,33 @@ __global__ __launch_bounds__(512) void cam_head_kernel(const float* __restrict__
     float* red = lg + Tmax;
     const int p = blockIdx.x, img = pair_img[p], cls = pair_cls[p], T = n_text[p], tid = threadIdx.x;
     for (int e = tid; e < E; e += 512) {
-        float s = 0.f;
-        for (int c = 0; c < nchunk; ++c) s += partial[((long)img * nchunk + c) * E + e];
-        f[e] = s / (L - 1);
+        const float* pp = partial + (long)img * nchunk * E + e;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // 8 independent loads in flight
+        int c = 0;
+        for (; c + 8 <= nchunk; c += 8)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += pp[(long)(c + u) * E];
+        for (; c < nchunk; ++c) s[0] += pp[(long)c * E];
+        f[e] = (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) / (L - 1);
     }
     __syncthreads();
     for (int t = tid; t < Ed; t += 512) {
-        float s = 0.f;
-        for (int e = 0; e < E; ++e) s = fmaf(f[e], proj[(long)e * Ed + t], s);
-        y[t] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int e = 0;
+        for (; e + 16 <= E; e += 16) {           // 16 coalesced row loads in flight per thread
+            float pv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) pv[u] = proj[(long)(e + u) * Ed + t];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) {
+                s0 = fmaf(f[e + u], pv[u], s0);
+                s1 = fmaf(f[e + u + 1], pv[u + 1], s1);
+                s2 = fmaf(f[e + u + 2], pv[u + 2], s2);
+                s3 = fmaf(f[e + u + 3], pv[u + 3], s3);
+            }
+        }
+        for (; e < E; ++e) s0 = fmaf(f[e], proj[(long)e * Ed + t], s0);
+        y[t] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
     float q = 0.f;
@@ -121,11 +163,36 @@ __global__ __launch_bounds__(512) void cam_head_kernel(const float* __restrict__
     __syncthreads();
     for (int k = tid; k < Ed; k += 512) dy[k] = (dy[k] - y[k] * dot) / ynorm;   // d/dy of y/|y|
     __syncthreads();
-    for (int e = tid; e < E; e += 512) {
-        const float* pr = proj + (long)e * Ed;
-        float s = 0.f;
-        for (int k = 0; k < Ed; ++k) s = fmaf(pr[k], dy[k], s);
-        df[(long)p * E + e] = s;
+    // df = proj dy: 8 rows of proj per wave at a time, 8 lanes per row reading 16-B pieces (coalesced 128 B per
+    // row and step, all loads of a row independent), 3-step shuffle reduction over the 8 lanes
+    if ((Ed & 3) == 0) {
+        const int rsub = lane >> 3, j = lane & 7;
+        for (int e0 = wv * 8; e0 < E; e0 += 64) {
+            const int e = e0 + rsub;
+            float s = 0.f;
+            if (e < E) {
+                const float* pr = proj + (long)e * Ed;
+#pragma unroll 4
+                for (int k = 4 * j; k < Ed; k += 32) {
+                    const float4 pv = *reinterpret_cast<const float4*>(pr + k);
+                    s = fmaf(pv.x, dy[k], s);
+                    s = fmaf(pv.y, dy[k + 1], s);
+                    s = fmaf(pv.z, dy[k + 2], s);
+                    s = fmaf(pv.w, dy[k + 3], s);
+                }
+            }
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            if (j == 0 && e < E) df[(long)p * E + e] = s;
+        }
+    } else {
+        for (int e = tid; e < E; e += 512) {
+            const float* pr = proj + (long)e * Ed;
+            float s = 0.f;
+            for (int k = 0; k < Ed; ++k) s = fmaf(pr[k], dy[k], s);
+            df[(long)p * E + e] = s;
+        }
     }
 }
 
@@ -179,6 +246,7 @@ __global__ __launch_bounds__(256) void lnpost_bwd_kernel(const float* __restrict
 
 // (f) g16[p,l,:] = fp16( (dx2s + LN2_bwd(da2s; x1[img,l,:])) / gs )  -- gradient reaching the fp16
 //     out-projection output, rounded like autograd does for the fp16 tensor (myAtt.py:321).
+template <int NV>   // E <= 64 * NV; the row of x1 / da2 is held in registers (one read of each)
 __global__ __launch_bounds__(256) void ln2_bwd_add_kernel(const float* __restrict__ da2,
                                                            const float* __restrict__ dx2,
                                                            const float* __restrict__ x1,
@@ -191,24 +259,40 @@ __global__ __launch_bounds__(256) void ln2_bwd_add_kernel(const float* __restric
     const int p = row / L, l = row % L;
     const long o = row * E;
     const float* xr = x1 + ((long)pair_img[p] * L + l) * E;
+    float xv[NV], gv[NV], dv[NV];
     float s = 0.f;
-    for (int e = lane; e < E; e += 64) s += xr[e];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = lane + 64 * i;
+        const bool ok = e < E;
+        xv[i] = ok ? xr[e] : 0.f;
+        gv[i] = ok ? da2[o + e] * w[e] : 0.f;
+        dv[i] = ok ? dx2[o + e] : 0.f;
+        s += xv[i];
+    }
     const float mean = wave_sum(s) / E;
     float q = 0.f;
-    for (int e = lane; e < E; e += 64) { const float d = xr[e] - mean; q += d * d; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float d = (lane + 64 * i < E) ? xv[i] - mean : 0.f;
+        q += d * d;
+    }
     const float rstd = rsqrtf(wave_sum(q) / E + eps);
     float sg = 0.f, sgx = 0.f;
-    for (int e = lane; e < E; e += 64) {
-        const float g = da2[o + e] * w[e];
-        sg += g;
-        sgx += g * (xr[e] - mean) * rstd;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        sg += gv[i];
+        sgx += gv[i] * (xv[i] - mean) * rstd;
     }
     sg = wave_sum(sg) / E;
     sgx = wave_sum(sgx) / E;
-    for (int e = lane; e < E; e += 64) {
-        const float g = da2[o + e] * w[e];
-        const float v = (dx2[o + e] + rstd * (g - sg - (xr[e] - mean) * rstd * sgx)) * inv_gs;
-        g16[o + e] = __float2half(v);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = lane + 64 * i;
+        if (e < E) {
+            const float v = (dv[i] + rstd * (gv[i] - sg - (xv[i] - mean) * rstd * sgx)) * inv_gs;
+            g16[o + e] = __float2half(v);
+        }
     }
 }
 
@@ -545,9 +629,14 @@ extern "C" int wc_cam_head(const float* x2, const float* lnw, const float* lnb, 
                  "wc_cam_head: bad argument");
     WC_CHECK_ARG(Tmax > 0 && Tmax <= 512 && E <= 4096 && Ed <= 4096, "wc_cam_head: Tmax <= 512, E, Ed <= 4096");
     hipStream_t st = (hipStream_t)stream;
-    const int nchunk = wc_cdiv(L, 64);
-    hipLaunchKernelGGL(lnpost_pool_kernel, dim3(nchunk, B), dim3(256), 4 * E * sizeof(float), st, x2, lnw, lnb,
-                       1e-5f, partial, L, E, nchunk);
+    const int nchunk = wc_cdiv(L, LNP_ROWS);
+    WC_CHECK_ARG(E <= 1024, "wc_cam_head: E <= 1024");
+    if (E <= 256)
+        hipLaunchKernelGGL(lnpost_pool_kernel<4>, dim3(nchunk, B), dim3(256), 4 * E * sizeof(float), st, x2, lnw, lnb,
+                           1e-5f, partial, L, E, nchunk);
+    else
+        hipLaunchKernelGGL(lnpost_pool_kernel<16>, dim3(nchunk, B), dim3(256), 4 * E * sizeof(float), st, x2, lnw, lnb,
+                           1e-5f, partial, L, E, nchunk);
     WC_LAUNCH_CHECK("lnpost_pool_kernel");
     const size_t sm = (E + 2 * Ed + Tmax + 16) * sizeof(float);
     hipLaunchKernelGGL(cam_head_kernel, dim3(P), dim3(512), sm, st, partial, proj, text, text_idx, n_text,
@@ -573,8 +662,13 @@ extern "C" int wc_ln2_bwd_add(const float* da2, const float* dx2, const float* x
     WC_CHECK_ARG(da2 && dx2 && x1 && lnw && pair_img && g16 && P > 0 && L > 0 && E > 0 && gs > 0,
                  "wc_ln2_bwd_add: bad argument");
     const long rows = (long)P * L;
-    hipLaunchKernelGGL(ln2_bwd_add_kernel, dim3(wc_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, da2,
-                       dx2, x1, lnw, 1e-5f, 1.0f / gs, pair_img, (__half*)g16, L, E, rows);
+    WC_CHECK_ARG(E <= 1024, "wc_ln2_bwd_add: E <= 1024");
+    if (E <= 256)
+        hipLaunchKernelGGL(ln2_bwd_add_kernel<4>, dim3(wc_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, da2,
+                           dx2, x1, lnw, 1e-5f, 1.0f / gs, pair_img, (__half*)g16, L, E, rows);
+    else
+        hipLaunchKernelGGL(ln2_bwd_add_kernel<16>, dim3(wc_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, da2,
+                           dx2, x1, lnw, 1e-5f, 1.0f / gs, pair_img, (__half*)g16, L, E, rows);
     WC_LAUNCH_CHECK("ln2_bwd_add_kernel");
     return WC_OK;
 }

@@ -56,7 +56,7 @@ class LastLayerState:
         E, Ed = v.proj.shape
         P = pair_img.numel()
         dev = self.x2.device
-        nchunk = (Lq + 63) // 64
+        nchunk = (Lq + 15) // 16
         partial = torch.empty(B * nchunk * E, device=dev, dtype=F32)
         probs = torch.zeros(P, Tmax, device=dev, dtype=F32)
         df = torch.empty(P, E, device=dev, dtype=F32)
