@@ -52,11 +52,25 @@ __global__ __launch_bounds__(256) void bilinear_bwd_y_kernel(const float* __rest
     if (y_lo < 0) y_lo = 0;
     if (y_hi > Hd - 1) y_hi = Hd - 1;
     float acc = 0.f;
-    for (int y = y_lo; y <= y_hi; ++y) {
+    int y = y_lo;
+    for (; y + 7 <= y_hi; y += 8) {            // 8 rows per trip: the loads are issued before the FMAs
+        float g[8], wy[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int y0, y1;
+            float ly;
+            src_index(y + u, Hs, sy, align, y0, y1, ly);
+            wy[u] = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);   // wave-uniform
+            g[u] = G[(long)(y + u) * Wd];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fmaf(wy[u], g[u], acc);
+    }
+    for (; y <= y_hi; ++y) {
         int y0, y1;
         float ly;
         src_index(y, Hs, sy, align, y0, y1, ly);
-        const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);   // wave-uniform
+        const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
         if (wy != 0.f) acc = fmaf(wy, G[(long)y * Wd], acc);
     }
     tmp[((long)blockIdx.z * Hs + ys) * Wd + x] = acc;

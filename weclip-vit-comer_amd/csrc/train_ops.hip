@@ -150,19 +150,53 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 
 // S[b,i,j] = z(i,j) + z(j,i),  z = dAP * AP * (1 - AP)   (backward of sigmoid(F^T F) w.r.t. the Gram matrix,
 // symmetrised so that dF = S F); fp16 hi/lo operands for the GEMM.
+// One block per unordered pair of 64x64 tiles (ti <= tj): z is computed once per element, both tiles are read
+// coalesced (rows), and the transposed partner comes from LDS.
 __global__ __launch_bounds__(256) void sigmoid_gram_bwd_kernel(const float* __restrict__ dAP, const float* __restrict__ AP,
                                                                 __half* __restrict__ hi, __half* __restrict__ lo, int n,
-                                                                int ldo, float scale) {
-    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
-    if (j >= n) return;
+                                                                int ldo, float scale, int nt) {
+    __shared__ float za[64][65], zb[64][65];      // z of tile (ti, tj) and of tile (tj, ti)
+    // blockIdx.x enumerates pairs ti <= tj
+    int ti = 0, rem = blockIdx.x;
+    while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
+    const int tj = ti + rem, b = blockIdx.y;
     const long base = (long)b * n * n;
-    const long o = base + (long)i * n + j, ot = base + (long)j * n + i;
-    const float a = AP[o], at = AP[ot];
-    const float v = scale * (dAP[o] * a * (1.f - a) + dAP[ot] * at * (1.f - at));
-    const __half h = __float2half(v);
-    const long oo = (long)b * n * ldo + (long)i * ldo + j;
-    hi[oo] = h;
-    if (lo) lo[oo] = __float2half(v - __half2float(h));
+    const int i0 = ti * 64, j0 = tj * 64;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        float v = 0.f, vt = 0.f;
+        if (i0 + r < n && j0 + c < n) {
+            const long o = base + (long)(i0 + r) * n + j0 + c;
+            const float a = AP[o];
+            v = dAP[o] * a * (1.f - a);
+        }
+        if (ti != tj && j0 + r < n && i0 + c < n) {
+            const long o = base + (long)(j0 + r) * n + i0 + c;
+            const float a = AP[o];
+            vt = dAP[o] * a * (1.f - a);
+        }
+        za[r][c] = v;
+        zb[r][c] = vt;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        // S(i0+r, j0+c) = z(i0+r, j0+c) + z(j0+c, i0+r)
+        if (i0 + r < n && j0 + c < n) {
+            const float v = scale * (za[r][c] + (ti == tj ? za[c][r] : zb[c][r]));
+            const __half h = __float2half(v);
+            const long oo = (long)b * n * ldo + (long)(i0 + r) * ldo + j0 + c;
+            hi[oo] = h;
+            if (lo) lo[oo] = __float2half(v - __half2float(h));
+        }
+        if (ti != tj && j0 + r < n && i0 + c < n) {
+            const float v = scale * (zb[r][c] + za[c][r]);
+            const __half h = __float2half(v);
+            const long oo = (long)b * n * ldo + (long)(j0 + r) * ldo + i0 + c;
+            hi[oo] = h;
+            if (lo) lo[oo] = __float2half(v - __half2float(h));
+        }
+    }
 }
 
 // out32[r,c] = x[r,c] * cs[(r / rpb), c];  hi/lo = fp16 split of it   (dropout-mask backward + operand split)
@@ -240,8 +274,9 @@ extern "C" int wc_layernorm_bwd(const float* dy, const float* x, const float* w,
 extern "C" int wc_sigmoid_gram_bwd(const float* dAP, const float* AP, void* hi, void* lo, int B, int n, int ldo,
                                    float scale, void* stream) {
     WC_CHECK_ARG(dAP && AP && hi && B > 0 && n > 0 && n <= 65535 && ldo >= n, "wc_sigmoid_gram_bwd: bad argument");
-    hipLaunchKernelGGL(sigmoid_gram_bwd_kernel, dim3(wc_cdiv(n, 256), n, B), dim3(256), 0, (hipStream_t)stream, dAP, AP,
-                       (__half*)hi, (__half*)lo, n, ldo, scale);
+    const int nt = wc_cdiv(n, 64);
+    hipLaunchKernelGGL(sigmoid_gram_bwd_kernel, dim3(nt * (nt + 1) / 2, B), dim3(256), 0, (hipStream_t)stream, dAP, AP,
+                       (__half*)hi, (__half*)lo, n, ldo, scale, nt);
     WC_LAUNCH_CHECK("sigmoid_gram_bwd_kernel");
     return WC_OK;
 }
