@@ -544,6 +544,7 @@ __global__ __launch_bounds__(256) void attn_bwd_colsum_edge_kernel(const __half*
 }
 
 // (j) column sums of dq, dk, dv for one (pair, head): c[p, {0,E,2E} + h*DH + d]
+// thread = (16-byte chunk of the head's DH halves, token slice): 256 / (DH/8) slices, 16-B row loads.
 __global__ __launch_bounds__(256) void qkv_colsum_kernel(const __half* __restrict__ qkv,
                                                           const __half* __restrict__ dO,
                                                           const float* __restrict__ u,
@@ -552,31 +553,46 @@ __global__ __launch_bounds__(256) void qkv_colsum_kernel(const __half* __restric
                                                           const int* __restrict__ pair_img,
                                                           float* __restrict__ c, int L, int H, int DH,
                                                           float inv_sqrt_dh, float inv_qscale) {
-    __shared__ float red[3][4][64];
+    __shared__ float red[3][64][65];          // [q|k|v][slice][d]
     const int h = blockIdx.x, p = blockIdx.y, img = pair_img[p];
-    const int E = H * DH, d = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const __half* qb = qkv + (long)img * L * 3 * E + (long)h * DH;
-    const __half* dob = dO + (long)p * L * E + (long)h * DH;
+    const int E = H * DH, nch = DH >> 3, nsl = 256 / nch;          // 8 chunks x 32 slices (DH 64), 4 x 64 (DH 32)
+    const int ch = threadIdx.x % nch, sl = threadIdx.x / nch;
+    const __half* qb = qkv + (long)img * L * 3 * E + (long)h * DH + ch * 8;
+    const __half* dob = dO + (long)p * L * E + (long)h * DH + ch * 8;
     const float* ub = u + ((long)p * H + h) * L;
     const float* sb = dS0 + ((long)p * H + h) * L;
     const float* pb = P0 + ((long)p * H + h) * L;
-    float cq = 0.f, ck = 0.f, cv = 0.f;
-    if (d < DH)
-        for (int l = part; l < L; l += 4) {
-            const __half* row = qb + (long)l * 3 * E;
-            cq = fmaf(ub[l], __half2float(row[E + d]), cq);
-            ck = fmaf(sb[l], __half2float(row[d]), ck);
-            cv = fmaf(1.0f - pb[l], __half2float(dob[(long)l * E + d]), cv);
+    float cq[8], ck[8], cv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cq[j] = ck[j] = cv[j] = 0.f;
+    for (int l = sl; l < L; l += nsl) {
+        const __half* row = qb + (long)l * 3 * E;
+        const f16x8 kv = *reinterpret_cast<const f16x8*>(row + E);
+        const f16x8 qv = *reinterpret_cast<const f16x8*>(row);
+        const f16x8 dv = *reinterpret_cast<const f16x8*>(dob + (long)l * E);
+        const float a = ub[l], s0 = sb[l], om = 1.0f - pb[l];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            cq[j] = fmaf(a, (float)kv[j], cq[j]);
+            ck[j] = fmaf(s0, (float)qv[j], ck[j]);
+            cv[j] = fmaf(om, (float)dv[j], cv[j]);
         }
-    red[0][part][d] = cq;
-    red[1][part][d] = ck;
-    red[2][part][d] = cv;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[0][sl][ch * 8 + j] = cq[j];
+        red[1][sl][ch * 8 + j] = ck[j];
+        red[2][sl][ch * 8 + j] = cv[j];
+    }
     __syncthreads();
-    if (threadIdx.x < 64 && d < DH) {
+    const int d = threadIdx.x & 63, w3 = threadIdx.x >> 6;      // waves 0..2 finish q, k, v
+    if (w3 < 3 && d < DH) {
+        float t = 0.f;
+        for (int k = 0; k < nsl; ++k) t += red[w3][k][d];
         float* out = c + (long)p * 3 * E + h * DH + d;
-        out[0] = (red[0][0][d] + red[0][1][d] + red[0][2][d] + red[0][3][d]) * inv_sqrt_dh;
-        out[E] = -(red[1][0][d] + red[1][1][d] + red[1][2][d] + red[1][3][d]) * inv_qscale;
-        out[2 * E] = red[2][0][d] + red[2][1][d] + red[2][2][d] + red[2][3][d];
+        if (w3 == 0) out[0] = t * inv_sqrt_dh;
+        else if (w3 == 1) out[E] = -t * inv_qscale;
+        else out[2 * E] = t;
     }
 }
 

@@ -73,13 +73,16 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
 }
 
 // sums[k] = sum over blocks of part[blk*4 + k]  (deterministic second stage)
-__global__ __launch_bounds__(256) void seg_loss_reduce_kernel(const float* __restrict__ part, float* __restrict__ sums, long nblk) {
+__global__ __launch_bounds__(1024) void seg_loss_reduce_kernel(const float* __restrict__ part, float* __restrict__ sums, long nblk) {
     __shared__ float red[16];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long i = threadIdx.x; i < nblk; i += 1024) {          // one 16-byte load per partial block
+        const float4 v = *reinterpret_cast<const float4*>(part + i * 4);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+    }
     for (int k = 0; k < 4; ++k) {
-        float s = 0.f;
-        for (long i = threadIdx.x; i < nblk; i += 256) s += part[i * 4 + k];
-        s = block_sum(s, red);
-        if (threadIdx.x == 0) sums[k] = s;
+        const float t = block_sum(s[k], red);
+        if (threadIdx.x == 0) sums[k] = t;
         __syncthreads();
     }
 }
@@ -93,7 +96,7 @@ extern "C" int wc_seg_loss_fwd(const float* seg, const int64_t* label, float* pa
     hipLaunchKernelGGL(seg_loss_kernel<false>, grid, dim3(256), 0, st, seg, (const long*)label, part, nullptr, nullptr, nc,
                        h, w, H, W, (float)h / H, (float)w / W, ignore);
     WC_LAUNCH_CHECK("seg_loss_kernel<fwd>");
-    hipLaunchKernelGGL(seg_loss_reduce_kernel, dim3(1), dim3(256), 0, st, part, sums, (long)grid.x * grid.y * grid.z);
+    hipLaunchKernelGGL(seg_loss_reduce_kernel, dim3(1), dim3(1024), 0, st, part, sums, (long)grid.x * grid.y * grid.z);
     WC_LAUNCH_CHECK("seg_loss_reduce_kernel");
     return WC_OK;
 }
@@ -182,7 +185,7 @@ extern "C" int wc_aff_loss_fwd(const float* attn_pred, const int64_t* cam_label,
     hipLaunchKernelGGL(aff_loss_kernel<false>, grid, dim3(256), (size_t)h * w * 4, st, attn_pred, (const long*)cam_label, part,
                        nullptr, nullptr, h, w, H, W, radius, ignore);
     WC_LAUNCH_CHECK("aff_loss_kernel<fwd>");
-    hipLaunchKernelGGL(seg_loss_reduce_kernel, dim3(1), dim3(256), 0, st, part, sums, (long)grid.x * grid.y);
+    hipLaunchKernelGGL(seg_loss_reduce_kernel, dim3(1), dim3(1024), 0, st, part, sums, (long)grid.x * grid.y);
     WC_LAUNCH_CHECK("seg_loss_reduce_kernel");
     return WC_OK;
 }
