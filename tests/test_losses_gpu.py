@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("B,nc,h,w,scale", [(2, 21, 4, 6, 16), (1, 5, 7, 5, 16), (2, 21, 32, 32, 16),
-                                           (1, 4, 5, 7, 9.5), (1, 3, 12, 10, 1)])
+                                           (1, 4, 5, 7, 9.5), (1, 3, 12, 10, 1), (1, 40, 4, 6, 16)])
 def test_fused_seg_loss_forward_backward(B, nc, h, w, scale):
     from weclip_vit_comer_amd.utils.losses import get_seg_loss_fused
     g = torch.Generator().manual_seed(h)
