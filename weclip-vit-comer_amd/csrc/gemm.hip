@@ -793,8 +793,16 @@ __global__ __launch_bounds__(256) void sum_slices_wb_kernel(const float* __restr
     const long n = (long)rows * (cols + 1);
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < nslices; ++k) s += part[(long)k * n + i];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // 4 slice loads in flight
+    int k = 0;
+    for (; k + 4 <= nslices; k += 4) {
+        s0 += part[(long)k * n + i];
+        s1 += part[(long)(k + 1) * n + i];
+        s2 += part[(long)(k + 2) * n + i];
+        s3 += part[(long)(k + 3) * n + i];
+    }
+    for (; k < nslices; ++k) s0 += part[(long)k * n + i];
+    const float s = (s0 + s1) + (s2 + s3);
     const int r = (int)(i / (cols + 1)), c = (int)(i - (long)r * (cols + 1));
     if (c < cols) out_w[(long)r * cols + c] = s * alpha;
     else out_b[r] = s * alpha;
