@@ -135,3 +135,24 @@ def test_train_step_bucket_gradients_match_autograd_path():
     assert l0 == l1
     assert g0.abs().max().item() > 0
     assert torch.equal(g0, g1)
+
+
+@pytest.mark.parametrize("hw,labels", [((80, 112), [[1], [2, 5, 9], [0, 3]]), ((48, 64), [[4, 11, 17, 19]])])
+def test_ragged_batches_and_sizes_match_oracle(hw, labels):
+    """Odd batch (3: not a multiple of the 8 XCDs), a different number of classes per image (1 / 3 / 2 / 4) and
+    non-square token grids, whole forward vs the CPU oracle."""
+    from oracle import weclip_oracle as O
+    Hh, Ww = hw
+    m = _model()
+    imgs = synth.make_images(len(labels), Hh, Ww, seed=21)
+    seg, lab, ap = m(imgs.cuda(), ["x"] * len(labels), labels=labels)
+    sd = synth.make_clip_state_dict(**synth.TINY)
+    bg, fg = synth.make_text_features(20, 25, synth.TINY["embed_dim"])
+    fuse, dec = synth.make_head_state_dicts(width=synth.TINY["width"])
+    rseg, rlab, rap = O.weclip_forward(imgs, labels, sd, fuse, dec, bg, fg, heads=1)[:3]
+    e_seg = ((seg.detach().cpu() - rseg).abs().max() / rseg.abs().max()).item()
+    e_ap = (ap.detach().cpu() - rap).abs().max().item()
+    mism = (lab.cpu() != rlab).float().mean().item()
+    print(f"ragged {hw} {labels}: seg rel {e_seg:.2e}  attn_pred abs {e_ap:.2e}  label mismatch {mism:.3%}")
+    assert e_seg < 5e-3 and e_ap < 5e-3 and mism < 0.02
+    assert set(lab.unique().tolist()) <= set([0, 255] + [c + 1 for l in labels for c in l])
