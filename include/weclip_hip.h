@@ -149,6 +149,14 @@ int wc_split_f16(const float* x, void* hi, void* lo, long n, void* stream);
  * {src, hi, lo|0, hiT|0, loT|0, R, C, ldT}.  Replaces the per-layer `.half()` / `.t()` of the trainable weights. */
 int wc_convert_weights(const int64_t* table, int count, int blocks_per_tensor, void* stream);
 
+/* One AdamW step over many fp32 parameter tensors in one launch (reference utils/optimizer.py:3-33: torch.optim.AdamW
+ * with the poly-warm-up lr written per group).  table (device): count rows of 8 int64 {param, grad, exp_avg, exp_avg_sq,
+ * numel, 0, 0, 0}.  p *= 1 - lr*wd; m = lerp(m, g, 1-b1); v = v*b2 + (1-b2) g^2; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+ * with bias_correction{1,2} = 1 - beta^step (the update order of torch._multi_tensor_adam). */
+int wc_adamw_multi(const int64_t* table, int count, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, double bias_correction1, double bias_correction2, int blocks_per_tensor,
+                   void* stream);
+
 /* ---- LayerNorm ------------------------------------------------------------------------ */
 /* clip/model.py:177-183 (`LayerNorm.forward`, fp32 math).  x (rows, D) f32 with row stride ldx;
  * outputs (each optional): y32 f32, y16 fp16 hi, y16lo fp16 residual; all dense (rows, D). */

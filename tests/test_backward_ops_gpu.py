@@ -149,3 +149,37 @@ def test_weight_gradient_gemm_skips_cls_rows():
     ref = dy.double().t() @ tok[:, 1:].reshape(B * hw, C).double()
     got = part.sum(0).cpu().double()
     assert (got[:, :C] - ref).abs().max() / ref.abs().max() < 2e-6
+
+
+def test_fused_adamw_matches_torch_adamw():
+    """PolyWarmupAdamW's one-launch HIP step vs torch.optim.AdamW driven with the same schedule, 5 steps,
+    two parameter groups with different lr / weight decay."""
+    from weclip_vit_comer_amd.utils.optimizer import PolyWarmupAdamW
+    g = torch.Generator().manual_seed(3)
+    shapes = [(257, 33), (64,), (5, 7, 3)]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    grads = [[torch.randn(s, generator=g) * (0.1 + k) for s in shapes] for k in range(5)]
+
+    def make(dev):
+        ps = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+        return ps, [{"params": ps[:2], "lr": 2e-3, "weight_decay": 0.01}, {"params": ps[2:], "lr": 5e-4, "weight_decay": 0.0}]
+
+    ps_h, groups_h = make("cuda")
+    opt_h = PolyWarmupAdamW(groups_h, lr=2e-4, weight_decay=0.01, betas=[0.9, 0.999], warmup_iter=3, max_iter=100,
+                            warmup_ratio=1e-6, power=1.0)
+    ps_t, groups_t = make("cpu")
+    opt_t = PolyWarmupAdamW(groups_t, lr=2e-4, weight_decay=0.01, betas=[0.9, 0.999], warmup_iter=3, max_iter=100,
+                            warmup_ratio=1e-6, power=1.0)      # CPU parameters -> stock torch.optim.AdamW path
+    for k in range(5):
+        for p, gr in zip(ps_h, grads[k]):
+            p.grad = gr.cuda()
+        for p, gr in zip(ps_t, grads[k]):
+            p.grad = gr.clone().double().float()
+        assert opt_h._hip_ok() and not opt_t._hip_ok()
+        opt_h.step()
+        opt_t.step()
+    for a, b in zip(ps_h, ps_t):
+        assert (a.detach().cpu() - b.detach()).abs().max().item() < 2e-6 * max(1.0, b.abs().max().item())
+    sa, sb = opt_h.state[ps_h[0]], opt_t.state[ps_t[0]]
+    assert float(sa["step"]) == float(sb["step"]) == 5
+    assert (sa["exp_avg_sq"].cpu() - sb["exp_avg_sq"]).abs().max().item() < 1e-6 * sb["exp_avg_sq"].abs().max().item()

@@ -341,3 +341,43 @@ extern "C" int wc_convert_weights(const int64_t* table, int count, int blocks_pe
     WC_LAUNCH_CHECK("convert_weights_kernel");
     return WC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// AdamW step over many parameter tensors in ONE launch (reference utils/optimizer.py:3-33 = torch.optim.AdamW with a
+// scheduled lr; torch runs ~10 multi-tensor kernels per group).  table: count rows of 8 int64
+// {param, grad, exp_avg, exp_avg_sq, n, 0, 0, 0}.  Same update order as torch._multi_tensor_adam:
+//   p *= 1 - lr*wd;  m = lerp(m, g, 1-b1);  v = v*b2 + (1-b2)*g*g;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const long* __restrict__ table, float decay, float b2, float w1,
+                                                           float w2, float step_size, float bc2_sqrt, float eps) {
+    const long* e = table + (long)blockIdx.y * 8;
+    float* p = reinterpret_cast<float*>(e[0]);
+    const float* g = reinterpret_cast<const float*>(e[1]);
+    float* m = reinterpret_cast<float*>(e[2]);
+    float* v = reinterpret_cast<float*>(e[3]);
+    const long n = e[4];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i];
+        float pi = p[i] * decay;
+        const float mi = m[i] + w1 * (gi - m[i]);
+        const float vi = v[i] * b2 + (w2 * gi) * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi = pi - step_size * (mi / denom);
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+// Hyper-parameters arrive as doubles and the derived scalars (1 - lr*wd, 1 - beta, lr / bc1, sqrt(bc2)) are formed in
+// double like torch's Python-side arithmetic, then rounded once to fp32.
+extern "C" int wc_adamw_multi(const int64_t* table, int count, double lr, double beta1, double beta2, double eps,
+                              double weight_decay, double bias_correction1, double bias_correction2, int blocks_per_tensor,
+                              void* stream) {
+    WC_CHECK_ARG(table && count > 0 && count <= 65535 && blocks_per_tensor > 0 && bias_correction1 > 0 && bias_correction2 > 0,
+                 "wc_adamw_multi: bad argument");
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3(blocks_per_tensor, count), dim3(256), 0, (hipStream_t)stream, (const long*)table,
+                       (float)(1.0 - lr * weight_decay), (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
+                       (float)(lr / bias_correction1), (float)sqrt(bias_correction2), (float)eps);
+    WC_LAUNCH_CHECK("adamw_multi_kernel");
+    return WC_OK;
+}

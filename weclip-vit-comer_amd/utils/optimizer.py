@@ -25,6 +25,58 @@ class PolyWarmupAdamW(torch.optim.AdamW):
         if m is not None:
             for g, base in zip(self.param_groups, self._base_lr):
                 g["lr"] = base * m
-        out = super().step(closure)
+        if closure is None and self._hip_ok():
+            out = self._hip_step()
+        else:
+            out = super().step(closure)
         self.global_step += 1
         return out
+
+    # ---- one-launch-per-group HIP path (csrc/train_ops.hip adamw_multi_kernel) --------------------------------
+    def _hip_ok(self):
+        for g in self.param_groups:
+            if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
+                return False
+            for p in g["params"]:
+                if p.grad is not None and not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+                                               and p.grad.is_cuda and p.grad.dtype == torch.float32
+                                               and p.grad.is_contiguous() and not p.grad.is_sparse):
+                    return False
+        return True
+
+    @torch.no_grad()
+    def _hip_step(self):
+        from .. import _lib as L
+        if not hasattr(self, "_hip"):
+            self._hip = {}
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in params)
+            st = self._hip.get(gi)
+            if st is None or st["key"] != key:
+                dev = params[0].device
+                rows = []
+                for p in params:
+                    s = self.state[p]
+                    if len(s) == 0:        # same state layout as torch.optim.AdamW (checkpoints interoperate)
+                        s["step"] = torch.tensor(0.0, dtype=torch.float32)
+                        s["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        s["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    rows.append([p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(),
+                                 p.numel(), 0, 0, 0])
+                st = self._hip[gi] = {"key": key, "count": len(rows),
+                                      "table": torch.tensor(rows, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)}
+            for p in params:
+                self.state[p]["step"] += 1
+            step = float(self.state[params[0]]["step"])
+            b1, b2 = group["betas"]
+            L.lib().wc_adamw_multi(L.ptr(st["table"], torch.int64, "table"), st["count"], float(group["lr"]), float(b1),
+                                   float(b2), float(group["eps"]), float(group["weight_decay"]), 1.0 - b1 ** step,
+                                   1.0 - b2 ** step, 64, L.stream())
+            inc = getattr(torch.autograd.graph, "increment_version", None)
+            if inc is not None:            # the update happened below torch's view: bump the version counters
+                for p in params:           # (autograd's saved-tensor checks, ops.WeightCache)
+                    inc(p)
+        return None
