@@ -53,17 +53,21 @@ class PolyWarmupAdamW(torch.optim.AdamW):
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
                 continue
-            key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in params)
+            for p in params:
+                s = self.state[p]
+                if len(s) == 0:            # same state layout as torch.optim.AdamW (checkpoints interoperate)
+                    s["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    s["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    s["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            # pointer table, rebuilt whenever a tensor was replaced (first step, load_state_dict, new .grad)
+            key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
+                         self.state[p]["exp_avg_sq"].data_ptr(), p.numel()) for p in params)
             st = self._hip.get(gi)
             if st is None or st["key"] != key:
                 dev = params[0].device
                 rows = []
                 for p in params:
                     s = self.state[p]
-                    if len(s) == 0:        # same state layout as torch.optim.AdamW (checkpoints interoperate)
-                        s["step"] = torch.tensor(0.0, dtype=torch.float32)
-                        s["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                        s["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     rows.append([p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(),
                                  p.numel(), 0, 0, 0])
                 st = self._hip[gi] = {"key": key, "count": len(rows),
