@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __half* __restrict_
 
 // ------------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256) void attn_mean_kernel(const __half* __restrict__ qkv,
+__global__ __launch_bounds__(256, 2) void attn_mean_kernel(const __half* __restrict__ qkv,
                                                          const float* __restrict__ lse,
                                                          float* __restrict__ mean, int L, int H, int E, int origin,
                                                          int nt, int Bn) {

@@ -53,6 +53,7 @@ struct GemmArgs {
     const float* cscale;  // optional per-batch column scale after bias: v *= cscale[z*sCS + n] (Dropout2d)
     long sCS;
     int gx, gy;           // tile grid (N tiles, M tiles); the launch is 1-D over gx * roundup8(gy)
+    int auxvec;           // act 5: auxh rows are 8-byte addressable per 4 columns
     int vec;              // outputs / residual are 16-byte addressable per 4 columns: LDS-transposed wide epilogue
 };
 
@@ -156,7 +157,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                         }
                     } else {
                         const __half* hp = g.auxh + (long)grow * g.ldaux + gcol;
-                        for (int k = 0; k < 4 && gcol + k < g.N; ++k) f[it][k] *= __half2float(hp[k]) > 0.f ? 1.f : 0.f;   // ReLU'
+                        if (full && g.auxvec) {          // one 8-byte load of the four saved activations
+                            typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
+                            const f16x4_ hv = *reinterpret_cast<const f16x4_*>(hp);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) f[it][k] *= (float)hv[k] > 0.f ? 1.f : 0.f;
+                        } else {
+                            for (int k = 0; k < 4 && gcol + k < g.N; ++k) f[it][k] *= __half2float(hp[k]) > 0.f ? 1.f : 0.f;   // ReLU'
+                        }
                     }
                 }
             }
@@ -766,7 +774,7 @@ extern "C" int wc_gemm_km_f16(const void* dY, long lda, const void* X, long ldx,
     e.sC = (long)N * K1; e.sR = 0; e.bias = nullptr; e.resid = nullptr; e.ldr = 0;
     e.C32 = part; e.C16 = nullptr; e.C16lo = nullptr; e.ldc = K1; e.act = 0; e.round16 = 0; e.scale = 1.f; e.scale_cols = 0;
     e.P32 = nullptr; e.aux = nullptr; e.rowmap = nullptr; e.rpg = 1; e.ldaux = 0; e.auxh = nullptr; e.cscale = nullptr;
-    e.sCS = 0; e.gx = g.gx; e.gy = wc_cdiv(N, 128); e.vec = 0;
+    e.sCS = 0; e.gx = g.gx; e.gy = wc_cdiv(N, 128); e.vec = 0; e.auxvec = 0;
     dim3 grid((unsigned)(g.gx * wc_cdiv(N, 128)), 1, ns);
     const int pr = wc_prof_begin(stream);
     hipLaunchKernelGGL(gemm_km_kernel, grid, dim3(256), 4 * 64 * 256, (hipStream_t)stream, g);
@@ -880,6 +888,7 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
              (!C32 || (uintptr_t)C32 % 16 == 0) && (!C16 || (uintptr_t)C16 % 8 == 0) && (!C16lo || (uintptr_t)C16lo % 8 == 0) &&
              (act != 4 || (ldaux % 4 == 0 && (uintptr_t)aux % 16 == 0)))
                 ? 1 : 0;
+    g.auxvec = (act == 5 && ldaux % 4 == 0 && (uintptr_t)auxh % 8 == 0) ? 1 : 0;
     g.gx = wc_cdiv(N, BN);
     const int plan = gemm_plan(M, N, K, nseg, batch, act == 4 && rowmap);
     if (plan) {   // tall GEMM: 256x256 ping-pong kernel

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const __half* __restric
 // (i) u[p,h,l] = sum_q dS[q,l];  column 0:  dS0[p,h,q] = dS[q,0], P0[p,h,q] = P[q,0].
 // grid (key tiles of 128, H, P); 4 waves as 2(q) x 2(key), 128-row q tiles streamed through LDS.
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_colsum_kernel(const __half* __restrict__ qkv,
+__global__ __launch_bounds__(256, 2) void attn_bwd_colsum_kernel(const __half* __restrict__ qkv,
                                                                const __half* __restrict__ dO,
                                                                const float* __restrict__ lse,
                                                                const float* __restrict__ delta,
