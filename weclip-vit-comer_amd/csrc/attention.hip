@@ -33,7 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const __half* __restrict__ qkv,
+__global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const __half* __restrict__ qkv,
                                                         __half* __restrict__ out,
                                                         float* __restrict__ out32,
                                                         float* __restrict__ lse, int L, int H,
