@@ -69,7 +69,7 @@ __device__ __forceinline__ void store_split4(__half* hi, __half* lo, const float
 
 // ------------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const __half* __restrict__ qkv, const __half* __restrict__ kt,
+__global__ __launch_bounds__(256, (DH == 32 ? 3 : 1)) void attn_bwd_dq_kernel(const __half* __restrict__ qkv, const __half* __restrict__ kt,
                                                            const __half* __restrict__ dO, const float* __restrict__ lse,
                                                            const float* __restrict__ delta, __half* __restrict__ dhi,
                                                            __half* __restrict__ dlo, int L, int Lp, int H, int E) {
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const __half* __restri
 
 // ------------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const __half* __restrict__ qkv, const __half* __restrict__ qt,
+__global__ __launch_bounds__(256, (DH == 32 ? 3 : 1)) void attn_bwd_dkdv_kernel(const __half* __restrict__ qkv, const __half* __restrict__ qt,
                                                              const __half* __restrict__ dot, const __half* __restrict__ dO,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              __half* __restrict__ dhi, __half* __restrict__ dlo, int L, int Lp,
