@@ -337,7 +337,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_colsum_kernel(const __half* _
     constexpr int CH = DH / 8;
     constexpr int NC = 128 * CH / 256;
     constexpr int QBUF = 2 * TB + 1024;   // Q tile | dO tile | lse[128] | delta[128]
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // K | V | 2 x QBUF | red[2][128]
+    // K | V | QBUF | red[2][128]: ONE q-tile buffer (76 KiB in all) so that two workgroups share a CU; the next
+    // tile waits in registers during the MFMAs and is stored between two barriers
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, l31 = lane & 31, wr = wave >> 1, wc = wave & 1;
     // XCD-aware order: the key tiles of one (pair, head) run back to back on one XCD, which then streams that
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_colsum_kernel(const __half* _
     char* Ks = smem;
     char* Vs = smem + TB;
     char* Qs = smem + 2 * TB;
-    float* red = reinterpret_cast<float*>(smem + 2 * TB + 2 * QBUF);
+    float* red = reinterpret_cast<float*>(smem + 2 * TB + QBUF);
 
     // K, V tiles of this key block (rows clamped; padded keys are masked by zero dS below)
 #pragma unroll
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_colsum_kernel(const __half* _
     __syncthreads();
     const bool col0 = (k0 == 0 && wc == 0 && l31 == 0);
     for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
+        const int buf = 0;
         if (t + 1 < nt) GLOAD(t + 1);
         const char* base = Qs + buf * QBUF;
         const float* ls = reinterpret_cast<const float*>(base + 2 * TB);
@@ -465,7 +467,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_colsum_kernel(const __half* _
                         }
                     }
                 }
-        if (t + 1 < nt) LSTORE(buf ^ 1);
+        __syncthreads();                       // every wave is done reading the q-tile buffer
+        if (t + 1 < nt) LSTORE(0);
         __syncthreads();
     }
 #pragma unroll
@@ -707,14 +710,14 @@ extern "C" int wc_attn_bwd_colsum(const void* qkv, const void* dO, const float* 
     const int nkt = wc_cdiv(L - origin, 128), PH = P * H;
     dim3 grid((unsigned)(nkt * ((PH + 7) / 8 * 8)));
     if (DH == 64) {
-        const size_t lds = 2 * 128 * (64 * 2 + 16) + 2 * (2 * 128 * (64 * 2 + 16) + 1024) + 1024;
+        const size_t lds = 2 * 128 * (64 * 2 + 16) + (2 * 128 * (64 * 2 + 16) + 1024) + 1024;
         hipLaunchKernelGGL(attn_bwd_colsum_kernel<64>, grid, dim3(256), lds, st, (const __half*)qkv,
                            (const __half*)dO, lse, delta, pair_img, u, dS0, P0, L, H, E, origin, nkt, PH);
         if (origin)
             hipLaunchKernelGGL(attn_bwd_colsum_edge_kernel<64>, dim3(H, P), dim3(256), 0, st, (const __half*)qkv,
                                (const __half*)dO, lse, delta, pair_img, u, dS0, P0, L, H, E, origin);
     } else {
-        const size_t lds = 2 * 128 * (32 * 2 + 16) + 2 * (2 * 128 * (32 * 2 + 16) + 1024) + 1024;
+        const size_t lds = 2 * 128 * (32 * 2 + 16) + (2 * 128 * (32 * 2 + 16) + 1024) + 1024;
         hipLaunchKernelGGL(attn_bwd_colsum_kernel<32>, grid, dim3(256), lds, st, (const __half*)qkv,
                            (const __half*)dO, lse, delta, pair_img, u, dS0, P0, L, H, E, origin, nkt, PH);
         if (origin)
