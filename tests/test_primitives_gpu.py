@@ -126,6 +126,15 @@ def test_gemm_ragged_rows_split(ops):
     lo = torch.zeros_like(hi)
     ops.gemm(a.cuda(), w.cuda(), M, N, K, bias=bias.cuda(), out16=hi, out16lo=lo)
     assert _rel((hi.float() + lo.float()).cpu().double(), ref) < 2e-6
+    # QuickGELU' from a row-mapped pre-activation (GradCAM: 16 (image, class) pairs of 1025 rows reading 8 images)
+    rpg = 1025
+    rowmap = torch.tensor([3, 3, 0, 7, 1, 1, 2, 5, 6, 6, 4, 0, 2, 7, 5, 4], dtype=torch.int32)
+    u = torch.randn(8 * rpg, N, generator=g)
+    ops.gemm(a.cuda(), w.cuda(), M, N, K, out32=out, act=4, aux=u.cuda(), rowmap=rowmap.cuda(), rpg=rpg, ldaux=N)
+    um = u.view(8, rpg, N)[rowmap.long()].reshape(M, N).double()
+    sg = torch.sigmoid(1.702 * um)
+    ref4 = (a.double() @ w.double().t()) * (sg * (1 + 1.702 * um * (1 - sg)))
+    assert _rel(out.cpu().double(), ref4) < 2e-6
 
 
 def test_gemm_batched(ops):

@@ -47,6 +47,7 @@ struct GemmArgs {
     float* P32;           // optional fp32 copy of the pre-activation value (acc + bias)
     const float* aux;     // act 4: v *= QuickGELU'(aux[arow*ldaux + n]), arow = rowmap[m / rpg]*rpg + m % rpg
     const int* rowmap;
+    int row0;             // row index of this launch's first row in the caller's matrix (rowmap arithmetic after a row split)
     int rpg;
     long ldaux;
     const __half* auxh;   // act 5: v *= (auxh[m*ldaux + n] > 0)  (ReLU backward from the saved fp16 output)
@@ -145,7 +146,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                     if (!ok[it]) continue;
                     const int grow = m0 + wr * 64 + c * 16 + it * 4 + (lane >> 4);
                     if (act == 4) {
-                        const long arow = g.rowmap ? (long)g.rowmap[grow / g.rpg] * g.rpg + grow % g.rpg : grow;
+                        const long arow = g.rowmap ? (long)g.rowmap[(grow + g.row0) / g.rpg] * g.rpg + (grow + g.row0) % g.rpg : grow;
                         const float* up = g.aux + arow * g.ldaux + gcol;
                         float u[4] = {0.f, 0.f, 0.f, 0.f};
                         if (full) { const float4 u4 = *reinterpret_cast<const float4*>(up); u[0] = u4.x; u[1] = u4.y; u[2] = u4.z; u[3] = u4.w; }
@@ -245,7 +246,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                     int row = rbase + (r & 3) + 8 * (r >> 2);
                     if (row > g.M - 1) row = g.M - 1;
                     if (act == 4) {
-                        const long arow = g.rowmap ? (long)g.rowmap[row / g.rpg] * g.rpg + row % g.rpg : row;
+                        const long arow = g.rowmap ? (long)g.rowmap[(row + g.row0) / g.rpg] * g.rpg + (row + g.row0) % g.rpg : row;
                         const float u = g.aux[arow * g.ldaux + colc];
                         const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u));
                         uv[r] = sg * (1.0f + 1.702f * u * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
@@ -773,7 +774,7 @@ extern "C" int wc_gemm_km_f16(const void* dY, long lda, const void* X, long ldx,
     e.nseg = 1; e.M = N; e.N = K1; e.K = 0; e.lda = e.ldw = 0; e.sA = e.sW = 0;
     e.sC = (long)N * K1; e.sR = 0; e.bias = nullptr; e.resid = nullptr; e.ldr = 0;
     e.C32 = part; e.C16 = nullptr; e.C16lo = nullptr; e.ldc = K1; e.act = 0; e.round16 = 0; e.scale = 1.f; e.scale_cols = 0;
-    e.P32 = nullptr; e.aux = nullptr; e.rowmap = nullptr; e.rpg = 1; e.ldaux = 0; e.auxh = nullptr; e.cscale = nullptr;
+    e.P32 = nullptr; e.aux = nullptr; e.rowmap = nullptr; e.row0 = 0; e.rpg = 1; e.ldaux = 0; e.auxh = nullptr; e.cscale = nullptr;
     e.sCS = 0; e.gx = g.gx; e.gy = wc_cdiv(N, 128); e.vec = 0; e.auxvec = 0;
     dim3 grid((unsigned)(g.gx * wc_cdiv(N, 128)), 1, ns);
     const int pr = wc_prof_begin(stream);
@@ -881,7 +882,7 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
     g.sA = sA; g.sW = sW; g.sC = sC; g.sR = sR; g.bias = bias; g.resid = resid; g.ldr = ldr;
     g.C32 = C32; g.C16 = (__half*)C16; g.C16lo = (__half*)C16lo; g.ldc = ldc;
     g.act = act; g.round16 = round16; g.scale = scale; g.scale_cols = scale_cols;
-    g.P32 = P32; g.aux = aux; g.rowmap = rowmap; g.rpg = rpg > 0 ? rpg : 1; g.ldaux = ldaux;
+    g.P32 = P32; g.aux = aux; g.rowmap = rowmap; g.row0 = 0; g.rpg = rpg > 0 ? rpg : 1; g.ldaux = ldaux;
     g.auxh = (const __half*)auxh; g.cscale = cscale; g.sCS = sCS;
     // wide epilogue needs every 4-column group of a row 16-B (fp32) / 8-B (fp16) addressable
     g.vec = (ldc % 4 == 0 && sC % 4 == 0 && (!resid || (ldr % 4 == 0 && sR % 4 == 0 && (uintptr_t)resid % 16 == 0)) &&
@@ -890,7 +891,7 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
                 ? 1 : 0;
     g.auxvec = (act == 5 && ldaux % 4 == 0 && (uintptr_t)auxh % 8 == 0) ? 1 : 0;
     g.gx = wc_cdiv(N, BN);
-    const int plan = gemm_plan(M, N, K, nseg, batch, act == 4 && rowmap);
+    const int plan = gemm_plan(M, N, K, nseg, batch, false);
     if (plan) {   // tall GEMM: 256x256 ping-pong kernel
         g.gx = wc_cdiv(N, 256);
         g.gy = wc_cdiv(M, 256);
@@ -926,7 +927,8 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
         if (g.C16) g.C16 += (long)m_main * ldc;
         if (g.C16lo) g.C16lo += (long)m_main * ldc;
         if (g.P32) g.P32 += (long)m_main * ldc;
-        if (g.aux) g.aux += (long)m_main * ldaux;
+        if (g.aux && !g.rowmap) g.aux += (long)m_main * ldaux;
+        if (g.rowmap) g.row0 = m_main;          // row-mapped aux rows: keep the pointer, shift the row index
         if (g.auxh) g.auxh += (long)m_main * ldaux;
         g.M = M = m_rem;
         g.gx = wc_cdiv(N, BN);
