@@ -32,6 +32,85 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define NEG_BIG (-1.0e30f)
 
 // ------------------------------------------------------------------------------------------------
+// The first `q_origin` query rows of every (b, h): one workgroup per row.  scores -> LDS, block max / sum,
+// P rounded to fp16 like the MFMA operand of the tiled kernel, O = P V with lanes along dh.
+// Runs as extra workgroups of attn_fwd_kernel (they fill CU slots as the tiled workgroups drain).
+// lds: >= (L + 16 + (256 / (DH / 8)) * DH) floats.
+template <int DH>
+__device__ __forceinline__ void attn_row_body(const __half* __restrict__ qkv, __half* __restrict__ out,
+                                              float* __restrict__ out32, float* __restrict__ lse, int L, int H,
+                                              int E, int q, int h, int b, float* lds) {
+    constexpr int NCH = DH / 8;              // 16-B chunks per row
+    constexpr int NPT = 256 / NCH;           // key slices in the P V pass
+    float* sc = lds;                         // [L] scores, then probabilities
+    float* red = lds + ((L + 3) & ~3);
+    float (*part)[DH] = reinterpret_cast<float (*)[DH]>(red + 16);
+    const int tid = threadIdx.x;
+    const long ldq = 3L * E;
+    const __half* base = qkv + (long)b * L * ldq + (long)h * DH;
+    f16x8 qv[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) qv[c] = *reinterpret_cast<const f16x8*>(base + (long)q * ldq + c * 8);
+    float mx = NEG_BIG;
+    for (int key = tid; key < L; key += 256) {
+        const __half* kr = base + E + (long)key * ldq;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const f16x8 kv = *reinterpret_cast<const f16x8*>(kr + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s = fmaf((float)qv[c][j], (float)kv[j], s);
+        }
+        sc[key] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = block_max(mx, red);
+    float sum = 0.f;
+    for (int key = tid; key < L; key += 256) {
+        const float pr = __builtin_amdgcn_exp2f(sc[key] - mx);
+        sum += pr;
+        sc[key] = (float)(_Float16)pr;
+    }
+    sum = block_sum(sum, red);               // (its barriers also publish sc[])
+    // O = P V: thread = (16-B dh chunk, key slice); 4 row loads in flight per thread
+    const int ch = tid % NCH, pt = tid / NCH;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    const __half* vcol = base + 2 * E + ch * 8;
+    int key = pt;
+    for (; key + 3 * NPT < L; key += 4 * NPT) {
+        f16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(vcol + (long)(key + u * NPT) * ldq);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float pr = sc[key + u * NPT];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = fmaf(pr, (float)v[u][j], o[j]);
+        }
+    }
+    for (; key < L; key += NPT) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(vcol + (long)key * ldq);
+        const float pr = sc[key];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaf(pr, (float)v[j], o[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[pt][ch * 8 + j] = o[j];
+    __syncthreads();
+    if (tid < DH) {
+        float v = 0.f;
+        for (int k = 0; k < NPT; ++k) v += part[k][tid];
+        v /= sum;
+        const long oi = ((long)b * L + q) * E + (long)h * DH + tid;
+        out[oi] = __float2half(v);
+        if (out32) out32[oi] = v;
+        if (tid == 0) lse[((long)b * H + h) * L + q] = mx + log2f(sum);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const __half* __restrict__ qkv,
                                                         __half* __restrict__ out,
@@ -54,6 +133,13 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const __half* __restri
     // images, heads in turn, the q blocks of a head back to back -- K/V of a (b, h) are then fetched from HBM
     // once instead of once per XCD (measured: 458 MB -> per-launch traffic near the 100 MB algorithmic).
     const int per_img = nqb * H;
+    const int main_blocks = per_img * ((Bn + 7) / 8 * 8);
+    if ((int)blockIdx.x >= main_blocks) {        // remainder rows [0, q_origin): one workgroup per (row, head, image)
+        const int e = blockIdx.x - main_blocks;
+        const int hb = e / q_origin;
+        attn_row_body<DH>(qkv, out, out32, lse, L, H, E, e - hb * q_origin, hb % H, hb / H, reinterpret_cast<float*>(smem));
+        return;
+    }
     const int slot = blockIdx.x >> 3;
     const int b = (slot / per_img) * 8 + (blockIdx.x & 7);
     if (b >= Bn) return;
@@ -230,6 +316,42 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const __half* __restri
     }
 }
 
+// mean_h P_h for the entries the origin-shifted tiles leave out: rows q < r (all keys) and columns k < r (q >= r).
+// Runs as extra workgroups of attn_mean_kernel: `blk` = edge-block index inside image b (16 entries per block).
+template <int DH>
+__device__ __forceinline__ void attn_mean_edge_body(const __half* __restrict__ qkv, const float* __restrict__ lse,
+                                                    float* __restrict__ mean, int L, int H, int E, int r, int blk, int b) {
+    // 16 lanes per entry, one head each (heads 16, 32, .. loop); the 16-lane group sums the heads
+    const int hl = threadIdx.x & 15;
+    const long e = (long)blk * 16 + (threadIdx.x >> 4);
+    const long nrow = (long)r * L;                    // entries of the first r rows
+    const long ncol = (long)r * (L - r);              // remaining entries of the first r columns
+    const bool live = e < nrow + ncol;
+    int q = 0, k = 0;
+    if (live) {
+        if (e < nrow) { q = (int)(e / L); k = (int)(e - (long)q * L); }
+        else { const long f = e - nrow; k = (int)(f / (L - r)); q = r + (int)(f - (long)k * (L - r)); }
+    }
+    const long ldq = 3L * E;
+    const __half* qr = qkv + ((long)b * L + q) * ldq;
+    const __half* kr = qkv + ((long)b * L + k) * ldq + E;
+    float acc = 0.f;
+    for (int h = hl; h < H; h += 16) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH / 8; ++c) {
+            const f16x8 a = *reinterpret_cast<const f16x8*>(qr + h * DH + c * 8);
+            const f16x8 w = *reinterpret_cast<const f16x8*>(kr + h * DH + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s = fmaf((float)a[j], (float)w[j], s);
+        }
+        acc += __builtin_amdgcn_exp2f(s - lse[((long)b * H + h) * L + q]);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (live && hl == 0) mean[(long)b * L * L + (long)q * L + k] = acc / H;
+}
+
 // ------------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_mean_kernel(const __half* __restrict__ qkv,
@@ -249,6 +371,14 @@ __global__ __launch_bounds__(256, 2) void attn_mean_kernel(const __half* __restr
     const int wr = wave >> 1, wc = wave & 1;
     // XCD-aware order (see attn_fwd_kernel): one XCD walks all tiles of an image, so that image's Q and K
     // (2 x L x E halves, ~3 MB) stay in its L2 across the nt x nt tiles
+    const int main_blocks = nt * nt * ((Bn + 7) / 8 * 8);
+    if ((int)blockIdx.x >= main_blocks) {        // edge entries (rows / columns < origin), 16 per workgroup
+        const long nedge = (long)origin * L + (long)origin * (L - origin);
+        const int per_img = (int)((nedge + 15) / 16);
+        const int e = blockIdx.x - main_blocks;
+        attn_mean_edge_body<DH>(qkv, lse, mean, L, H, E, origin, e % per_img, e / per_img);
+        return;
+    }
     const int slot = blockIdx.x >> 3;
     const int b = (slot / (nt * nt)) * 8 + (blockIdx.x & 7);
     if (b >= Bn) return;
@@ -359,119 +489,6 @@ __global__ __launch_bounds__(256, 2) void attn_mean_kernel(const __half* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// The first `nrows` query rows of every (b, h): one workgroup per row.  scores -> LDS, block max / sum,
-// P rounded to fp16 like the MFMA operand of the tiled kernel, O = P V with lanes along dh.
-template <int DH>
-__global__ __launch_bounds__(256) void attn_rows_kernel(const __half* __restrict__ qkv, __half* __restrict__ out,
-                                                         float* __restrict__ out32, float* __restrict__ lse, int L, int H,
-                                                         int E) {
-    extern __shared__ float sc[];            // [L] scores, then probabilities
-    __shared__ float red[16];
-    constexpr int NCH = DH / 8;              // 16-B chunks per row
-    constexpr int NPT = 256 / NCH;           // key slices in the P V pass
-    __shared__ float part[NPT][DH];
-    const int tid = threadIdx.x, q = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const long ldq = 3L * E;
-    const __half* base = qkv + (long)b * L * ldq + (long)h * DH;
-    f16x8 qv[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) qv[c] = *reinterpret_cast<const f16x8*>(base + (long)q * ldq + c * 8);
-    float mx = NEG_BIG;
-    for (int key = tid; key < L; key += 256) {
-        const __half* kr = base + E + (long)key * ldq;
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const f16x8 kv = *reinterpret_cast<const f16x8*>(kr + c * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s = fmaf((float)qv[c][j], (float)kv[j], s);
-        }
-        sc[key] = s;
-        mx = fmaxf(mx, s);
-    }
-    mx = block_max(mx, red);
-    float sum = 0.f;
-    for (int key = tid; key < L; key += 256) {
-        const float pr = __builtin_amdgcn_exp2f(sc[key] - mx);
-        sum += pr;
-        sc[key] = (float)(_Float16)pr;
-    }
-    sum = block_sum(sum, red);               // (its barriers also publish sc[])
-    // O = P V: thread = (16-B dh chunk, key slice); 4 row loads in flight per thread
-    const int ch = tid % NCH, pt = tid / NCH;
-    float o[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = 0.f;
-    const __half* vcol = base + 2 * E + ch * 8;
-    int key = pt;
-    for (; key + 3 * NPT < L; key += 4 * NPT) {
-        f16x8 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(vcol + (long)(key + u * NPT) * ldq);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float pr = sc[key + u * NPT];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = fmaf(pr, (float)v[u][j], o[j]);
-        }
-    }
-    for (; key < L; key += NPT) {
-        const f16x8 v = *reinterpret_cast<const f16x8*>(vcol + (long)key * ldq);
-        const float pr = sc[key];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = fmaf(pr, (float)v[j], o[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) part[pt][ch * 8 + j] = o[j];
-    __syncthreads();
-    if (tid < DH) {
-        float v = 0.f;
-        for (int k = 0; k < NPT; ++k) v += part[k][tid];
-        v /= sum;
-        const long oi = ((long)b * L + q) * E + (long)h * DH + tid;
-        out[oi] = __float2half(v);
-        if (out32) out32[oi] = v;
-        if (tid == 0) lse[((long)b * H + h) * L + q] = mx + log2f(sum);
-    }
-}
-
-// mean_h P_h for the entries the origin-shifted tiles leave out: rows q < r (all keys) and columns k < r (q >= r).
-template <int DH>
-__global__ __launch_bounds__(256) void attn_mean_edge_kernel(const __half* __restrict__ qkv, const float* __restrict__ lse,
-                                                              float* __restrict__ mean, int L, int H, int E, int r) {
-    // 16 lanes per entry, one head each (heads 16, 32, .. loop); the 16-lane group sums the heads
-    const int b = blockIdx.y;
-    const int hl = threadIdx.x & 15;
-    const long e = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const long nrow = (long)r * L;                    // entries of the first r rows
-    const long ncol = (long)r * (L - r);              // remaining entries of the first r columns
-    const bool live = e < nrow + ncol;
-    int q = 0, k = 0;
-    if (live) {
-        if (e < nrow) { q = (int)(e / L); k = (int)(e - (long)q * L); }
-        else { const long f = e - nrow; k = (int)(f / (L - r)); q = r + (int)(f - (long)k * (L - r)); }
-    }
-    const long ldq = 3L * E;
-    const __half* qr = qkv + ((long)b * L + q) * ldq;
-    const __half* kr = qkv + ((long)b * L + k) * ldq + E;
-    float acc = 0.f;
-    for (int h = hl; h < H; h += 16) {
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < DH / 8; ++c) {
-            const f16x8 a = *reinterpret_cast<const f16x8*>(qr + h * DH + c * 8);
-            const f16x8 w = *reinterpret_cast<const f16x8*>(kr + h * DH + c * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s = fmaf((float)a[j], (float)w[j], s);
-        }
-        acc += __builtin_amdgcn_exp2f(s - lse[((long)b * H + h) * L + q]);
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (live && hl == 0) mean[(long)b * L * L + (long)q * L + k] = acc / H;
-}
-
-// ------------------------------------------------------------------------------------------------
 // A remainder of at most ATT_EDGE_MAX rows (L % 128) is finished by the row kernels; the tiles then start at it.
 #define ATT_EDGE_MAX 8
 static int attn_origin(int L) {
@@ -484,35 +501,22 @@ extern "C" int wc_attn_fwd(const void* qkv, void* out, float* out32, float* lse,
     const int E = H * DH;
     WC_CHECK_ARG(qkv && out && lse && B > 0 && L > 0, "wc_attn_fwd: bad argument");
     WC_CHECK_ARG(DH == 64 || DH == 32, "wc_attn_fwd: head dim must be 32 or 64 (got %d)", DH);
-    WC_CHECK_ARG(E % 8 == 0 && B <= 65535 && H <= 65535 && (long)L * 4 <= 60 * 1024 &&
-                 (long)wc_cdiv(L, 128) * H * (B + 7) < (1L << 31), "wc_attn_fwd: bad shape");
-    const int r = attn_origin(L);
+    WC_CHECK_ARG(E % 8 == 0 && B <= 65535 && H <= 65535 && (long)wc_cdiv(L, 128) * H * (B + 7) < (1L << 30),
+                 "wc_attn_fwd: bad shape");
+    const size_t lds = DH == 64 ? 2 * (64 * (64 * 2 + 16) + 64 * 128) : 2 * (64 * (32 * 2 + 16) + 64 * 64);
+    int r = attn_origin(L);
+    if (r && ((size_t)L + 4 + 16 + (256 / (DH / 8)) * DH) * 4 > lds) r = 0;     // row path needs its scores in LDS
     const int nqb = wc_cdiv(L - r, 128);
-    dim3 grid((unsigned)(nqb * H * ((B + 7) / 8 * 8)));
+    dim3 grid((unsigned)(nqb * H * ((B + 7) / 8 * 8) + r * H * B));
     hipStream_t st = (hipStream_t)stream;
-    if (DH == 64) {
-        const size_t lds = 2 * (64 * (64 * 2 + 16) + 64 * 128);
-        { const int pr = wc_prof_begin(stream);
+    const int pr = wc_prof_begin(stream);
+    if (DH == 64)
         hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), lds, st, (const __half*)qkv, (__half*)out, out32, lse, L, H,
                            E, r, nqb, B);
-        wc_prof_end(pr, "attn_fwd_kernel<64>", 4.0 * B * H * (double)L * L * DH, stream); }
-        if (r)
-            { const int pr = wc_prof_begin(stream);
-            hipLaunchKernelGGL(attn_rows_kernel<64>, dim3(r, H, B), dim3(256), (size_t)L * 4, st, (const __half*)qkv,
-                               (__half*)out, out32, lse, L, H, E);
-            wc_prof_end(pr, "attn_rows_kernel<64>", 4.0 * B * H * (double)r * L * DH, stream); }
-    } else {
-        const size_t lds = 2 * (64 * (32 * 2 + 16) + 64 * 64);
-        { const int pr = wc_prof_begin(stream);
+    else
         hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), lds, st, (const __half*)qkv, (__half*)out, out32, lse, L, H,
                            E, r, nqb, B);
-        wc_prof_end(pr, "attn_fwd_kernel<32>", 4.0 * B * H * (double)L * L * DH, stream); }
-        if (r)
-            { const int pr = wc_prof_begin(stream);
-            hipLaunchKernelGGL(attn_rows_kernel<32>, dim3(r, H, B), dim3(256), (size_t)L * 4, st, (const __half*)qkv,
-                               (__half*)out, out32, lse, L, H, E);
-            wc_prof_end(pr, "attn_rows_kernel<32>", 4.0 * B * H * (double)r * L * DH, stream); }
-    }
+    wc_prof_end(pr, DH == 64 ? "attn_fwd_kernel<64>" : "attn_fwd_kernel<32>", 4.0 * B * H * (double)L * L * DH, stream);
     WC_LAUNCH_CHECK("attn_fwd_kernel");
     return WC_OK;
 }
@@ -524,32 +528,16 @@ extern "C" int wc_attn_mean(const void* qkv, const float* lse, float* mean, int 
     WC_CHECK_ARG(DH == 64 || DH == 32, "wc_attn_mean: head dim must be 32 or 64 (got %d)", DH);
     const int r = attn_origin(L);
     const int nt = wc_cdiv(L - r, 128);
-    dim3 grid((unsigned)(nt * nt * ((B + 7) / 8 * 8)));
     const long nedge = (long)r * L + (long)r * (L - r);
+    dim3 grid((unsigned)(nt * nt * ((B + 7) / 8 * 8) + wc_cdiv(nedge, 16) * B));
     hipStream_t st = (hipStream_t)stream;
-    if (DH == 64) {
-        const size_t lds = 2 * (2 * 128 * (64 * 2 + 16) + 512);
-        { const int pr = wc_prof_begin(stream);
-        hipLaunchKernelGGL(attn_mean_kernel<64>, grid, dim3(256), lds, st, (const __half*)qkv, lse, mean,
-                           L, H, E, r, nt, B);
-        wc_prof_end(pr, "attn_mean_kernel<64>", 2.0 * B * H * (double)L * L * DH, stream); }
-        if (r)
-            { const int pr = wc_prof_begin(stream);
-            hipLaunchKernelGGL(attn_mean_edge_kernel<64>, dim3(wc_cdiv(nedge, 16), B), dim3(256), 0, st, (const __half*)qkv,
-                               lse, mean, L, H, E, r);
-            wc_prof_end(pr, "attn_mean_edge_kernel<64>", 2.0 * H * DH * (double)nedge * B, stream); }
-    } else {
-        const size_t lds = 2 * (2 * 128 * (32 * 2 + 16) + 512);
-        { const int pr = wc_prof_begin(stream);
-        hipLaunchKernelGGL(attn_mean_kernel<32>, grid, dim3(256), lds, st, (const __half*)qkv, lse, mean,
-                           L, H, E, r, nt, B);
-        wc_prof_end(pr, "attn_mean_kernel<32>", 2.0 * B * H * (double)L * L * DH, stream); }
-        if (r)
-            { const int pr = wc_prof_begin(stream);
-            hipLaunchKernelGGL(attn_mean_edge_kernel<32>, dim3(wc_cdiv(nedge, 16), B), dim3(256), 0, st, (const __half*)qkv,
-                               lse, mean, L, H, E, r);
-            wc_prof_end(pr, "attn_mean_edge_kernel<32>", 2.0 * H * DH * (double)nedge * B, stream); }
-    }
+    const size_t lds = DH == 64 ? 2 * (2 * 128 * (64 * 2 + 16) + 512) : 2 * (2 * 128 * (32 * 2 + 16) + 512);
+    const int pr = wc_prof_begin(stream);
+    if (DH == 64)
+        hipLaunchKernelGGL(attn_mean_kernel<64>, grid, dim3(256), lds, st, (const __half*)qkv, lse, mean, L, H, E, r, nt, B);
+    else
+        hipLaunchKernelGGL(attn_mean_kernel<32>, grid, dim3(256), lds, st, (const __half*)qkv, lse, mean, L, H, E, r, nt, B);
+    wc_prof_end(pr, DH == 64 ? "attn_mean_kernel<64>" : "attn_mean_kernel<32>", 2.0 * B * H * (double)L * L * DH, stream);
     WC_LAUNCH_CHECK("attn_mean_kernel");
     return WC_OK;
 }
