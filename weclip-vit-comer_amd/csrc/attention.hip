@@ -10,7 +10,7 @@
 //   attn_mean_kernel : mean_h P_h = (1/H) sum_h exp2(Q_h K_h^T - LSE_h) for a 128x128 tile,
 //                      the H-head sum held in MFMA accumulators, written once, coalesced
 //                      (the returned `attn_output_weights.sum(dim=1) / num_heads`).
-//   attn_rows_kernel / attn_mean_edge_kernel : the first L % 128 query rows (and key columns) when that
+//   attn_row_body / attn_mean_edge_body (extra workgroups of the two kernels above): the first L % 128 query rows (and key columns) when that
 //                      remainder is tiny (the CLS token of a 1 + 32*32 sequence): a 129th row must not cost
 //                      a whole 128-row tile, so the tiled kernels start at row L % 128 and these finish the rest.
 // V stays row-major [key][dh] (as the in-projection wrote it); the O^T = V^T P^T fragments (8 consecutive keys
