@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--classes-per-image", type=int, default=2)
     ap.add_argument("--precision", default=None, choices=[None, "fast", "exact"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comer", action="store_true",
+                    help="enable the ViT-CoMer inserts (no reference code exists for them; off = the reference model)")
     ap.add_argument("--timer-stride", type=int, default=7,
                     help="HIP-event pair around 1 of every n instrumented kernel launches (0: none, roofline = null)")
     ap.add_argument("--cpu-images", type=int, default=2, help="images in the bounded CPU-oracle sample")
@@ -90,7 +92,7 @@ def main():
     bg, fg = synth.make_text_features(20, 25, 512)
     fuse, dec = synth.make_head_state_dicts()
     model = WeCLIP(num_classes=21, clip_model=sd, embedding_dim=256, in_channels=[768] * 4,
-                   dataset_root_path=None, device=dev, text_features=(bg.to(dev), fg.to(dev)))
+                   dataset_root_path=None, device=dev, text_features=(bg.to(dev), fg.to(dev)), comer=args.comer)
     model.decoder_fts_fuse.load_state_dict(fuse)
     model.decoder.load_state_dict(dec)
     model.train()
@@ -164,7 +166,7 @@ def main():
         "dtype": "f16 MFMA operands / f32 accumulate, f32 residual+softmax+LN+PAR (precision=%s)" % config.precision,
         "data": "synthetic",
         "config": {"workload": f"WeCLIP VOC full train step, batch {B}/GPU at {S}x{S}, K={K} classes/image "
-                               f"(BASELINE configs[2]{'/[3] DP' if world > 1 else ''})",
+                               f"(BASELINE configs[2]{'/[3] DP' if world > 1 else ''})" + (" + ViT-CoMer inserts" if args.comer else ""),
                    "global_batch": world * B, "parallelism": f"dp{world}"},
         "roofline": roofs[0] if roofs else None,
         "roofline_other": roofs[1:],

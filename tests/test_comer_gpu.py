@@ -67,3 +67,27 @@ def test_weclip_with_comer_inserts_runs_a_train_step():
     before = m.comer.fuse.weight.detach().clone()
     loss, ls, la = step(img, labels=synth.TINY_LABELS)
     assert torch.isfinite(loss) and not torch.equal(before, m.comer.fuse.weight.detach())
+
+
+@pytest.mark.parametrize("N,C,H,W,k", [(2, 64, 17, 23, 3), (1, 8, 64, 64, 5), (3, 5, 6, 4, 7)])
+def test_depthwise_conv_matches_torch(N, C, H, W, k):
+    """csrc/dwconv.hip (MRFP's nn.Conv2d(groups=C)) forward and all three gradients vs torch's conv2d in fp64 on the CPU."""
+    import torch.nn as nn
+    from weclip_vit_comer_amd.WeCLIP_model.comer import _dwconv
+    torch.manual_seed(k)
+    conv = nn.Conv2d(C, C, k, padding=k // 2, groups=C)
+    x = torch.randn(N, C, H, W)
+    ref_conv = nn.Conv2d(C, C, k, padding=k // 2, groups=C).double()
+    ref_conv.load_state_dict({n: v.double() for n, v in conv.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    yr = ref_conv(xr)
+    gy = torch.randn(N, C, H, W)
+    yr.backward(gy.double())
+    conv = conv.cuda()
+    xg = x.cuda().requires_grad_(True)
+    y = _dwconv(conv, xg)
+    y.backward(gy.cuda())
+    assert (y.detach().cpu().double() - yr.detach()).abs().max().item() < 1e-5
+    assert (xg.grad.cpu().double() - xr.grad).abs().max().item() < 1e-5
+    assert (conv.weight.grad.cpu().double() - ref_conv.weight.grad).abs().max().item() < 1e-4 * ref_conv.weight.grad.abs().max().item()
+    assert (conv.bias.grad.cpu().double() - ref_conv.bias.grad).abs().max().item() < 1e-4 * ref_conv.bias.grad.abs().max().item()

@@ -92,6 +92,44 @@ def _ref_points(h, w, device):
     return torch.stack([xs.reshape(-1), ys.reshape(-1)], -1)        # (h*w, 2) as (x, y)
 
 
+class _DWConvFunction(torch.autograd.Function):
+    """nn.Conv2d(C, C, k, padding=k//2, groups=C) on the HIP kernels of csrc/dwconv.hip (MIOpen's grouped
+    backward-weight path takes milliseconds on these small maps)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.float().contiguous()
+        w = weight.detach().float().contiguous()
+        N, C, H, W = x.shape
+        k = w.shape[-1]
+        y = torch.empty_like(x)
+        L.lib().wc_dwconv_fwd(L.ptr(x, torch.float32, "x"), L.ptr(w, torch.float32, "w"),
+                              L.ptr(bias.detach().float().contiguous(), torch.float32, "bias") if bias is not None else None,
+                              L.ptr(y), N, C, H, W, k, L.stream())
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        N, C, H, W = x.shape
+        k = w.shape[-1]
+        dx, dw = torch.empty_like(x), torch.empty_like(w)
+        db = torch.empty(C, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+        L.lib().wc_dwconv_bwd(L.ptr(x), L.ptr(w), L.ptr(dy, torch.float32, "dy"), L.ptr(dx), L.ptr(dw), L.ptr(db), N, C, H, W,
+                              k, L.stream())
+        return dx, dw, db
+
+
+def _dwconv(conv, x):
+    if x.is_cuda and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == conv.in_channels == conv.out_channels \
+            and conv.kernel_size[0] == conv.kernel_size[1] and conv.kernel_size[0] <= 7 and conv.padding == (conv.kernel_size[0] // 2,) * 2:
+        return _DWConvFunction.apply(x, conv.weight, conv.bias)
+    return conv(x)
+
+
 class MRFP(nn.Module):
     """FC -> depth-wise convs with two receptive fields (3x3 / 5x5 on channel halves) -> FC."""
 
@@ -107,7 +145,7 @@ class MRFP(nn.Module):
         for h, w in shapes:
             t = x[:, s:s + h * w].transpose(1, 2).reshape(x.shape[0], -1, h, w)
             a, b = t.chunk(2, dim=1)
-            outs.append(torch.cat([self.dw3(a), self.dw5(b)], 1).flatten(2).transpose(1, 2))
+            outs.append(torch.cat([_dwconv(self.dw3, a), _dwconv(self.dw5, b)], 1).flatten(2).transpose(1, 2))
             s += h * w
         return c + self.fc2(F.gelu(torch.cat(outs, 1)))
 
