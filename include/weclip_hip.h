@@ -293,11 +293,11 @@ int wc_msda_bwd(const float* value, const int* h_shapes, int n_levels, const flo
 
 /* Depth-wise conv2d (stride 1, zero "same" padding k/2, odd k <= 7) of the MRFP block of the ViT-CoMer inserts
  * (nn.Conv2d(C, C, k, padding=k//2, groups=C); no reference code).  x, y, dy, dx: (N, C, H, W) f32;
- * w, dw: (C, 1, k, k); bias, db: (C) (bias / db may be NULL). */
+ * w, dw: (C, 1, k, k); bias, db: (C) (bias / db may be NULL); part: workspace N*C*(k*k+1) f32. */
 int wc_dwconv_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int k,
                   void* stream);
-int wc_dwconv_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int N, int C,
-                  int H, int W, int k, void* stream);
+int wc_dwconv_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, float* part,
+                  int N, int C, int H, int W, int k, void* stream);
 
 #ifdef __cplusplus
 }

@@ -118,8 +118,9 @@ class _DWConvFunction(torch.autograd.Function):
         k = w.shape[-1]
         dx, dw = torch.empty_like(x), torch.empty_like(w)
         db = torch.empty(C, device=x.device, dtype=torch.float32) if ctx.has_bias else None
-        L.lib().wc_dwconv_bwd(L.ptr(x), L.ptr(w), L.ptr(dy, torch.float32, "dy"), L.ptr(dx), L.ptr(dw), L.ptr(db), N, C, H, W,
-                              k, L.stream())
+        part = torch.empty(N * C * (k * k + 1), device=x.device, dtype=torch.float32)
+        L.lib().wc_dwconv_bwd(L.ptr(x), L.ptr(w), L.ptr(dy, torch.float32, "dy"), L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(part),
+                              N, C, H, W, k, L.stream())
         return dx, dw, db
 
 

@@ -32,20 +32,21 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ i
     out[(long)nc * H * W + (long)y * W + x] = acc;
 }
 
-// one block per channel: every thread accumulates all k*k taps (+ bias) over its share of (n, y, x)
+// one block per (channel, image): every thread accumulates all k*k taps (+ bias) over its share of (y, x);
+// part[n][c][k*k + 1] is summed over the images by dwconv_bwdw_final_kernel
 __global__ __launch_bounds__(256) void dwconv_bwdw_kernel(const float* __restrict__ in, const float* __restrict__ dy,
-                                                           float* __restrict__ dw, float* __restrict__ db, int N, int C,
-                                                           int H, int W, int k) {
+                                                           float* __restrict__ part, int C, int H, int W, int k) {
     __shared__ float red[16];
-    const int c = blockIdx.x, p = k >> 1;
+    const int c = blockIdx.x, n = blockIdx.y, p = k >> 1;
     float acc[DW_MAXK * DW_MAXK + 1];
 #pragma unroll
     for (int t = 0; t < DW_MAXK * DW_MAXK + 1; ++t) acc[t] = 0.f;
-    const long HW = (long)H * W;
-    for (long i = threadIdx.x; i < (long)N * HW; i += 256) {
-        const int n = (int)(i / HW), r = (int)(i - (long)n * HW), y = r / W, x = r - y * W;
-        const float g = dy[((long)n * C + c) * HW + r];
-        const float* I = in + ((long)n * C + c) * HW;
+    const int HW = H * W;
+    const float* G = dy + ((long)n * C + c) * HW;
+    const float* I = in + ((long)n * C + c) * HW;
+    for (int r = threadIdx.x; r < HW; r += 256) {
+        const int y = r / W, x = r - y * W;
+        const float g = G[r];
         acc[DW_MAXK * DW_MAXK] += g;
 #pragma unroll
         for (int ky = 0; ky < DW_MAXK; ++ky)
@@ -53,18 +54,30 @@ __global__ __launch_bounds__(256) void dwconv_bwdw_kernel(const float* __restric
             for (int kx = 0; kx < DW_MAXK; ++kx) {
                 if (ky < k && kx < k) {
                     const int yy = y + ky - p, xx = x + kx - p;
-                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc[ky * DW_MAXK + kx] = fmaf(g, I[(long)yy * W + xx], acc[ky * DW_MAXK + kx]);
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc[ky * DW_MAXK + kx] = fmaf(g, I[yy * W + xx], acc[ky * DW_MAXK + kx]);
                 }
             }
     }
+    float* out = part + ((long)n * C + c) * (k * k + 1);
     for (int ky = 0; ky < k; ++ky)
         for (int kx = 0; kx < k; ++kx) {
             const float s = block_sum(acc[ky * DW_MAXK + kx], red);
-            if (threadIdx.x == 0) dw[(long)c * k * k + ky * k + kx] = s;
+            if (threadIdx.x == 0) out[ky * k + kx] = s;
             __syncthreads();
         }
     const float sb = block_sum(acc[DW_MAXK * DW_MAXK], red);
-    if (threadIdx.x == 0 && db) db[c] = sb;
+    if (threadIdx.x == 0) out[k * k] = sb;
+}
+
+__global__ __launch_bounds__(256) void dwconv_bwdw_final_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                 float* __restrict__ db, int N, int C, int kk) {
+    const int i = blockIdx.x * 256 + threadIdx.x;       // over C * (kk + 1)
+    if (i >= C * (kk + 1)) return;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += part[(long)n * C * (kk + 1) + i];
+    const int c = i / (kk + 1), t = i - c * (kk + 1);
+    if (t < kk) dw[(long)c * kk + t] = s;
+    else if (db) db[c] = s;
 }
 
 static int dw_check(const char* who, const void* a, const void* b, const void* c, int N, int C, int H, int W, int k) {
@@ -82,15 +95,19 @@ extern "C" int wc_dwconv_fwd(const float* x, const float* w, const float* bias, 
     return WC_OK;
 }
 
-extern "C" int wc_dwconv_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int N, int C,
-                             int H, int W, int k, void* stream) {
+// part: workspace N * C * (k*k + 1) floats.
+extern "C" int wc_dwconv_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, float* part,
+                             int N, int C, int H, int W, int k, void* stream) {
     if (dw_check("wc_dwconv_bwd", x, w, dy, N, C, H, W, k)) return WC_ERR_ARG;
-    WC_CHECK_ARG(dx && dw, "wc_dwconv_bwd: dx and dw are required");
+    WC_CHECK_ARG(dx && dw && part && N <= 65535, "wc_dwconv_bwd: dx, dw and part are required");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(dwconv_kernel<true>, dim3(wc_cdiv(W, 64), wc_cdiv(H, 4), N * C), dim3(256), 0, st, dy, w,
                        (const float*)nullptr, dx, C, H, W, k);
     WC_LAUNCH_CHECK("dwconv_kernel<bwd>");
-    hipLaunchKernelGGL(dwconv_bwdw_kernel, dim3(C), dim3(256), 0, st, x, dy, dw, db, N, C, H, W, k);
+    hipLaunchKernelGGL(dwconv_bwdw_kernel, dim3(C, N), dim3(256), 0, st, x, dy, part, C, H, W, k);
     WC_LAUNCH_CHECK("dwconv_bwdw_kernel");
+    hipLaunchKernelGGL(dwconv_bwdw_final_kernel, dim3(wc_cdiv((long)C * (k * k + 1), 256)), dim3(256), 0, st, part, dw, db, N, C,
+                       k * k);
+    WC_LAUNCH_CHECK("dwconv_bwdw_final_kernel");
     return WC_OK;
 }
