@@ -91,3 +91,28 @@ def test_depthwise_conv_matches_torch(N, C, H, W, k):
     assert (xg.grad.cpu().double() - xr.grad).abs().max().item() < 1e-5
     assert (conv.weight.grad.cpu().double() - ref_conv.weight.grad).abs().max().item() < 1e-4 * ref_conv.weight.grad.abs().max().item()
     assert (conv.bias.grad.cpu().double() - ref_conv.bias.grad).abs().max().item() < 1e-4 * ref_conv.bias.grad.abs().max().item()
+
+
+def test_comer_hip_decoder_matches_stock_autograd_decoder():
+    """With the inserts enabled the decoder / linear_pred / attn_pred run on the HIP path from the fused features
+    (DecoderFunction); outputs and the gradients reaching the inserts must match the stock-autograd decoder."""
+    from oracle import synth
+    from weclip_vit_comer_amd.WeCLIP_model.model_attn_aff_voc import WeCLIP
+    from weclip_vit_comer_amd.utils.losses import get_seg_loss_fused
+    img = synth.make_images(2, *synth.TINY_HW).cuda()
+    res = {}
+    for impl in ("hip", "torch"):
+        torch.manual_seed(0)
+        sd = synth.make_clip_state_dict(**synth.TINY)
+        bg, fg = synth.make_text_features(20, 25, synth.TINY["embed_dim"])
+        m = WeCLIP(num_classes=21, clip_model=sd, embedding_dim=256, in_channels=[64] * 4, device="cuda",
+                   text_features=(bg.cuda(), fg.cuda()), comer=True)
+        m.eval()
+        m.head_impl = impl
+        seg, lab, ap = m(img, ["a", "b"], labels=synth.TINY_LABELS)
+        loss = get_seg_loss_fused(seg, lab) + 0.1 * ap.mean()
+        loss.backward()
+        res[impl] = (seg.detach(), ap.detach(), m.comer.fuse.weight.grad.clone(),
+                     m.decoder.linear_pred.weight.grad.clone(), m.comer.cti[0].to_v.value_proj.weight.grad.clone())
+    for a, b, tol in zip(res["hip"], res["torch"], (5e-3, 5e-3, 5e-2, 5e-2, 5e-2)):
+        assert (a - b).abs().max().item() <= tol * max(b.abs().max().item(), 1e-6), (a - b).abs().max().item()

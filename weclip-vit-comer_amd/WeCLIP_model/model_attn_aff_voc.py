@@ -13,7 +13,7 @@ from .. import cam_pipeline as CP
 from ..clip import clip_tool as CT
 from ..clip import vit_engine as VE
 from ..clip.clip import load as clip_load
-from ..head_engine import HeadEngine, HeadFunction
+from ..head_engine import DecoderFunction, HeadEngine, HeadFunction
 from ..pytorch_grad_cam import GradCAM
 from .comer import CoMerInteraction
 from .Decoder.TransDecoder import DecoderTransformer
@@ -126,14 +126,19 @@ class WeCLIP(nn.Module):
             seg, attn_pred = HeadFunction.apply(self.head_engine, x16, B, Lq, h, w, drop, *self.head_engine.params())
         else:
             if self.comer is not None:
-                toks = [mlp.tokens(r.view(B, Lq, -1)[:, 1:, :]) for mlp, r in
-                        zip(self.decoder_fts_fuse.linears_modulelist, xs)]
+                used = set(self.comer.stage_blocks)       # only these adapter outputs enter the inserts
+                toks = [mlp.tokens(r.view(B, Lq, -1)[:, 1:, :]) if i in used else None for i, (mlp, r) in
+                        enumerate(zip(self.decoder_fts_fuse.linears_modulelist, xs))]
                 fts = self.decoder_fts_fuse.dropout(self.comer(img, toks, (h, w)))
             else:
                 fts = self.decoder_fts_fuse.forward_rows(xs, B, Lq, h, w)
-            seg, _ = self.decoder(fts, need_weights=False)
-            f = fts.reshape(B, fts.shape[1], h * w)
-            attn_pred = torch.sigmoid(f.transpose(2, 1).bmm(f))
+            if self.head_impl == "hip":      # decoder + linear_pred + attn_pred on the HIP path, from the fused features
+                rows = fts.permute(0, 2, 3, 1).reshape(B * h * w, fts.shape[1])
+                seg, attn_pred = DecoderFunction.apply(self.head_engine, rows, B, h, w, *self.head_engine.dec_params())
+            else:
+                seg, _ = self.decoder(fts, need_weights=False)
+                f = fts.reshape(B, fts.shape[1], h * w)
+                attn_pred = torch.sigmoid(f.transpose(2, 1).bmm(f))
         if mode == "val" and not self.val_runs_cam:
             return seg, None, attn_pred
         with torch.no_grad():

@@ -46,6 +46,12 @@ class HeadEngine:
         return ["fuse." + n for n, _ in self.fuse.named_parameters()] + \
                ["dec." + n for n, _ in self.dec.named_parameters()]
 
+    def dec_params(self):
+        return list(self.dec.parameters())
+
+    def dec_param_names(self):
+        return ["dec." + n for n, _ in self.dec.named_parameters()]
+
     def _weight_matrices(self):
         out = []
         for l, mlp in enumerate(self.fuse.linears_modulelist):
@@ -59,17 +65,27 @@ class HeadEngine:
         return [(n, t if t.dtype == F32 and t.is_contiguous() else t.float().contiguous()) for n, t in out]
 
     # ------------------------------------------------------------------------------ forward
-    def forward(self, xs, B, Lq, h, w, drop_scale=None):
+    def forward(self, xs, B, Lq, h, w, drop_scale=None, F_rows=None):
         """xs: `index` Splits of the encoder block outputs (B*L, C) fp16 (CLS row first per image).
-        drop_scale (B, E) f32 = Dropout2d mask / (1 - p) or None.  Returns (seg, attn_pred, ctx)."""
+        drop_scale (B, E) f32 = Dropout2d mask / (1 - p) or None.  Returns (seg, attn_pred, ctx).
+        F_rows (B*h*w, E) f32, if given, replaces the adapters + fuse stage (the ViT-CoMer inserts produce the
+        decoder input themselves): only the decoder, linear_pred and attn_pred run here, and backward() returns
+        the gradient w.r.t. F_rows under the key "__dF__"."""
         ex = config.exact()
         E, hw, M = self.E, h * w, B * h * w
-        C = xs[0].hi.shape[1]
-        dev = xs[0].hi.device
         n = self.index
-        ctx = dict(B=B, L=Lq, h=h, w=w, xs=xs, drop=drop_scale, ex=ex)
         wc = self.wcache
         wc.refresh(self._weight_matrices(), ex, force=self.fuse.training or self.dec.training)
+        if F_rows is not None:
+            dev = F_rows.device
+            ctx = dict(B=B, L=Lq, h=h, w=w, xs=None, drop=None, ex=ex, front=False)
+            F32_ = F_rows.detach().float().contiguous()
+            Fh = ops.split_f16(F32_, True)
+            ctx.update(F32=F32_, Fh=Fh)
+            return self._decode(ctx, F32_, Fh, B, h, w, ex)
+        C = xs[0].hi.shape[1]
+        dev = xs[0].hi.device
+        ctx = dict(B=B, L=Lq, h=h, w=w, xs=xs, drop=drop_scale, ex=ex, front=True)
         # adapters: t1 = relu(X W1^T + b1); cat[:, l] = t1 W2^T + b2
         cat = Split(torch.empty(M, n * E, device=dev, dtype=F16), torch.empty(M, n * E, device=dev, dtype=F16) if ex else None)
         t1s = []
@@ -90,6 +106,13 @@ class HeadEngine:
         ops.gemm(cat, wf, hw, E, n * E, bias=_f(self.fuse.linear_fuse.bias), out32=F32_, out16=Fh.hi, out16lo=Fh.lo,
                  batch=B, sA=hw * n * E, sW=0, sC=hw * E, cscale=drop_scale, sCS=E)
         ctx.update(cat=cat, t1s=t1s, F32=F32_, Fh=Fh)
+        return self._decode(ctx, F32_, Fh, B, h, w, ex)
+
+    def _decode(self, ctx, F32_, Fh, B, h, w, ex):
+        """decoder blocks -> linear_pred, and attn_pred = sigmoid(F^T F), from the fused feature rows F."""
+        E, hw, M = self.E, h * w, B * h * w
+        dev = F32_.device
+        wc = self.wcache
         # decoder blocks
         x = F32_
         blocks = []
@@ -166,6 +189,9 @@ class HeadEngine:
             ops.gemm(S, FT, hw, E, hwp, lda=hwp, ldw=Kp, out32=dF, resid=dx, batch=B, sA=hw * hwp, sW=hwp, sC=hw * E)
         else:
             dF = dx
+        if not ctx.get("front", True):          # decoder-only mode: the caller owns everything in front of F
+            grads["__dF__"] = dF * inv          # gradients are carried multiplied by GRAD_SCALE
+            return grads
         # ---- Dropout2d backward + fuse
         _, dFp = ops.colscale_split(dF, ctx["drop"], hw, want32=False, with_lo=ex)
         cat = ctx["cat"]
@@ -267,3 +293,31 @@ class HeadFunction(torch.autograd.Function):
                 d.copy_(g[n].reshape(d.shape))
             out.append(None)                          # already in the caller's buffer
         return (None,) * 7 + tuple(out)
+
+
+class DecoderFunction(torch.autograd.Function):
+    """autograd bridge for the decoder-only mode: (F_rows, decoder params...) -> (seg, attn_pred)."""
+
+    @staticmethod
+    def forward(ctx, engine, F_rows, B, h, w, *params):
+        seg, ap, c = engine.forward(None, B, h * w, h, w, F_rows=F_rows)
+        ctx.engine, ctx.c = engine, c
+        return seg, ap
+
+    @staticmethod
+    def backward(ctx, dseg, dap):
+        eng = ctx.engine
+        g = eng.backward(ctx.c, dseg.contiguous() if dseg is not None else None,
+                         dap.contiguous() if dap is not None else None)
+        ctx.c = None
+        direct = eng.direct_grads
+        out = []
+        for n, p in zip(eng.dec_param_names(), eng.dec_params()):
+            d = direct.get(n) if direct else None
+            if d is None:
+                out.append(g[n].reshape(p.shape))
+                continue
+            if g[n].data_ptr() != d.data_ptr():
+                d.copy_(g[n].reshape(d.shape))
+            out.append(None)
+        return (None, g["__dF__"], None, None, None) + tuple(out)
