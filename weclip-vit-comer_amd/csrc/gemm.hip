@@ -571,7 +571,36 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
         __builtin_amdgcn_s_barrier();                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     }
-    for (int t = 0; t < nt; t += 2) {
+    // steady state (every stage target exists, three half-tiles stay in flight): no guards, constant vmcnt(6)
+#define PP_PHASE_S(READS_, tj_, qj_, slotj_, MMA_)                                                            \
+    {                                                                                                         \
+        READS_;                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        PP_STAGE(tj_, qj_, slotj_);                                                                           \
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                      \
+        __builtin_amdgcn_s_barrier();                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                                        \
+        MMA_;                                                                                                 \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_s_barrier();                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }
+    int t = 0;
+    for (; t + 4 <= nt; t += 2) {
+        PP_PHASE_S(PP_READ_B(fb0, 1) PP_READ_A(0), t + 1, 1, 5, PP_MMA(0, fb0, 0));
+        PP_PHASE_S(PP_READ_B(fb1, 2), t + 1, 2, 6, PP_MMA(0, fb1, 1));
+        PP_PHASE_S(PP_READ_A(3), t + 1, 3, 7, PP_MMA(1, fb1, 1));
+        PP_PHASE_S(, t + 2, 0, 0, PP_MMA(1, fb0, 0));
+        PP_PHASE_S(PP_READ_B(fb0, 5) PP_READ_A(4), t + 2, 1, 1, PP_MMA(0, fb0, 0));
+        PP_PHASE_S(PP_READ_B(fb1, 6), t + 2, 2, 2, PP_MMA(0, fb1, 1));
+        PP_PHASE_S(PP_READ_A(7), t + 2, 3, 3, PP_MMA(1, fb1, 1));
+        PP_PHASE_S(, t + 3, 0, 4, PP_MMA(1, fb0, 0));
+    }
+#undef PP_PHASE_S
+    for (; t < nt; t += 2) {          // the last K-tiles: guarded stages, draining waits
         const int phi = 4 * t;
         // K-tile t (even): slots 0..3; stages half-tiles phi+5.. = (t+1: B0 B1 A1), (t+2: A0)
         PP_PHASE(phi + 0, PP_READ_B(fb0, 1) PP_READ_A(0), t + 1, 1, 5, PP_MMA(0, fb0, 0));
