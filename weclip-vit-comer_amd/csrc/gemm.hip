@@ -106,6 +106,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         const int gcol = n0 + wc * 64 + c4;
         const bool full = gcol + 3 < g.N;
         const bool has_lo = g.C16lo != nullptr;
+        const bool has_sc = g.scale_cols > 0 || g.cscale != nullptr;     // uniform: most launches carry no column scale
 #pragma unroll
         for (int c = 0; c < 4; ++c) {            // rows [16c, 16c+16) of the wave's 64x64 sub-tile
             const int mi = c >> 1, rq0 = (c & 1) * 8;
@@ -119,8 +120,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] = __half2float(__float2half(v[e]));
             }
+            if (has_sc) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] *= sc[e >> 3];
+                for (int e = 0; e < 16; ++e) v[e] *= sc[e >> 3];
+            }
             if constexpr (!AUX) { WC_EPI_ACT(v, 16) }
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
@@ -183,9 +186,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
             for (int it = 0; it < 4; ++it) {
                 __half h[4], l[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    h[k] = __float2half(f[it][k]);
-                    l[k] = __float2half(f[it][k] - __half2float(h[k]));
+                for (int k = 0; k < 4; ++k) h[k] = __float2half(f[it][k]);
+                if (has_lo) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) l[k] = __float2half(f[it][k] - __half2float(h[k]));
                 }
                 if (!ok[it]) continue;
                 if (full) {
@@ -441,11 +445,11 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
 // half the bytes per flop.  Each K-tile is staged as FOUR 16-KiB half-tiles, in the order they are consumed:
 //   A0 = rows 0..63 of both row groups, B0 = columns 0..31 of all four column groups, B1 = columns 32..63,
 //   A1 = rows 64..127 -- and computed in four phases: (A0,B0) (A0,B1) (A1,B1) (A1,B0), 8 MFMAs each.
-// LDS holds 8 half-tile slots (128 KiB).  Phase p issues the LDS-DMA of half-tile p+5, waits (counted
-// vmcnt) until half-tile p+2 has landed -- three half-tiles stay in flight across the barriers -- and reads
-// its fragments from half-tiles <= p+1; a slot is re-staged three phases after its last read.
-// The two row groups run one barrier apart: while the waves of one group multiply, the other group's waves
-// (their SIMD neighbours) read fragments and issue DMA, so LDS reads, DMA and MFMA overlap.
+// LDS holds 8 half-tile slots (128 KiB).  Phase p reads its fragments from half-tiles <= p+1, waits (counted
+// vmcnt) until half-tile p+2 has landed -- three half-tiles stay in flight across the barriers -- and issues
+// the LDS-DMA of half-tile p+6 between its MFMAs; a slot is re-staged at least two phases after its last read.
+// The two row groups run one barrier apart: while the waves of one group multiply (and issue DMA), the other
+// group's waves (their SIMD neighbours) read fragments, so LDS reads, DMA and MFMA overlap.
 #define PP_SLOT 16384
 template <bool AUX>
 __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
@@ -503,7 +507,8 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
 #define PP_WAIT(n_)                                                                 \
     {                                                                               \
         const int w__ = (n_);                                                       \
-        if (w__ >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");              \
+        if (w__ >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");              \
+        else if (w__ == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         \
         else if (w__ == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         \
         else if (w__ == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");         \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       \
@@ -533,9 +538,9 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
     float bv[2], sc[2];
     gemm_colvals(g, n0, wc, lane, 0, bv, sc);
 
-    // prologue: half-tiles 0..4 (nt >= 2 is guaranteed by the launcher), the first two landed
-    PP_STAGE(0, 0, 0); PP_STAGE(0, 1, 1); PP_STAGE(0, 2, 2); PP_STAGE(0, 3, 3); PP_STAGE(1, 0, 4);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // prologue: half-tiles 0..5 (nt >= 2 is guaranteed by the launcher), the first two landed
+    PP_STAGE(0, 0, 0); PP_STAGE(0, 1, 1); PP_STAGE(0, 2, 2); PP_STAGE(0, 3, 3); PP_STAGE(1, 0, 4); PP_STAGE(1, 1, 5);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();       // row group 1 runs one barrier behind group 0
 
@@ -554,12 +559,13 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
         acc[a_][1][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][ks], fb_[ks], acc[a_][1][b_], 0, 0, 0); \
     }                                                                                                         \
     asm volatile("" : "+v"(acc[a_][0][b_]), "+v"(acc[a_][1][b_]));   /* keeps the MFMAs inside their phase */
-    // one phase: [fragment reads] -> DMA of half-tile phi+5 -> counted wait -> barrier -> 8 MFMAs -> barrier
+    // one phase of the guarded form (last K-tiles): [fragment reads] -> DMA of half-tile phi+6 -> counted wait ->
+    // barrier -> 8 MFMAs -> barrier
 #define PP_PHASE(phi_, READS_, tj_, qj_, slotj_, MMA_)                                                        \
     {                                                                                                         \
         READS_;                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
-        if ((phi_) + 5 < nj) PP_STAGE(tj_, qj_, slotj_);                                                      \
+        if ((phi_) + 6 < nj) PP_STAGE(tj_, qj_, slotj_);                                                      \
         PP_WAIT(nj - 3 - (phi_));                                                                             \
         __builtin_amdgcn_s_barrier();                                                                         \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
@@ -571,18 +577,41 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
         __builtin_amdgcn_s_barrier();                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     }
-    // steady state (every stage target exists, three half-tiles stay in flight): no guards, constant vmcnt(6)
-#define PP_PHASE_S(READS_, tj_, qj_, slotj_, MMA_)                                                            \
+    // Steady state (every stage target exists): no guards, constant vmcnt.  The two DMA instructions of a phase are
+    // issued INSIDE the MFMA segment (after the 1st and the 3rd MFMA pair) and fetch half-tile phi+6: in-kernel
+    // s_memtime stamps showed an LDS-DMA wave-instruction costing its wave 125-165 cycles of issue time when the
+    // four waves of a row group issue together right after a barrier (the CU's address path takes ~38 cycles
+    // per 1-KiB piece), which made the read segment (reads + 2 DMA, 360-460 cycles) the long pole beside the
+    // partner's 8 MFMAs (~290).  Among the MFMAs the issue stall overlaps the matrix pipe's own latency.
+    // The wait before the barrier then leaves three half-tiles in flight (phi+3..phi+5) and half-tile phi+2 landed.
+#define PP_STAGE_H(t_, q_, slot_, h_)                                                                         \
+    {                                                                                                         \
+        const int seg__ = (t_) / ktiles;                                                                      \
+        const long k0__ = (long)((t_) - seg__ * ktiles) * BK;                                                 \
+        const __half* P__ = ((q_) == 0 || (q_) == 3) ? (seg__ == 0 ? g.A[0] : (seg__ == 1 ? g.A[1] : g.A[2])) \
+                                                     : (seg__ == 0 ? g.W[0] : (seg__ == 1 ? g.W[1] : g.W[2])); \
+        const long o__ = (q_) == 0 ? offA0[h_] : (q_) == 1 ? offB0[h_] : (q_) == 2 ? offB1[h_] : offA1[h_];   \
+        char* d__ = smem + (slot_) * PP_SLOT + wave * 1024 + (h_) * 8192;                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(P__ + o__ + k0__), (lds_ptr)d__, 16, 0, 0);                \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }
+#define PP_PHASE_S(READS_, tj_, qj_, slotj_, a_, fb_, b_)                                                     \
     {                                                                                                         \
         READS_;                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
-        PP_STAGE(tj_, qj_, slotj_);                                                                           \
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                      \
         __builtin_amdgcn_s_barrier();                                                                         \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         __builtin_amdgcn_s_setprio(1);                                                                        \
-        MMA_;                                                                                                 \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                    \
+            acc[a_][0][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][ks], fb_[ks], acc[a_][0][b_], 0, 0, 0); \
+            acc[a_][1][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][ks], fb_[ks], acc[a_][1][b_], 0, 0, 0); \
+            if (ks == 0) PP_STAGE_H(tj_, qj_, slotj_, 0)                                                      \
+            if (ks == 2) PP_STAGE_H(tj_, qj_, slotj_, 1)                                                      \
+        }                                                                                                     \
+        asm volatile("" : "+v"(acc[a_][0][b_]), "+v"(acc[a_][1][b_]));                                        \
         __builtin_amdgcn_s_setprio(0);                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         __builtin_amdgcn_s_barrier();                                                                         \
@@ -590,29 +619,30 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
     }
     int t = 0;
     for (; t + 4 <= nt; t += 2) {
-        PP_PHASE_S(PP_READ_B(fb0, 1) PP_READ_A(0), t + 1, 1, 5, PP_MMA(0, fb0, 0));
-        PP_PHASE_S(PP_READ_B(fb1, 2), t + 1, 2, 6, PP_MMA(0, fb1, 1));
-        PP_PHASE_S(PP_READ_A(3), t + 1, 3, 7, PP_MMA(1, fb1, 1));
-        PP_PHASE_S(, t + 2, 0, 0, PP_MMA(1, fb0, 0));
-        PP_PHASE_S(PP_READ_B(fb0, 5) PP_READ_A(4), t + 2, 1, 1, PP_MMA(0, fb0, 0));
-        PP_PHASE_S(PP_READ_B(fb1, 6), t + 2, 2, 2, PP_MMA(0, fb1, 1));
-        PP_PHASE_S(PP_READ_A(7), t + 2, 3, 3, PP_MMA(1, fb1, 1));
-        PP_PHASE_S(, t + 3, 0, 4, PP_MMA(1, fb0, 0));
+        PP_PHASE_S(PP_READ_B(fb0, 1) PP_READ_A(0), t + 1, 2, 6, 0, fb0, 0);
+        PP_PHASE_S(PP_READ_B(fb1, 2), t + 1, 3, 7, 0, fb1, 1);
+        PP_PHASE_S(PP_READ_A(3), t + 2, 0, 0, 1, fb1, 1);
+        PP_PHASE_S(, t + 2, 1, 1, 1, fb0, 0);
+        PP_PHASE_S(PP_READ_B(fb0, 5) PP_READ_A(4), t + 2, 2, 2, 0, fb0, 0);
+        PP_PHASE_S(PP_READ_B(fb1, 6), t + 2, 3, 3, 0, fb1, 1);
+        PP_PHASE_S(PP_READ_A(7), t + 3, 0, 4, 1, fb1, 1);
+        PP_PHASE_S(, t + 3, 1, 5, 1, fb0, 0);
     }
+#undef PP_STAGE_H
 #undef PP_PHASE_S
     for (; t < nt; t += 2) {          // the last K-tiles: guarded stages, draining waits
         const int phi = 4 * t;
-        // K-tile t (even): slots 0..3; stages half-tiles phi+5.. = (t+1: B0 B1 A1), (t+2: A0)
-        PP_PHASE(phi + 0, PP_READ_B(fb0, 1) PP_READ_A(0), t + 1, 1, 5, PP_MMA(0, fb0, 0));
-        PP_PHASE(phi + 1, PP_READ_B(fb1, 2), t + 1, 2, 6, PP_MMA(0, fb1, 1));
-        PP_PHASE(phi + 2, PP_READ_A(3), t + 1, 3, 7, PP_MMA(1, fb1, 1));
-        PP_PHASE(phi + 3, , t + 2, 0, 0, PP_MMA(1, fb0, 0));
+        // K-tile t (even): slots 0..3; stages half-tiles phi+6.. = (t+1: B1 A1), (t+2: A0 B0)
+        PP_PHASE(phi + 0, PP_READ_B(fb0, 1) PP_READ_A(0), t + 1, 2, 6, PP_MMA(0, fb0, 0));
+        PP_PHASE(phi + 1, PP_READ_B(fb1, 2), t + 1, 3, 7, PP_MMA(0, fb1, 1));
+        PP_PHASE(phi + 2, PP_READ_A(3), t + 2, 0, 0, PP_MMA(1, fb1, 1));
+        PP_PHASE(phi + 3, , t + 2, 1, 1, PP_MMA(1, fb0, 0));
         if (t + 1 < nt) {
-            // K-tile t+1 (odd): slots 4..7; stages (t+2: B0 B1 A1), (t+3: A0)
-            PP_PHASE(phi + 4, PP_READ_B(fb0, 5) PP_READ_A(4), t + 2, 1, 1, PP_MMA(0, fb0, 0));
-            PP_PHASE(phi + 5, PP_READ_B(fb1, 6), t + 2, 2, 2, PP_MMA(0, fb1, 1));
-            PP_PHASE(phi + 6, PP_READ_A(7), t + 2, 3, 3, PP_MMA(1, fb1, 1));
-            PP_PHASE(phi + 7, , t + 3, 0, 4, PP_MMA(1, fb0, 0));
+            // K-tile t+1 (odd): slots 4..7; stages (t+2: B1 A1), (t+3: A0 B0)
+            PP_PHASE(phi + 4, PP_READ_B(fb0, 5) PP_READ_A(4), t + 2, 2, 2, PP_MMA(0, fb0, 0));
+            PP_PHASE(phi + 5, PP_READ_B(fb1, 6), t + 2, 3, 3, PP_MMA(0, fb1, 1));
+            PP_PHASE(phi + 6, PP_READ_A(7), t + 3, 0, 4, PP_MMA(1, fb1, 1));
+            PP_PHASE(phi + 7, , t + 3, 1, 5, PP_MMA(1, fb0, 0));
         }
     }
 #undef PP_PHASE
