@@ -72,8 +72,10 @@ int wc_bilinear_resize_bwd(const float* gdst, float* gsrc, float* tmp, int plane
 /* ---- segmentation loss fused with the logit up-sampling -------------------------------- */
 /* scripts/dist_clip_voc.py:250 (bilinear up-sampling of seg to H x W) + get_seg_loss :105-113.
  * seg (B,nc,h,w) f32 low-res logits, label (B,H,W) i64 (ignore = 255).
- * wc_seg_loss_fwd: sums (4) = [sum nll over label==0, #label==0, sum nll over fg labels, #fg];
- *                  loss = 0.5*(sums[0]/sums[1] + sums[2]/sums[3]); part: ceil(W/64)*ceil(H/4)*B*4 f32.
+ * wc_seg_loss_fwd: sums (8) = [sum nll over label==0, #label==0, sum nll over fg labels, #fg,
+ *                  loss = 0.5*(sums[0]/sums[1] + sums[2]/sums[3]), 0.5/sums[1], 0.5/sums[3], 0]
+ *                  (sums[5..6]: the backward weights wts for an upstream gradient of 1);
+ *                  part: ceil(W/64)*ceil(H/4)*B*4 f32.
  * wc_seg_loss_bwd: ghr (B,nc,H,W) = wts[bg|fg] * (softmax - onehot) per pixel (0 for ignored); the
  *                  low-res gradient is wc_bilinear_resize_bwd(ghr). */
 int wc_seg_loss_fwd(const float* seg, const int64_t* label, float* part, float* sums, int B, int nc, int h, int w,
@@ -84,7 +86,8 @@ int wc_seg_loss_bwd(const float* seg, const int64_t* label, const float* wts, fl
 /* Affinity loss fused with the affinity-label construction (reference utils/camutils.py:226-247 +
  * scripts/dist_clip_voc.py:116-133 radius mask + utils/losses.py:11-22): attn_pred (B,hw,hw) f32, cam_label (B,H,W)
  * int64 pseudo labels (nearest down-sampled to h x w inside), Chebyshev `radius`.
- * fwd: sums (4) = [sum_pos(1-p), n_pos, sum_neg(p), n_neg]  (loss = 0.5*s0/(s1+1) + 0.5*s2/(s3+1));
+ * fwd: sums (8) = [sum_pos(1-p), n_pos, sum_neg(p), n_neg, loss = 0.5*s0/(s1+1) + 0.5*s2/(s3+1),
+ *      -0.5/(s1+1), 0.5/(s3+1), 0]  (sums[5..6]: the backward coef for an upstream gradient of 1);
  *      part: workspace 4*B*ceil(hw/8) f32.
  * bwd: dap (B,hw,hw) = coef[0] on positive pairs, coef[1] on negative pairs, 0 elsewhere (coef: 2 device floats). */
 int wc_aff_loss_fwd(const float* attn_pred, const int64_t* cam_label, float* part, float* sums, int B, int h,

@@ -72,9 +72,15 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
     }
 }
 
-// sums[k] = sum over blocks of part[blk*4 + k]  (deterministic second stage)
-__global__ __launch_bounds__(1024) void seg_loss_reduce_kernel(const float* __restrict__ part, float* __restrict__ sums, long nblk) {
+// sums[k] = sum over blocks of part[blk*4 + k]  (deterministic second stage), then the scalar tail of the loss so
+// that no elementwise torch launches follow: sums[4] = the loss, sums[5..6] = d loss / d (per-pixel term) for the two
+// classes of terms (the backward kernels' weights for an upstream gradient of 1).
+//   mode 0 (segmentation, get_seg_loss):  0.5 * (s0 / s1 + s2 / s3);                 0.5 / s1,  0.5 / s3
+//   mode 1 (affinity, get_aff_loss):      0.5 * s0 / (s1 + 1) + 0.5 * s2 / (s3 + 1); -0.5 / (s1 + 1), 0.5 / (s3 + 1)
+__global__ __launch_bounds__(1024) void seg_loss_reduce_kernel(const float* __restrict__ part, float* __restrict__ sums, long nblk,
+                                                               int mode) {
     __shared__ float red[16];
+    __shared__ float tot[4];
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (long i = threadIdx.x; i < nblk; i += 1024) {          // one 16-byte load per partial block
         const float4 v = *reinterpret_cast<const float4*>(part + i * 4);
@@ -82,8 +88,20 @@ __global__ __launch_bounds__(1024) void seg_loss_reduce_kernel(const float* __re
     }
     for (int k = 0; k < 4; ++k) {
         const float t = block_sum(s[k], red);
-        if (threadIdx.x == 0) sums[k] = t;
+        if (threadIdx.x == 0) { sums[k] = t; tot[k] = t; }
         __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (mode == 0) {
+            sums[4] = 0.5f * (tot[0] / tot[1] + tot[2] / tot[3]);
+            sums[5] = 0.5f / tot[1];
+            sums[6] = 0.5f / tot[3];
+        } else {
+            sums[4] = 0.5f * tot[0] / (tot[1] + 1.0f) + 0.5f * tot[2] / (tot[3] + 1.0f);
+            sums[5] = -0.5f / (tot[1] + 1.0f);
+            sums[6] = 0.5f / (tot[3] + 1.0f);
+        }
+        sums[7] = 0.f;
     }
 }
 
@@ -96,7 +114,7 @@ extern "C" int wc_seg_loss_fwd(const float* seg, const int64_t* label, float* pa
     hipLaunchKernelGGL(seg_loss_kernel<false>, grid, dim3(256), 0, st, seg, (const long*)label, part, nullptr, nullptr, nc,
                        h, w, H, W, (float)h / H, (float)w / W, ignore);
     WC_LAUNCH_CHECK("seg_loss_kernel<fwd>");
-    hipLaunchKernelGGL(seg_loss_reduce_kernel, dim3(1), dim3(1024), 0, st, part, sums, (long)grid.x * grid.y * grid.z);
+    hipLaunchKernelGGL(seg_loss_reduce_kernel, dim3(1), dim3(1024), 0, st, part, sums, (long)grid.x * grid.y * grid.z, 0);
     WC_LAUNCH_CHECK("seg_loss_reduce_kernel");
     return WC_OK;
 }
@@ -185,7 +203,7 @@ extern "C" int wc_aff_loss_fwd(const float* attn_pred, const int64_t* cam_label,
     hipLaunchKernelGGL(aff_loss_kernel<false>, grid, dim3(256), (size_t)h * w * 4, st, attn_pred, (const long*)cam_label, part,
                        nullptr, nullptr, h, w, H, W, radius, ignore);
     WC_LAUNCH_CHECK("aff_loss_kernel<fwd>");
-    hipLaunchKernelGGL(seg_loss_reduce_kernel, dim3(1), dim3(1024), 0, st, part, sums, (long)grid.x * grid.y);
+    hipLaunchKernelGGL(seg_loss_reduce_kernel, dim3(1), dim3(1024), 0, st, part, sums, (long)grid.x * grid.y, 1);
     WC_LAUNCH_CHECK("seg_loss_reduce_kernel");
     return WC_OK;
 }

@@ -220,6 +220,15 @@ class HeadEngine:
             return d.view(shape)
         return torch.empty(shape, device=self.dec.linear_pred.weight.device, dtype=F32)
 
+    def _ln_dest(self, wname, bname, D):
+        """(2, D) view over the weight and bias gradient buffers of a LayerNorm when the caller's bucket holds them
+        back to back (parameters() order: weight, bias), else None (layernorm_bwd then allocates)."""
+        gw = self.direct_grads.get(wname) if self.direct_grads else None
+        gb = self.direct_grads.get(bname) if self.direct_grads else None
+        if gw is None or gb is None or not gw.is_contiguous() or gb.data_ptr() != gw.data_ptr() + 4 * D:
+            return None
+        return torch.as_strided(gw, (2, D), (D, 1))
+
     def _wgrad(self, dy16, x16, M, N_, K_, inv, grads, wname, bname, lda=None, ldx=None, xmap=None):
         """dW (N_, K_) = inv * dY^T X and db (N_) = inv * dY^T 1 from the row-major fp16 operands as they lie
         in memory (csrc/gemm.hip gemm_km_kernel: transposing LDS reads, no operand transposes).  The output has
@@ -251,7 +260,8 @@ class HeadEngine:
         da2 = torch.empty(M, E, device=dev, dtype=F32)
         ops.gemm(du, wT("fc"), M, E, 4 * E, out32=da2)
         wg(du.hi, c["a2"].hi, 4 * E, E, prefix + "mlp.c_fc.weight", prefix + "mlp.c_fc.bias")
-        dx1, g16, dgb2 = ops.layernorm_bwd(da2, c["x1"], pk.ln2_w, add=dx2, want32=True, want16=True, alpha=inv)
+        dx1, g16, dgb2 = ops.layernorm_bwd(da2, c["x1"], pk.ln2_w, add=dx2, want32=True, want16=True, alpha=inv,
+                                           dgb=self._ln_dest(prefix + "ln_2.weight", prefix + "ln_2.bias", E))
         grads[prefix + "ln_2.weight"], grads[prefix + "ln_2.bias"] = dgb2[0], dgb2[1]
         # forced-fp16 out-projection (clip/myAtt.py:321): gradient rounded to fp16 on both sides
         do16 = torch.empty(M, E, device=dev, dtype=F16)
@@ -262,7 +272,8 @@ class HeadEngine:
         da = torch.empty(M, E, device=dev, dtype=F32)
         ops.gemm(dqkv, wT("in"), M, E, 3 * E, out32=da)
         wg(dqkv.hi, c["a"].hi, 3 * E, E, prefix + "attn.in_proj_weight", prefix + "attn.in_proj_bias")
-        dx, _, dgb1 = ops.layernorm_bwd(da, c["x"], pk.ln1_w, add=dx1, want32=True, alpha=inv)
+        dx, _, dgb1 = ops.layernorm_bwd(da, c["x"], pk.ln1_w, add=dx1, want32=True, alpha=inv,
+                                        dgb=self._ln_dest(prefix + "ln_1.weight", prefix + "ln_1.bias", E))
         grads[prefix + "ln_1.weight"], grads[prefix + "ln_1.bias"] = dgb1[0], dgb1[1]
         return dx
 

@@ -199,14 +199,16 @@ def colsum(src, R, C, *, ld=None, alpha=1.0, round16=False, out=None):
     return out
 
 
-def layernorm_bwd(dy, x, w, *, add=None, want32=True, want16=False, out_scale=1.0, alpha=1.0, eps=1e-5):
-    """-> (dx32 or None, dx16 or None, dgb (2, D) = alpha*[dgamma; dbeta])."""
+def layernorm_bwd(dy, x, w, *, add=None, want32=True, want16=False, out_scale=1.0, alpha=1.0, eps=1e-5, dgb=None):
+    """-> (dx32 or None, dx16 or None, dgb (2, D) = alpha*[dgamma; dbeta]); `dgb`, if given, is the (2, D) f32
+    destination (e.g. the adjacent weight / bias gradient views of a flat gradient bucket)."""
     rows, D = x.shape
     dev = x.device
     dx32 = torch.empty(rows, D, device=dev, dtype=F32) if want32 else None
     dx16 = torch.empty(rows, D, device=dev, dtype=F16) if want16 else None
     part = torch.empty(((rows + 15) // 16) * 2 * D, device=dev, dtype=F32)
-    dgb = torch.empty(2, D, device=dev, dtype=F32)
+    if dgb is None:
+        dgb = torch.empty(2, D, device=dev, dtype=F32)
     L.lib().wc_layernorm_bwd(L.ptr(dy, F32, "dy"), L.ptr(x, F32, "x"), L.ptr(w, F32, "w"), L.ptr(add, F32, "add"), eps,
                              L.ptr(dx32), L.ptr(dx16), float(out_scale), L.ptr(part), L.ptr(dgb), float(alpha), rows,
                              D, L.stream())

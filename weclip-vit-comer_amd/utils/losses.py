@@ -36,13 +36,13 @@ class _SegLossFn(torch.autograd.Function):
         H, W = label.shape[1:]
         nblk = ((W + 63) // 64) * ((H + 3) // 4) * B
         part = torch.empty(nblk * 4, device=seg.device, dtype=torch.float32)
-        sums = torch.empty(4, device=seg.device, dtype=torch.float32)
+        sums = torch.empty(8, device=seg.device, dtype=torch.float32)
         L.lib().wc_seg_loss_fwd(L.ptr(seg, torch.float32, "seg"), L.ptr(label, torch.int64, "label"), L.ptr(part),
                                 L.ptr(sums), B, nc, h, w, H, W, int(ignore_index), L.stream())
         ctx.save_for_backward(seg, label, sums)
         ctx.ignore = int(ignore_index)
-        # mean over an empty set is NaN in F.cross_entropy too (0/0)
-        return 0.5 * (sums[0] / sums[1] + sums[2] / sums[3])
+        # mean over an empty set is NaN in F.cross_entropy too (0/0); the scalar tail is computed by the reduce kernel
+        return sums[4].clone()
 
     @staticmethod
     def backward(ctx, g):
@@ -50,7 +50,7 @@ class _SegLossFn(torch.autograd.Function):
         seg, label, sums = ctx.saved_tensors
         B, nc, h, w = seg.shape
         H, W = label.shape[1:]
-        wts = (0.5 * g / torch.stack((sums[1], sums[3]))).float().contiguous()   # no index tensor: no host sync
+        wts = sums[5:7] * g            # (0.5 / n_bg, 0.5 / n_fg) from the forward reduce kernel: no host sync
         out = torch.empty_like(seg)
         ghr = torch.empty(B, nc, H, W, device=seg.device, dtype=torch.float32)
         L.lib().wc_seg_loss_bwd(L.ptr(seg), L.ptr(label), L.ptr(wts, torch.float32, "wts"), L.ptr(ghr), B, nc, h, w, H, W,
@@ -80,19 +80,19 @@ class _AffLossFn(torch.autograd.Function):
         if h * w != hw:
             raise RuntimeError("attn_pred does not match the 1/16 token grid of the labels")
         part = torch.empty(4 * B * ((hw + 7) // 8), device=ap.device, dtype=torch.float32)
-        sums = torch.empty(4, device=ap.device, dtype=torch.float32)
+        sums = torch.empty(8, device=ap.device, dtype=torch.float32)
         L.lib().wc_aff_loss_fwd(L.ptr(ap, torch.float32, "attn_pred"), L.ptr(lab, torch.int64, "cam_label"), L.ptr(part),
                                 L.ptr(sums), B, h, w, H, W, int(radius), int(ignore_index), L.stream())
         ctx.save_for_backward(lab, sums)
         ctx.meta = (B, h, w, H, W, int(radius), int(ignore_index))
-        return 0.5 * sums[0] / (sums[1] + 1) + 0.5 * sums[2] / (sums[3] + 1)
+        return sums[4].clone()
 
     @staticmethod
     def backward(ctx, g):
         from .. import _lib as L
         lab, sums = ctx.saved_tensors
         B, h, w, H, W, radius, ignore = ctx.meta
-        coef = (g * torch.stack((-0.5 / (sums[1] + 1), 0.5 / (sums[3] + 1)))).float().contiguous()
+        coef = sums[5:7] * g           # (-0.5 / (n_pos + 1), 0.5 / (n_neg + 1)) from the forward reduce kernel
         dap = torch.empty(B, h * w, h * w, device=lab.device, dtype=torch.float32)
         L.lib().wc_aff_loss_bwd(L.ptr(lab), L.ptr(coef, torch.float32, "coef"), L.ptr(dap), B, h, w, H, W, radius, ignore,
                                 L.stream())
