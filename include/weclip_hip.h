@@ -120,6 +120,19 @@ int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const void* W0, 
                 int scale_cols, float* P32, const float* aux, const int* rowmap, int rpg,
                 long ldaux, const void* auxh, const float* cscale, long sCS, void* stream);
 
+/* Grouped form of wc_gemm_f16: several small GEMMs of one shape in ONE launch -- the 11 adapter MLPs of
+ * WeCLIP_model/segformer_head.py:58-76 (one nn.Linear pair per encoder block, the reference loops over them) times
+ * the B images.  Batch index z splits into z2 = z / zdiv (group: adapter) and z1 = z % zdiv (image): A, W and the
+ * outputs move by z1*s? + z2*s?2 elements, the bias by z2*sB2 and the act-5 aux by z2*sX2; everything else as
+ * wc_gemm_f16 (which is this entry with zdiv = batch and zero second-level strides). */
+int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A2, const void* W0, const void* W1,
+                        const void* W2, int nseg, int M, int N, int K, long lda, long ldw, int batch,
+                        long sA, long sW, long sC, const float* bias, const float* resid, long ldr, long sR,
+                        float* C32, void* C16, void* C16lo, long ldc, int act, int round16, float scale,
+                        int scale_cols, float* P32, const float* aux, const int* rowmap, int rpg,
+                        long ldaux, const void* auxh, const float* cscale, long sCS, int zdiv, long sA2, long sW2,
+                        long sC2, long sB2, long sX2, void* stream);
+
 /* Which kernel wc_gemm_f16 runs for a shape (for profiling / roofline bookkeeping only):
  * 0 = 128x128x64 kernel, 1 = 256x256x64 ping-pong kernel, 2 = ping-pong kernel + 128x128 kernel on the ragged
  * last M % 256 rows (two launches). */

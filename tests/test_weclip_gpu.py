@@ -137,6 +137,45 @@ def test_train_step_bucket_gradients_match_autograd_path():
     assert torch.equal(g0, g1)
 
 
+@pytest.mark.parametrize("precision", ["fast", "exact"])
+def test_grouped_adapter_launches_equal_per_adapter_launches(monkeypatch, precision):
+    """The adapters run as grouped GEMM launches (wc_gemm_f16_grouped: all blocks x images in one launch) when the
+    encoder stacked its fp16 block outputs; same tiles and accumulation order, so loss and every gradient must be
+    bit-identical to the per-adapter launches."""
+    from weclip_vit_comer_amd import config
+    from weclip_vit_comer_amd.train_step import TrainStep
+    img = synth.make_images(3, H, W, seed=5).cuda()
+    monkeypatch.setattr(config, "precision", precision)
+
+    from weclip_vit_comer_amd import head_engine as HE
+    real_gemm = HE.ops.gemm
+    grouped_calls = []
+
+    def spy(*a, **kw):
+        if kw.get("zdiv") is not None:
+            grouped_calls.append(kw["batch"])
+        return real_gemm(*a, **kw)
+
+    monkeypatch.setattr(HE.ops, "gemm", spy)
+
+    def run(grouped):
+        monkeypatch.setenv("WECLIP_GROUPED_ADAPTERS", "1" if grouped else "0")
+        torch.manual_seed(0)
+        m = _model()
+        m.train()
+        step = TrainStep(m, bucket=True)
+        torch.manual_seed(1)
+        loss, _, _ = step(img, labels=[[1], [2, 5], [0, 3]])
+        return loss.item(), step.bucket.flat.clone()
+
+    l0, g0 = run(False)
+    assert not grouped_calls
+    l1, g1 = run(True)
+    assert len(grouped_calls) == 3          # proj (blocks x images), proj_2 and the ReLU-backward GEMM (blocks)
+    assert l0 == l1 and g0.abs().max().item() > 0
+    assert torch.equal(g0, g1)
+
+
 @pytest.mark.parametrize("hw,labels", [((80, 112), [[1], [2, 5, 9], [0, 3]]), ((48, 64), [[4, 11, 17, 19]])])
 def test_ragged_batches_and_sizes_match_oracle(hw, labels):
     """Odd batch (3: not a multiple of the 8 XCDs), a different number of classes per image (1 / 3 / 2 / 4) and

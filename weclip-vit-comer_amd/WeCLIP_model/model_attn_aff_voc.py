@@ -114,7 +114,7 @@ class WeCLIP(nn.Module):
         seg_trans = self.iter_num > self.seg_trans_after or mode == "val"
         img = img.cuda().float().contiguous()
         hip_head = self.head_impl == "hip" and self.comer is None
-        x16 = [] if hip_head else None
+        x16 = VE.X16Stack(self.encoder.visual.transformer.layers - 1) if hip_head else None
         with torch.no_grad():
             xs, maps, _, Lq = self.encode(img, seg_trans, x16)
         if hip_head:

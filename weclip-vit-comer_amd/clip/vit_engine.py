@@ -40,6 +40,24 @@ class BlockPack:
         self.pj_b = f(blk.mlp.c_proj.bias)
 
 
+class X16Stack(list):
+    """List of the fp16 block outputs that also owns ONE (n, M, E) buffer they are slices of, so that the adapter
+    GEMMs over all blocks can run as a grouped launch (uniform stride between blocks): `big` / `big_lo`."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.n, self.big, self.big_lo = n, None, None
+
+    def next_slot(self, M, E, dev, ex):
+        if self.big is None:
+            self.big = torch.empty(self.n, M, E, device=dev, dtype=F16)
+            self.big_lo = torch.empty(self.n, M, E, device=dev, dtype=F16) if ex else None
+        i = len(self)
+        if i >= self.n or self.big.shape[1:] != (M, E):
+            return None
+        return Split(self.big[i], self.big_lo[i] if self.big_lo is not None else None)
+
+
 def run_block(pk, x, B, L, want_mean=True, keep=None, x16_out=None):
     """x (B*L, E) fp32 -> (x_out fp32, head-mean map (B,L,L) or None).
     `keep`, if a dict, receives intermediates needed by the analytic backward."""
@@ -64,7 +82,8 @@ def run_block(pk, x, B, L, want_mean=True, keep=None, x16_out=None):
     x2 = torch.empty(M, E, device=dev, dtype=F32)
     x2h = None
     if x16_out is not None:     # fp16 copy of the block output for the adapter GEMMs (no extra pass)
-        x2h = Split(torch.empty(M, E, device=dev, dtype=F16), torch.empty(M, E, device=dev, dtype=F16) if ex else None)
+        nxt = x16_out.next_slot(M, E, dev, ex) if isinstance(x16_out, X16Stack) else None
+        x2h = nxt or Split(torch.empty(M, E, device=dev, dtype=F16), torch.empty(M, E, device=dev, dtype=F16) if ex else None)
         x16_out.append(x2h)
     ops.gemm(z, pk.pj_w, M, E, 4 * E, bias=pk.pj_b, resid=x1, out32=x2,
              out16=x2h.hi if x2h else None, out16lo=x2h.lo if x2h else None)

@@ -56,6 +56,10 @@ struct GemmArgs {
     int gx, gy;           // tile grid (N tiles, M tiles); the launch is 1-D over gx * roundup8(gy)
     int auxvec;           // act 5: auxh rows are 8-byte addressable per 4 columns
     int vec;              // outputs / residual are 16-byte addressable per 4 columns: LDS-transposed wide epilogue
+    // two-level batch (grouped small GEMMs, e.g. 11 adapters x B images in one launch): z2 = z / zdiv, z1 = z % zdiv;
+    // A, W, C move by z1 * s? + z2 * s?2; bias by z2 * sB2 and the act-5 aux by z2 * sX2 (elements)
+    int zdiv;
+    long sA2, sW2, sC2, sB2, sX2;
 };
 
 // Epilogue shared by the kernel variants.  C/D layout of the 32x32 MFMA: col = lane&31,
@@ -77,12 +81,12 @@ struct GemmArgs {
 // Per-column epilogue constants of a lane's two output columns (bias, scale): fetched BEFORE the K loop of a
 // tile so that their latency (and, with LDS-DMA in flight, the in-order wait behind it) is off the epilogue.
 __device__ __forceinline__ void gemm_colvals(const GemmArgs& g, int n0, int wc, int lane, long zb, float (&bv)[2],
-                                             float (&sc)[2]) {
+                                             float (&sc)[2], long bbase = 0) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int col = n0 + wc * 64 + ni * 32 + (lane & 31);
         const int colc = col < g.N ? col : g.N - 1;
-        bv[ni] = g.bias ? g.bias[colc] : 0.f;
+        bv[ni] = g.bias ? g.bias[bbase + colc] : 0.f;
         sc[ni] = (col < g.scale_cols) ? g.scale : 1.0f;
         if (g.cscale) sc[ni] *= g.cscale[zb * g.sCS + colc];
     }
@@ -91,8 +95,7 @@ __device__ __forceinline__ void gemm_colvals(const GemmArgs& g, int n0, int wc, 
 template <bool AUX>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int m0, int n0, int wr, int wc,
                                               int lane, long zb, char* scratch, const float (&bv)[2],
-                                              const float (&sc)[2]) {
-    const long cb = zb * g.sC;
+                                              const float (&sc)[2], long cb, long xb = 0) {
     const int act = g.act;
     const bool has_res = g.resid != nullptr;
     const bool r16 = g.round16 != 0;
@@ -160,7 +163,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                             f[it][k] *= sg * (1.0f + 1.702f * u[k] * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
                         }
                     } else {
-                        const __half* hp = g.auxh + (long)grow * g.ldaux + gcol;
+                        const __half* hp = g.auxh + xb + (long)grow * g.ldaux + gcol;
                         if (full && g.auxvec) {          // one 8-byte load of the four saved activations
                             typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
                             const f16x4_ hv = *reinterpret_cast<const f16x4_*>(hp);
@@ -255,7 +258,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                         const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u));
                         uv[r] = sg * (1.0f + 1.702f * u * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
                     } else {
-                        uv[r] = __half2float(g.auxh[(long)row * g.ldaux + colc]) > 0.f ? 1.f : 0.f;   // ReLU'
+                        uv[r] = __half2float(g.auxh[xb + (long)row * g.ldaux + colc]) > 0.f ? 1.f : 0.f;   // ReLU'
                     }
                 }
             }
@@ -340,6 +343,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
     if (ty >= gy) return;
     const int m0 = ty * BM, n0 = tx * BN;
     const long zb = blockIdx.z;
+    const long z2 = (int)blockIdx.z / g.zdiv, z1 = zb - z2 * g.zdiv;
 
     long aoff[4], woff[4];
 #pragma unroll
@@ -351,8 +355,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
         if (ar > g.M - 1) ar = g.M - 1;
         int wrow = n0 + row;
         if (wrow > g.N - 1) wrow = g.N - 1;
-        aoff[i] = zb * g.sA + (long)ar * g.lda + c * 8;
-        woff[i] = zb * g.sW + (long)wrow * g.ldw + c * 8;
+        aoff[i] = z1 * g.sA + z2 * g.sA2 + (long)ar * g.lda + c * 8;
+        woff[i] = z1 * g.sW + z2 * g.sW2 + (long)wrow * g.ldw + c * 8;
     }
     const int ktiles = g.K / BK;
     const int nt = ktiles * g.nseg;
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float bv[2], sc[2];
-    gemm_colvals(g, n0, wc, lane, zb, bv, sc);
+    gemm_colvals(g, n0, wc, lane, zb, bv, sc, z2 * g.sB2);
     GLDS(0, 0);
     __syncthreads();     // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
     for (int t = 0; t < nt; ++t) {
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
         __syncthreads();
     }
 #undef GLDS
-    gemm_epilogue<AUX>(g, acc, m0, n0, wr, wc, lane, zb, smem + wave * 8192, bv, sc);
+    gemm_epilogue<AUX>(g, acc, m0, n0, wr, wc, lane, zb, smem + wave * 8192, bv, sc, z1 * g.sC + z2 * g.sC2, z2 * g.sX2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -653,8 +657,8 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
 #undef PP_STAGE
     if (wr == 0) __builtin_amdgcn_s_barrier();       // re-align the two row groups
     __syncthreads();                                 // every wave is done with the operand slots: epilogue scratch
-    gemm_epilogue<AUX>(g, acc[0], m0 + wr * 128, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc);
-    gemm_epilogue<AUX>(g, acc[1], m0 + wr * 128 + 64, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc);
+    gemm_epilogue<AUX>(g, acc[0], m0 + wr * 128, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc, 0);
+    gemm_epilogue<AUX>(g, acc[1], m0 + wr * 128 + 64, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -809,7 +813,7 @@ __global__ __launch_bounds__(256, 2) void gemm_km_kernel(KmArgs g) {
         }
     }
     const float bv[2] = {0.f, 0.f}, sc[2] = {1.f, 1.f};
-    gemm_epilogue<false>(g.e, acc, n0, k0, wr, wc, lane, z, smem + wave * 8192, bv, sc);
+    gemm_epilogue<false>(g.e, acc, n0, k0, wr, wc, lane, z, smem + wave * 8192, bv, sc, (long)z * g.e.sC);
 }
 
 // part: (nslices, N, K + bias) fp32 with nslices = ceil(M / mslice); zeros: device buffer of >= 16 zero bytes.
@@ -835,6 +839,7 @@ extern "C" int wc_gemm_km_f16(const void* dY, long lda, const void* X, long ldx,
     e.C32 = part; e.C16 = nullptr; e.C16lo = nullptr; e.ldc = K1; e.act = 0; e.round16 = 0; e.scale = 1.f; e.scale_cols = 0;
     e.P32 = nullptr; e.aux = nullptr; e.rowmap = nullptr; e.row0 = 0; e.rpg = 1; e.ldaux = 0; e.auxh = nullptr; e.cscale = nullptr;
     e.sCS = 0; e.gx = g.gx; e.gy = wc_cdiv(N, 128); e.vec = 0; e.auxvec = 0;
+    e.zdiv = 1; e.sA2 = e.sW2 = e.sC2 = e.sB2 = e.sX2 = 0;
     dim3 grid((unsigned)(g.gx * wc_cdiv(N, 128)), 1, ns);
     const int pr = wc_prof_begin(stream);
     hipLaunchKernelGGL(gemm_km_kernel, grid, dim3(256), 4 * 64 * 256, (hipStream_t)stream, g);
@@ -911,6 +916,14 @@ static int gemm_plan(int M, int N, int K, int nseg, int batch, bool row_mapped_a
     return split ? 2 : 1;
 }
 
+extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A2, const void* W0, const void* W1,
+                                   const void* W2, int nseg, int M, int N, int K, long lda, long ldw, int batch, long sA,
+                                   long sW, long sC, const float* bias, const float* resid, long ldr, long sR, float* C32,
+                                   void* C16, void* C16lo, long ldc, int act, int round16, float scale, int scale_cols,
+                                   float* P32, const float* aux, const int* rowmap, int rpg, long ldaux, const void* auxh,
+                                   const float* cscale, long sCS, int zdiv, long sA2, long sW2, long sC2, long sB2,
+                                   long sX2, void* stream);
+
 extern "C" int wc_gemm_plan(int M, int N, int K, int nseg, int batch) {
     return gemm_plan(M, N, K, nseg, batch, false);
 }
@@ -922,6 +935,19 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
                            int round16, float scale, int scale_cols, float* P32, const float* aux,
                            const int* rowmap, int rpg, long ldaux, const void* auxh, const float* cscale,
                            long sCS, void* stream) {
+    return wc_gemm_f16_grouped(A0, A1, A2, W0, W1, W2, nseg, M, N, K, lda, ldw, batch, sA, sW, sC, bias, resid, ldr, sR,
+                               C32, C16, C16lo, ldc, act, round16, scale, scale_cols, P32, aux, rowmap, rpg, ldaux, auxh,
+                               cscale, sCS, batch, 0, 0, 0, 0, 0, stream);
+}
+
+extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A2, const void* W0,
+                                   const void* W1, const void* W2, int nseg, int M, int N, int K, long lda,
+                                   long ldw, int batch, long sA, long sW, long sC, const float* bias,
+                                   const float* resid, long ldr, long sR, float* C32, void* C16, void* C16lo, long ldc,
+                                   int act, int round16, float scale, int scale_cols, float* P32, const float* aux,
+                                   const int* rowmap, int rpg, long ldaux, const void* auxh, const float* cscale,
+                                   long sCS, int zdiv, long sA2, long sW2, long sC2, long sB2, long sX2, void* stream) {
+    WC_CHECK_ARG(zdiv >= 1 && sA2 % 8 == 0 && sW2 % 8 == 0, "wc_gemm_f16_grouped: zdiv >= 1, sA2 / sW2 %% 8 == 0");
     WC_CHECK_ARG(nseg >= 1 && nseg <= 3, "wc_gemm_f16: nseg must be 1..3");
     WC_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % BK == 0, "wc_gemm_f16: need M,N>0 and K %% 64 == 0 (got M=%d N=%d K=%d)", M, N, K);
     WC_CHECK_ARG(A0 && W0 && (nseg < 2 || (A1 && W1)) && (nseg < 3 || (A2 && W2)),
@@ -943,12 +969,13 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
     g.act = act; g.round16 = round16; g.scale = scale; g.scale_cols = scale_cols;
     g.P32 = P32; g.aux = aux; g.rowmap = rowmap; g.row0 = 0; g.rpg = rpg > 0 ? rpg : 1; g.ldaux = ldaux;
     g.auxh = (const __half*)auxh; g.cscale = cscale; g.sCS = sCS;
+    g.zdiv = zdiv; g.sA2 = sA2; g.sW2 = sW2; g.sC2 = sC2; g.sB2 = sB2; g.sX2 = sX2;
     // wide epilogue needs every 4-column group of a row 16-B (fp32) / 8-B (fp16) addressable
-    g.vec = (ldc % 4 == 0 && sC % 4 == 0 && (!resid || (ldr % 4 == 0 && sR % 4 == 0 && (uintptr_t)resid % 16 == 0)) &&
+    g.vec = (ldc % 4 == 0 && sC % 4 == 0 && sC2 % 4 == 0 && (!resid || (ldr % 4 == 0 && sR % 4 == 0 && (uintptr_t)resid % 16 == 0)) &&
              (!C32 || (uintptr_t)C32 % 16 == 0) && (!C16 || (uintptr_t)C16 % 8 == 0) && (!C16lo || (uintptr_t)C16lo % 8 == 0) &&
              (act != 4 || (ldaux % 4 == 0 && (uintptr_t)aux % 16 == 0)))
                 ? 1 : 0;
-    g.auxvec = (act == 5 && ldaux % 4 == 0 && (uintptr_t)auxh % 8 == 0) ? 1 : 0;
+    g.auxvec = (act == 5 && ldaux % 4 == 0 && sX2 % 4 == 0 && (uintptr_t)auxh % 8 == 0) ? 1 : 0;
     g.gx = wc_cdiv(N, BN);
     const int plan = gemm_plan(M, N, K, nseg, batch, false);
     if (plan) {   // tall GEMM: 256x256 ping-pong kernel

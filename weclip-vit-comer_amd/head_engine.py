@@ -28,6 +28,19 @@ def _f(p):
     return p.detach().float().contiguous()
 
 
+def _uniform_stride(ts):
+    """Element stride between consecutive same-shaped tensors of one allocation, or None."""
+    p = [t.data_ptr() for t in ts]
+    if len(p) < 2:
+        return None
+    d = p[1] - p[0]
+    es = ts[0].element_size()
+    if d <= 0 or d % (8 * es) or any(p[i + 1] - p[i] != d for i in range(len(p) - 1)) or \
+            any(t.shape != ts[0].shape for t in ts):
+        return None
+    return d // es
+
+
 class HeadEngine:
     def __init__(self, fuse, dec):
         self.fuse, self.dec = fuse, dec
@@ -88,15 +101,30 @@ class HeadEngine:
         ctx = dict(B=B, L=Lq, h=h, w=w, xs=xs, drop=drop_scale, ex=ex, front=True)
         # adapters: t1 = relu(X W1^T + b1); cat[:, l] = t1 W2^T + b2
         cat = Split(torch.empty(M, n * E, device=dev, dtype=F16), torch.empty(M, n * E, device=dev, dtype=F16) if ex else None)
-        t1s = []
-        for l, mlp in enumerate(self.fuse.linears_modulelist):
-            a = Split(xs[l].hi.view(-1)[C:], xs[l].lo.view(-1)[C:] if (ex and xs[l].lo is not None) else None)
-            t1 = Split(torch.empty(M, E, device=dev, dtype=F16), torch.empty(M, E, device=dev, dtype=F16) if ex else None)
-            ops.gemm(a, wc.w(f"ad{l}.proj"), hw, E, C, bias=_f(mlp.proj.bias), out16=t1.hi, out16lo=t1.lo,
-                     act=2, batch=B, sA=Lq * C, sW=0, sC=hw * E)
-            ops.gemm(t1, wc.w(f"ad{l}.proj_2"), M, E, E, bias=_f(mlp.proj_2.bias),
-                     out16=cat.hi.view(-1)[l * E:], out16lo=cat.lo.view(-1)[l * E:] if ex else None, ldc=n * E)
-            t1s.append(t1)
+        t1b = Split(torch.empty(n, M, E, device=dev, dtype=F16), torch.empty(n, M, E, device=dev, dtype=F16) if ex else None)
+        t1s = [Split(t1b.hi[l], t1b.lo[l] if ex else None) for l in range(n)]
+        grp = self._adapter_groups(xs, B, Lq, C, ex)
+        if grp is not None:
+            # all n adapters in TWO grouped launches (wc_gemm_f16_grouped) instead of 2 n: the encoder wrote its fp16
+            # block outputs into one (n, B*L, C) buffer and the weight cache holds the adapter weights at a uniform stride
+            xb, sw1, sw2 = grp
+            mods = self.fuse.linears_modulelist
+            b1 = torch.stack([m.proj.bias.detach().float() for m in mods])
+            b2 = torch.stack([m.proj_2.bias.detach().float() for m in mods])
+            a = Split(xb.hi.view(-1)[C:], xb.lo.view(-1)[C:] if (ex and xb.lo is not None) else None)
+            ops.gemm(a, wc.w("ad0.proj"), hw, E, C, bias=b1, out16=t1b.hi, out16lo=t1b.lo, act=2, batch=n * B, zdiv=B,
+                     sA=Lq * C, sA2=B * Lq * C, sW=0, sW2=sw1, sC=hw * E, sC2=M * E, sB2=E)
+            ops.gemm(t1b, wc.w("ad0.proj_2"), M, E, E, bias=b2, out16=cat.hi, out16lo=cat.lo, ldc=n * E, batch=n, zdiv=1,
+                     sA2=M * E, sW2=sw2, sC2=E, sB2=E)
+        else:
+            for l, mlp in enumerate(self.fuse.linears_modulelist):
+                a = Split(xs[l].hi.view(-1)[C:], xs[l].lo.view(-1)[C:] if (ex and xs[l].lo is not None) else None)
+                t1 = t1s[l]
+                ops.gemm(a, wc.w(f"ad{l}.proj"), hw, E, C, bias=_f(mlp.proj.bias), out16=t1.hi, out16lo=t1.lo,
+                         act=2, batch=B, sA=Lq * C, sW=0, sC=hw * E)
+                ops.gemm(t1, wc.w(f"ad{l}.proj_2"), M, E, E, bias=_f(mlp.proj_2.bias),
+                         out16=cat.hi.view(-1)[l * E:], out16lo=cat.lo.view(-1)[l * E:] if ex else None, ldc=n * E)
+        ctx["t1b"] = t1b
         # fuse (1x1 conv) + Dropout2d
         F32_ = torch.empty(M, E, device=dev, dtype=F32)
         # F always carries its fp16 remainder: the Gram matrix F^T F squares the rounding error of F and sigmoid'(0) = 1/4
@@ -201,12 +229,19 @@ class HeadEngine:
         # ---- adapters
         xs, Lq = ctx["xs"], ctx["L"]
         C = xs[0].hi.shape[1]
+        dt1b = torch.empty(n, M, E, device=dev, dtype=F16)
+        swT = _uniform_stride([self.wcache.wT(f"ad{l}.proj_2")[0].hi for l in range(n)])
+        grouped = ctx.get("t1b") is not None and swT is not None and os.environ.get("WECLIP_GROUPED_ADAPTERS", "1") != "0"
+        if grouped:       # dt1[l] = (dcat[:, l] W2[l]) * relu'(t1[l]) for all adapters in one grouped launch
+            ops.gemm(dcat, self.wcache.wT("ad0.proj_2")[0], M, E, E, lda=n * E, out16=dt1b, act=5, auxh=ctx["t1b"].hi,
+                     ldaux=E, batch=n, zdiv=1, sA2=E, sW2=swT, sC2=M * E, sX2=M * E)
         for l, mlp in enumerate(self.fuse.linears_modulelist):
             p = f"fuse.linears_modulelist.{l}."
             dt2 = Split(dcat.hi.view(-1)[l * E:], dcat.lo.view(-1)[l * E:] if ex else None)
             t1 = ctx["t1s"][l]
-            dt1_16 = torch.empty(M, E, device=dev, dtype=F16)
-            ops.gemm(dt2, self.wcache.wT(f"ad{l}.proj_2")[0], M, E, E, lda=n * E, out16=dt1_16, act=5, auxh=t1.hi, ldaux=E)
+            dt1_16 = dt1b[l]
+            if not grouped:
+                ops.gemm(dt2, self.wcache.wT(f"ad{l}.proj_2")[0], M, E, E, lda=n * E, out16=dt1_16, act=5, auxh=t1.hi, ldaux=E)
             wg(dt2.hi, t1.hi, E, E, p + "proj_2.weight", p + "proj_2.bias", lda=n * E)
             # X = the hw patch rows of every image of the (B, 1 + hw, C) encoder tokens (CLS rows skipped)
             wg(dt1_16, xs[l].hi, E, C, p + "proj.weight", p + "proj.bias", xmap=(hw, Lq, 1))
@@ -219,6 +254,25 @@ class HeadEngine:
         if d is not None:
             return d.view(shape)
         return torch.empty(shape, device=self.dec.linear_pred.weight.device, dtype=F32)
+
+    def _adapter_groups(self, xs, B, Lq, C, ex):
+        """(stacked block outputs Split (n, B*L, C), element stride between consecutive adapters' `proj` / `proj_2`
+        operands in the weight cache) when the adapters can run as grouped launches, else None."""
+        n = self.index
+        big = getattr(xs, "big", None)
+        if os.environ.get("WECLIP_GROUPED_ADAPTERS", "1") == "0" or big is None or len(xs) != n or n < 2 or \
+                tuple(big.shape) != (n, B * Lq, C) or (ex and xs.big_lo is None):
+            return None
+        wc = self.wcache
+        st = []
+        for key in ("proj", "proj_2"):
+            p = [wc.w(f"ad{l}.{key}").hi.data_ptr() for l in range(n)]
+            d = p[1] - p[0]
+            if d <= 0 or d % 16 or any(p[l + 1] - p[l] != d for l in range(n - 1)) or \
+                    any(wc.w(f"ad{l}.{key}").hi.shape != wc.w(f"ad0.{key}").hi.shape for l in range(n)):
+                return None
+            st.append(d // 2)
+        return Split(big, xs.big_lo if ex else None), st[0], st[1]
 
     def _ln_dest(self, wname, bname, D):
         """(2, D) view over the weight and bias gradient buffers of a LayerNorm when the caller's bucket holds them

@@ -57,9 +57,10 @@ def split_f16(x, with_lo=False):
 def gemm(a, w, M, N, K, *, lda=None, ldw=None, bias=None, resid=None, ldr=None, sR=None,
          out32=None, out16=None, out16lo=None, ldc=None, act=0, round16=False, scale=1.0,
          scale_cols=0, batch=1, sA=0, sW=0, sC=0, pre32=None, aux=None, rowmap=None, rpg=0,
-         ldaux=0, auxh=None, cscale=None, sCS=0):
+         ldaux=0, auxh=None, cscale=None, sCS=0, zdiv=None, sA2=0, sW2=0, sC2=0, sB2=0, sX2=0):
     """C = epilogue(A W^T).  `a`, `w`: Split (or fp16 tensors).  Segments accumulated:
-    (a.hi,w.hi) [+ (a.lo,w.hi)] [+ (a.hi,w.lo)]."""
+    (a.hi,w.hi) [+ (a.lo,w.hi)] [+ (a.hi,w.lo)].  zdiv / s?2: grouped launch (wc_gemm_f16_grouped): batch index
+    z -> group z // zdiv (second-level strides) and member z % zdiv (sA / sW / sC)."""
     a = a if isinstance(a, Split) else Split(a)
     w = w if isinstance(w, Split) else Split(w)
     segs = [(a.hi, w.hi)]
@@ -74,13 +75,14 @@ def gemm(a, w, M, N, K, *, lda=None, ldw=None, bias=None, resid=None, ldr=None, 
     wp = [L.ptr(s[1], F16, "W") for s in segs] + [None] * (3 - len(segs))
     ldr = ldc if ldr is None else ldr
     sR = sC if sR is None else sR
-    L.lib().wc_gemm_f16(ap[0], ap[1], ap[2], wp[0], wp[1], wp[2], len(segs), M, N, K, lda, ldw,
-                        batch, sA, sW, sC, L.ptr(bias, F32, "bias"), L.ptr(resid, F32, "resid"),
-                        ldr, sR, L.ptr(out32, F32, "out32"), L.ptr(out16, F16, "out16"),
-                        L.ptr(out16lo, F16, "out16lo"), ldc, act, 1 if round16 else 0,
-                        float(scale), scale_cols, L.ptr(pre32, F32, "pre32"), L.ptr(aux, F32, "aux"),
-                        L.ptr(rowmap, torch.int32, "rowmap"), rpg, ldaux, L.ptr(auxh, F16, "auxh"),
-                        L.ptr(cscale, F32, "cscale"), sCS, L.stream())
+    L.lib().wc_gemm_f16_grouped(ap[0], ap[1], ap[2], wp[0], wp[1], wp[2], len(segs), M, N, K, lda, ldw,
+                                batch, sA, sW, sC, L.ptr(bias, F32, "bias"), L.ptr(resid, F32, "resid"),
+                                ldr, sR, L.ptr(out32, F32, "out32"), L.ptr(out16, F16, "out16"),
+                                L.ptr(out16lo, F16, "out16lo"), ldc, act, 1 if round16 else 0,
+                                float(scale), scale_cols, L.ptr(pre32, F32, "pre32"), L.ptr(aux, F32, "aux"),
+                                L.ptr(rowmap, torch.int32, "rowmap"), rpg, ldaux, L.ptr(auxh, F16, "auxh"),
+                                L.ptr(cscale, F32, "cscale"), sCS, batch if zdiv is None else zdiv, sA2, sW2, sC2, sB2,
+                                sX2, L.stream())
 
 
 def layernorm(x, weight, bias, *, eps=1e-5, want32=False, want16=True, with_lo=False, rows=None,
