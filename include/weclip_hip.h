@@ -146,6 +146,10 @@ int wc_sum_slices(const float* part, float* out, int nslices, long n, float alph
  * .weight/.bias gradients of nn.Linear / 1x1 nn.Conv2d (reference WeCLIP_model/segformer_head.py:22-28). */
 int wc_sum_slices_wb(const float* part, float* out_w, float* out_b, int nslices, int rows, int cols,
                      float alpha, void* stream);
+/* `groups` such reductions of one shape in one launch: part (groups, nslices, rows, cols+1); group i writes
+ * out_w + i*gW and out_b + i*gB (elements) -- the per-adapter gradient views of a flat gradient bucket. */
+int wc_sum_slices_wb_grouped(const float* part, float* out_w, float* out_b, int nslices, int rows, int cols,
+                             float alpha, int groups, long gW, long gB, void* stream);
 
 /* Weight-gradient GEMM on row-major operands: part[z, n, k] = sum over the tokens m of slice z of dY[m, n] * X[m, k]
  * (and, with bias != 0, one more column k = K holding sum_m dY[m, n]); z = 0 .. ceil(M / mslice) - 1, mslice a multiple
@@ -156,6 +160,11 @@ int wc_sum_slices_wb(const float* part, float* out_w, float* out_b, int nslices,
  * dense matrix) -- lets X be the patch rows of a (B, 1 + hw, C) token tensor.  zeros: >= 16 zero bytes. */
 int wc_gemm_km_f16(const void* dY, long lda, const void* X, long ldx, const void* zeros, int M, int N, int K,
                    int x_rpg, int x_gs, int x_off, int mslice, int bias, float* part, void* stream);
+/* `groups` weight gradients of one shape in one launch (the 11 adapter Linears, segformer_head.py:58-76): group i
+ * reads dY + i*gA and X + i*gX (elements) and writes part + i*nslices*N*(K+bias). */
+int wc_gemm_km_f16_grouped(const void* dY, long lda, const void* X, long ldx, const void* zeros, int M, int N, int K,
+                           int x_rpg, int x_gs, int x_off, int mslice, int bias, float* part, int groups, long gA,
+                           long gX, void* stream);
 /* fp32 -> fp16 hi (+ lo = fp16(x - hi), may be NULL): `.half()` casts of weights/activations
  * (clip/model.py:457-478 convert_weights; clip/myAtt.py:321). */
 int wc_split_f16(const float* x, void* hi, void* lo, long n, void* stream);

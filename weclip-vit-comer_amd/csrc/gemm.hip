@@ -683,6 +683,7 @@ struct KmArgs {
     int mslice;           // tokens per slice (multiple of 64)
     int bias;
     int gx;
+    long gA, gX, gP;      // group (blockIdx.y) strides of dY, X and the partials, in elements
     GemmArgs e;           // epilogue: M = N, N = K + bias, C32 = partials, ldc, sC
 };
 
@@ -697,6 +698,8 @@ __global__ __launch_bounds__(256, 2) void gemm_km_kernel(KmArgs g) {
     const int ty = blockIdx.x / g.gx, tx = blockIdx.x - ty * g.gx;
     const int n0 = ty * 128, k0 = tx * 128;
     const int z = blockIdx.z;
+    const __half* Ag = g.A + (long)blockIdx.y * g.gA;      // group (e.g. adapter) of a grouped launch
+    const __half* Xg = g.X + (long)blockIdx.y * g.gX;
     const int mbeg = z * g.mslice;
     const int mend = (mbeg + g.mslice < g.M) ? mbeg + g.mslice : g.M;
     const int nt = (mend - mbeg + 63) / 64;
@@ -726,8 +729,8 @@ __global__ __launch_bounds__(256, 2) void gemm_km_kernel(KmArgs g) {
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
             const int m_ = mbeg + (t_) * 64 + rowi[i];                                                           \
             const bool in_ = m_ < mend;                                                                          \
-            const __half* pa_ = (in_ && aok[i]) ? g.A + (long)m_ * g.lda + acol[i] : g.zeros;                    \
-            const __half* px_ = (in_ && xok[i]) ? g.X + ((long)xg[i] * g.x_gs + xr[i] + g.x_off) * g.ldx + xcol[i] : g.zeros; \
+            const __half* pa_ = (in_ && aok[i]) ? Ag + (long)m_ * g.lda + acol[i] : g.zeros;                     \
+            const __half* px_ = (in_ && xok[i]) ? Xg + ((long)xg[i] * g.x_gs + xr[i] + g.x_off) * g.ldx + xcol[i] : g.zeros; \
             __builtin_amdgcn_global_load_lds((gbl_ptr)pa_, (lds_ptr)(dst_ + i * 4096), 16, 0, 0);                \
             __builtin_amdgcn_global_load_lds((gbl_ptr)px_, (lds_ptr)(dst_ + TILE + i * 4096), 16, 0, 0);         \
             xr[i] += 64;                                                                                         \
@@ -813,13 +816,26 @@ __global__ __launch_bounds__(256, 2) void gemm_km_kernel(KmArgs g) {
         }
     }
     const float bv[2] = {0.f, 0.f}, sc[2] = {1.f, 1.f};
-    gemm_epilogue<false>(g.e, acc, n0, k0, wr, wc, lane, z, smem + wave * 8192, bv, sc, (long)z * g.e.sC);
+    gemm_epilogue<false>(g.e, acc, n0, k0, wr, wc, lane, z, smem + wave * 8192, bv, sc, (long)z * g.e.sC + (long)blockIdx.y * g.gP);
 }
 
 // part: (nslices, N, K + bias) fp32 with nslices = ceil(M / mslice); zeros: device buffer of >= 16 zero bytes.
+extern "C" int wc_gemm_km_f16_grouped(const void* dY, long lda, const void* X, long ldx, const void* zeros, int M, int N,
+                                      int K, int x_rpg, int x_gs, int x_off, int mslice, int bias, float* part, int groups,
+                                      long gA, long gX, void* stream);
+
 extern "C" int wc_gemm_km_f16(const void* dY, long lda, const void* X, long ldx, const void* zeros, int M, int N, int K,
                               int x_rpg, int x_gs, int x_off, int mslice, int bias, float* part, void* stream) {
+    return wc_gemm_km_f16_grouped(dY, lda, X, ldx, zeros, M, N, K, x_rpg, x_gs, x_off, mslice, bias, part, 1, 0, 0, stream);
+}
+
+// groups > 1: `groups` weight gradients of one shape in one launch (blockIdx.y): group i reads dY + i*gA and X + i*gX
+// (elements) and writes part + i * nslices * N * (K + bias).
+extern "C" int wc_gemm_km_f16_grouped(const void* dY, long lda, const void* X, long ldx, const void* zeros, int M, int N,
+                                      int K, int x_rpg, int x_gs, int x_off, int mslice, int bias, float* part, int groups,
+                                      long gA, long gX, void* stream) {
     WC_CHECK_ARG(dY && X && zeros && part && M > 0 && N > 0 && K > 0, "wc_gemm_km_f16: bad argument");
+    WC_CHECK_ARG(groups >= 1 && groups <= 65535 && gA % 8 == 0 && gX % 8 == 0, "wc_gemm_km_f16_grouped: bad group strides");
     WC_CHECK_ARG(lda % 8 == 0 && ldx % 8 == 0 && lda >= N && ldx >= K && ((uintptr_t)dY | (uintptr_t)X | (uintptr_t)zeros) % 16 == 0,
                  "wc_gemm_km_f16: operand rows must be 16-byte aligned (lda, ldx %% 8 == 0)");
     WC_CHECK_ARG(mslice > 0 && mslice % 64 == 0, "wc_gemm_km_f16: mslice must be a positive multiple of 64");
@@ -840,10 +856,11 @@ extern "C" int wc_gemm_km_f16(const void* dY, long lda, const void* X, long ldx,
     e.P32 = nullptr; e.aux = nullptr; e.rowmap = nullptr; e.row0 = 0; e.rpg = 1; e.ldaux = 0; e.auxh = nullptr; e.cscale = nullptr;
     e.sCS = 0; e.gx = g.gx; e.gy = wc_cdiv(N, 128); e.vec = 0; e.auxvec = 0;
     e.zdiv = 1; e.sA2 = e.sW2 = e.sC2 = e.sB2 = e.sX2 = 0;
-    dim3 grid((unsigned)(g.gx * wc_cdiv(N, 128)), 1, ns);
+    g.gA = gA; g.gX = gX; g.gP = (long)ns * N * K1;
+    dim3 grid((unsigned)(g.gx * wc_cdiv(N, 128)), groups, ns);
     const int pr = wc_prof_begin(stream);
     hipLaunchKernelGGL(gemm_km_kernel, grid, dim3(256), 4 * 64 * 256, (hipStream_t)stream, g);
-    wc_prof_end(pr, "gemm_km_kernel", 2.0 * M * N * K1, stream);
+    wc_prof_end(pr, "gemm_km_kernel", 2.0 * M * N * K1 * groups, stream);
     WC_LAUNCH_CHECK("gemm_km_kernel");
     return WC_OK;
 }
@@ -862,8 +879,11 @@ __global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict
 // columns 0..cols-1 go to the dense weight gradient out_w (rows, cols), the last column to the bias gradient.
 __global__ __launch_bounds__(256) void sum_slices_wb_kernel(const float* __restrict__ part, float* __restrict__ out_w,
                                                              float* __restrict__ out_b, int nslices, int rows, int cols,
-                                                             float alpha) {
+                                                             float alpha, long gW, long gB) {
     const long n = (long)rows * (cols + 1);
+    part += (long)blockIdx.y * nslices * n;        // group of a grouped weight-gradient launch
+    out_w += (long)blockIdx.y * gW;
+    out_b += (long)blockIdx.y * gB;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // 4 slice loads in flight
@@ -881,11 +901,21 @@ __global__ __launch_bounds__(256) void sum_slices_wb_kernel(const float* __restr
     else out_b[r] = s * alpha;
 }
 
+extern "C" int wc_sum_slices_wb_grouped(const float* part, float* out_w, float* out_b, int nslices, int rows, int cols,
+                                        float alpha, int groups, long gW, long gB, void* stream);
+
 extern "C" int wc_sum_slices_wb(const float* part, float* out_w, float* out_b, int nslices, int rows, int cols,
                                 float alpha, void* stream) {
-    WC_CHECK_ARG(part && out_w && out_b && nslices > 0 && rows > 0 && cols > 0, "wc_sum_slices_wb: bad argument");
-    hipLaunchKernelGGL(sum_slices_wb_kernel, dim3(wc_cdiv((long)rows * (cols + 1), 256)), dim3(256), 0,
-                       (hipStream_t)stream, part, out_w, out_b, nslices, rows, cols, alpha);
+    return wc_sum_slices_wb_grouped(part, out_w, out_b, nslices, rows, cols, alpha, 1, 0, 0, stream);
+}
+
+// part (groups, nslices, rows, cols + 1); group i writes out_w + i*gW and out_b + i*gB (elements)
+extern "C" int wc_sum_slices_wb_grouped(const float* part, float* out_w, float* out_b, int nslices, int rows, int cols,
+                                        float alpha, int groups, long gW, long gB, void* stream) {
+    WC_CHECK_ARG(part && out_w && out_b && nslices > 0 && rows > 0 && cols > 0 && groups >= 1 && groups <= 65535,
+                 "wc_sum_slices_wb: bad argument");
+    hipLaunchKernelGGL(sum_slices_wb_kernel, dim3(wc_cdiv((long)rows * (cols + 1), 256), groups), dim3(256), 0,
+                       (hipStream_t)stream, part, out_w, out_b, nslices, rows, cols, alpha, gW, gB);
     WC_LAUNCH_CHECK("sum_slices_wb_kernel");
     return WC_OK;
 }

@@ -235,6 +235,8 @@ class HeadEngine:
         if grouped:       # dt1[l] = (dcat[:, l] W2[l]) * relu'(t1[l]) for all adapters in one grouped launch
             ops.gemm(dcat, self.wcache.wT("ad0.proj_2")[0], M, E, E, lda=n * E, out16=dt1b, act=5, auxh=ctx["t1b"].hi,
                      ldaux=E, batch=n, zdiv=1, sA2=E, sW2=swT, sC2=M * E, sX2=M * E)
+        if grouped and self._adapter_wgrads_grouped(ctx, dcat, dt1b, xs, B, Lq, C, M, inv, grads):
+            return grads
         for l, mlp in enumerate(self.fuse.linears_modulelist):
             p = f"fuse.linears_modulelist.{l}."
             dt2 = Split(dcat.hi.view(-1)[l * E:], dcat.lo.view(-1)[l * E:] if ex else None)
@@ -273,6 +275,38 @@ class HeadEngine:
                 return None
             st.append(d // 2)
         return Split(big, xs.big_lo if ex else None), st[0], st[1]
+
+    def _adapter_wgrads_grouped(self, ctx, dcat, dt1b, xs, B, Lq, C, M, inv, grads):
+        """Weight / bias gradients of all n adapters in two grouped weight-gradient GEMMs + two grouped split-K
+        reductions (instead of 2 n + 2 n launches), written straight into the caller's gradient bucket.  Needs the
+        stacked encoder outputs and bucket views at a uniform stride between adapters; returns False otherwise."""
+        n, E, hw = self.index, self.E, ctx["h"] * ctx["w"]
+        big = getattr(xs, "big", None)
+        if big is None or not self.direct_grads or tuple(big.shape) != (n, B * Lq, C):
+            return False
+        names = [[f"fuse.linears_modulelist.{l}.{k}" for l in range(n)] for k in ("proj.weight", "proj.bias", "proj_2.weight", "proj_2.bias")]
+        dst = [[self.direct_grads.get(nm) for nm in row] for row in names]
+        if any(d is None or not d.is_contiguous() for row in dst for d in row):
+            return False
+        st = [_uniform_stride(row) for row in dst]
+        if any(v is None for v in st):
+            return False
+        from . import _lib as L
+
+        def run(dy, lda, gA, x, ldx, gX, N_, K_, xmap, gw, gb, sw, sb):
+            tiles = ((N_ + 127) // 128) * ((K_ + 1 + 127) // 128) * n
+            ns = max(1, min(_WGRAD_WGS // tiles, M // 256))       # one round of workgroups (2 per CU), few partials
+            part, ns = ops.wgrad_partials(dy, x, M, N_, K_, lda=lda, ldx=ldx, slices=ns, bias=True, xmap=xmap, groups=n, gA=gA, gX=gX)
+            L.lib().wc_sum_slices_wb_grouped(L.ptr(part, F32), L.ptr(gw, F32), L.ptr(gb, F32), ns, N_, K_, inv, n, sw, sb,
+                                             L.stream())
+
+        # proj_2: dY = dcat[:, l*E:(l+1)*E], X = t1[l];   proj: dY = dt1[l], X = patch rows of block output l
+        run(dcat.hi, n * E, E, ctx["t1b"].hi, E, M * E, E, E, None, dst[2][0], dst[3][0], st[2], st[3])
+        run(dt1b, E, M * E, big, C, B * Lq * C, E, C, (hw, Lq, 1), dst[0][0], dst[1][0], st[0], st[1])
+        for row, drow in zip(names, dst):
+            for nm, d in zip(row, drow):
+                grads[nm] = d
+        return True
 
     def _ln_dest(self, wname, bname, D):
         """(2, D) view over the weight and bias gradient buffers of a LayerNorm when the caller's bucket holds them

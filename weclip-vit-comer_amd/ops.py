@@ -169,10 +169,12 @@ def transpose_f16(src, R, C, *, ld=None, batch=1, sSrc=0, with_lo=False, scale=1
 _ZEROS = {}
 
 
-def wgrad_partials(dy16, x16, M, N, K, *, lda=None, ldx=None, slices=1, bias=True, xmap=None):
+def wgrad_partials(dy16, x16, M, N, K, *, lda=None, ldx=None, slices=1, bias=True, xmap=None, groups=1, gA=0, gX=0):
     """Split-K partials of dW = dY^T X (and db = dY^T 1 as column K) from ROW-MAJOR fp16 operands
     dy16 (M, lda), x16 (rows, ldx): -> (part (ns, N, K + bias) fp32, ns).  xmap = (rows_per_group, group_stride,
-    offset): token m reads X row (m // rpg) * stride + m % rpg + offset (patch rows of a (B, 1 + hw, C) tensor)."""
+    offset): token m reads X row (m // rpg) * stride + m % rpg + offset (patch rows of a (B, 1 + hw, C) tensor).
+    groups > 1: that many gradients of one shape in one launch, group i reading dy16 + i*gA and x16 + i*gX (elements);
+    part is then (groups, ns, N, K + bias)."""
     L.require_gpu()
     lda = N if lda is None else lda
     ldx = K if ldx is None else ldx
@@ -183,10 +185,10 @@ def wgrad_partials(dy16, x16, M, N, K, *, lda=None, ldx=None, slices=1, bias=Tru
     mslice = (-(-M // slices) + 63) // 64 * 64
     ns = -(-M // mslice)
     K1 = K + (1 if bias else 0)
-    part = torch.empty(ns, N, K1, device=dev, dtype=F32)
+    part = torch.empty((ns, N, K1) if groups == 1 else (groups, ns, N, K1), device=dev, dtype=F32)
     rpg, gs, off = xmap if xmap is not None else (max(M, 64), 0, 0)
-    L.lib().wc_gemm_km_f16(L.ptr(dy16, F16, "dY"), lda, L.ptr(x16, F16, "X"), ldx, L.ptr(z), M, N, K, rpg, gs, off,
-                           mslice, 1 if bias else 0, L.ptr(part), L.stream())
+    L.lib().wc_gemm_km_f16_grouped(L.ptr(dy16, F16, "dY"), lda, L.ptr(x16, F16, "X"), ldx, L.ptr(z), M, N, K, rpg, gs, off,
+                                   mslice, 1 if bias else 0, L.ptr(part), groups, gA, gX, L.stream())
     return part, ns
 
 
