@@ -50,6 +50,12 @@ int wc_par_iterate(const float* aff, const float* masks_in, float* masks_out, in
 int wc_par_forward(const float* img, const float* masks, float* out, float* tmp, float* aff_ws,
                    int B, int C, int H, int W, const int* h_dilations, int n_dil, int num_iter,
                    int group, void* stream);
+/* Same sweep with the affinities stored as 16-bit fixed-point pairs + one fp32 scale per pixel between the iterations
+ * (half the HBM bytes per sweep; |rounding error| <= max_t a_t * 7.7e-6 per weight, error-diffused so a pixel's weights
+ * keep their sum): the `fast` precision mode.  6 dilations (48 taps) only; aff_ws as for wc_par_forward. */
+int wc_par_forward_h(const float* img, const float* masks, float* out, float* tmp, float* aff_ws,
+                   int B, int C, int H, int W, const int* h_dilations, int n_dil, int num_iter,
+                   int group, void* stream);
 /* WeCLIP_model/model_attn_aff_voc.py:49-57 (`_refine_cams` tail): labels = valid_key[argmax_c].
  * valid_key (B,C) i64, nch (B) i32 channels in use per image (NULL = C), labels (B,H,W) i64. */
 int wc_par_labels(const float* masks, const int64_t* valid_key, const int* nch, int64_t* labels,

@@ -16,19 +16,31 @@ def PAR():
     return PAR
 
 
-def test_par_matches_reference_golden(PAR, golden):
+@pytest.fixture(params=["exact", "fast"])
+def tol(request, monkeypatch):
+    """exact: fp32 affinities between the sweeps, the tight tolerances below.  fast: the affinities are stored as fp16
+    pairs (|rounding| <= 7.7e-6 per weight, wc_par_forward_h); 20 sweeps of 48 weights accumulate to <= 3e-4 absolute
+    on masks in [0, 1.22] (tolerance written here: 5e-4)."""
+    from weclip_vit_comer_amd import config
+    monkeypatch.setattr(config, "precision", request.param)
+    if request.param == "exact":
+        return lambda t, fast=None: t
+    return lambda t, fast=None: fast if fast is not None else max(t, 5e-4)
+
+
+def test_par_matches_reference_golden(PAR, golden, tol):
     g = golden("tiny_func.npz")
     img = synth.make_images(2, *synth.TINY_HW)[:1].cuda()
     out = PAR(DIL, 20).cuda()(img, torch.from_numpy(g["par_masks"]).cuda())
-    np.testing.assert_allclose(out.cpu().numpy(), g["par_out"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(out.cpu().numpy(), g["par_out"], rtol=0, atol=tol(3e-5))
     # ragged size (37x53, smaller than the largest dilation), 5 channels, 3 iterations
     img2 = synth.make_images(1, 37, 53, seed=5).cuda()
     out2 = PAR(DIL, 3).cuda()(img2, torch.from_numpy(g["par2_masks"]).cuda())
-    np.testing.assert_allclose(out2.cpu().numpy(), g["par2_out"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out2.cpu().numpy(), g["par2_out"], rtol=0, atol=tol(2e-5))
 
 
 @pytest.mark.parametrize("shape", [(1, 2, 48, 80), (3, 3, 96, 64), (2, 6, 33, 130)])
-def test_par_matches_oracle(PAR, shape):
+def test_par_matches_oracle(PAR, shape, tol):
     b, C, H, W = shape
     img = synth.make_images(b, H, W, seed=3)
     g = torch.Generator().manual_seed(4)
@@ -40,19 +52,20 @@ def test_par_matches_oracle(PAR, shape):
         ref_aff = O.par_affinity(img[i:i + 1])
         np.testing.assert_allclose(aff[i].numpy(), ref_aff.numpy(), rtol=0, atol=2e-6)
         ref = O.par(img[i:i + 1], masks[i:i + 1])
-        np.testing.assert_allclose(out[i].numpy(), ref[0].numpy(), rtol=0, atol=3e-5)
+        print("PAR max abs error", (out[i] - ref[0]).abs().max().item())
+        np.testing.assert_allclose(out[i].numpy(), ref[0].numpy(), rtol=0, atol=tol(3e-5))
 
 
-def test_par_image_resized_to_mask_size(PAR):
+def test_par_image_resized_to_mask_size(PAR, tol):
     """val mode: image at another size than the masks (PAR.py:67, align_corners=True)."""
     img = synth.make_images(1, 40, 56, seed=9)
     masks = torch.rand(1, 3, 64, 80, generator=torch.Generator().manual_seed(1))
     out = PAR(DIL, 4).cuda()(img.cuda(), masks.cuda()).cpu()
     ref = O.par(img, masks, num_iter=4)
-    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=0, atol=tol(2e-5))
 
 
-def test_par_full_size_properties(PAR):
+def test_par_full_size_properties(PAR, tol):
     """BASELINE size 512x512, K+1 = 3: mass growth 1.01^20 and constant-mask fixed point."""
     B, C, H, W = 4, 3, 512, 512
     img = synth.make_images(B, H, W, seed=100).cuda()
@@ -64,13 +77,14 @@ def test_par_full_size_properties(PAR):
     out = mod(img, masks)
     ratio = (out.sum() / masks.sum()).item()
     assert abs(ratio - 1.01 ** 20) < 5e-3
+    # fast mode: the fp16 rounding of the 48 weights moves a row sum by ~3e-5 per sweep
     ones = torch.ones(B, C, H, W, device="cuda")
     out1 = mod(img, ones)
-    assert (out1 - 1.01 ** 20).abs().max().item() < 1e-4  # linear operator with row sums 1.01
+    assert (out1 - 1.01 ** 20).abs().max().item() < tol(1e-4, fast=3e-3)  # linear operator with row sums 1.01
     # linearity in the masks
     a, b = torch.rand_like(masks), torch.rand_like(masks)
     lin = mod(img, 2 * a + 3 * b) - (2 * mod(img, a) + 3 * mod(img, b))
-    assert lin.abs().max().item() < 1e-4
+    assert lin.abs().max().item() < 1e-4              # exact in both modes: the same stored weights in all three runs
 
 
 def test_refine_labels(PAR):

@@ -4,6 +4,8 @@
 `kernel` (8,1,3,3) buffer is kept so reference checkpoints (which store `par.kernel`,
 SURVEY.md §5) load with identical keys.  The arithmetic runs in csrc/par.hip.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -51,19 +53,22 @@ class PAR(nn.Module):
             # PAR.py:67 -- F.interpolate(imgs, size=masks, bilinear, align_corners=True)
             imgs = bilinear_resize(imgs, (h, w), align_corners=True)
         T = 8 * len(self.dilations)
+        # "fast" precision: the affinities live as 16-bit fixed-point pairs + a per-pixel scale between the sweeps (half
+        # the bytes of the HBM-bound sweep; |rounding error| <= max weight * 7.7e-6, error-diffused: csrc/par.hip)
+        from .. import config
+        h16 = T == 48 and not config.exact() and os.environ.get("WECLIP_PAR_F16", "1") != "0"
         # group so that aff + masks of a group stay inside the 256 MiB Infinity Cache across the sweeps
-        per_img = (T + 3 * C) * h * w * 4
+        per_img = ((T // 2 + 1 if h16 else T) + 3 * C) * h * w * 4
         group = max(1, min(b, (240 << 20) // max(per_img, 1)))   # measured best: 4 images at 512x512, C=3
-        import os
         if os.environ.get("WECLIP_PAR_GROUP"):
             group = max(1, min(b, int(os.environ["WECLIP_PAR_GROUP"])))
         out = torch.empty_like(masks)
         tmp = torch.empty_like(masks)
         aff = torch.empty(group * T * h * ((w + 63) // 64 * 64), device=masks.device, dtype=torch.float32)
         d = L.int_array(self.dilations)
-        L.lib().wc_par_forward(L.ptr(imgs, torch.float32, "imgs"), L.ptr(masks), L.ptr(out),
-                               L.ptr(tmp), L.ptr(aff), b, C, h, w, d, len(self.dilations),
-                               self.num_iter, group, L.stream())
+        fwd = L.lib().wc_par_forward_h if h16 else L.lib().wc_par_forward
+        fwd(L.ptr(imgs, torch.float32, "imgs"), L.ptr(masks), L.ptr(out), L.ptr(tmp), L.ptr(aff), b, C, h, w, d,
+            len(self.dilations), self.num_iter, group, L.stream())
         return out
 
 

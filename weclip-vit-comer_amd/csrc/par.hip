@@ -84,7 +84,13 @@ __device__ __forceinline__ long aff_base(bool tiled, long img, int T, int H, int
     return img * T * (long)H * W + (long)y * W + x;
 }
 
-template <int ND, bool TILED>
+// H16 (only with TILED): the affinities are stored as 16-bit fixed-point PAIRS with one fp32 scale per pixel,
+// [image][y][x/64][tap/2 (+1 slot: the scale)][64] dwords -- one 4-byte load per lane fetches two taps, a sweep reads
+// half the bytes.  q_t = round(a_t / scale), scale = max_t a_t / 65535: |error| <= max_t a_t * 7.7e-6 per weight (a
+// flat region has max a ~ 0.02: 1.6e-7; fp16 storage would be 7.6e-6 there and measured 3e-3 on the masks after 20
+// sweeps).  Used by the "fast" precision mode only; the exact mode keeps fp32.
+#define PAR_Q_SLOTS(T_) ((T_) / 2 + 1)
+template <int ND, bool TILED, bool H16 = false>
 __global__ __launch_bounds__(256) void par_affinity_reg_kernel(const float* __restrict__ img,
                                                                 float* __restrict__ aff, int H, int W,
                                                                 float w1, ParTaps taps) {
@@ -130,6 +136,33 @@ __global__ __launch_bounds__(256) void par_affinity_reg_kernel(const float* __re
         sum += v0[t];
     }
     const float inv = 1.0f / sum;
+    if constexpr (H16) {
+        const int XT = (W + 63) >> 6;
+        unsigned* A2 = reinterpret_cast<unsigned*>(aff) + (((long)blockIdx.z * H + y) * XT + (x >> 6)) * (long)PAR_Q_SLOTS(T) * 64 + (x & 63);
+        float amax = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            v0[t] = v0[t] * inv + taps.pi[t];
+            amax = fmaxf(amax, v0[t]);
+        }
+        const float scale = amax * (1.0f / 65535.0f), rs = 65535.0f / amax;
+        // error-diffused rounding: each weight takes over the rounding remainder of the previous one, so the 48 stored
+        // weights of a pixel sum to the fp32 row sum within ONE quantum (plain rounding is biased where the weights are
+        // nearly equal: flat regions round all 48 the same way and the bias compounds over the 20 sweeps)
+        float carry = 0.f;
+#pragma unroll
+        for (int j = 0; j < T / 2; ++j) {
+            const float a0 = v0[2 * j] + carry;
+            const float q0 = fminf(fmaxf(rintf(a0 * rs), 0.f), 65535.f);
+            carry = a0 - q0 * scale;
+            const float a1 = v0[2 * j + 1] + carry;
+            const float q1 = fminf(fmaxf(rintf(a1 * rs), 0.f), 65535.f);
+            carry = a1 - q1 * scale;
+            A2[j * 64] = (unsigned)q0 | ((unsigned)q1 << 16);
+        }
+        A2[(T / 2) * 64] = __float_as_uint(scale);
+        return;
+    }
     long ts;
     float* A = aff + aff_base(TILED, blockIdx.z, T, H, W, y, x, &ts);
 #pragma unroll
@@ -137,9 +170,14 @@ __global__ __launch_bounds__(256) void par_affinity_reg_kernel(const float* __re
 }
 
 static void launch_affinity(const float* img, float* aff, int nb, int H, int W, const ParTaps& tp,
-                            hipStream_t st, bool tiled) {
+                            hipStream_t st, bool tiled, bool h16 = false) {
     dim3 grid(wc_cdiv(W, 64), wc_cdiv(H, 4), nb);
     const int pr = wc_prof_begin(st);
+    if (tp.n == 48 && tiled && h16) {
+        hipLaunchKernelGGL((par_affinity_reg_kernel<6, true, true>), grid, dim3(256), 0, st, img, aff, H, W, 0.3f, tp);
+        wc_prof_end(pr, "par_affinity_reg_kernel<6, true, true>", 4.0 * nb * (double)H * W * 3 + nb * (double)H * W * (2.0 * tp.n + 4.0), st);
+        return;
+    }
     if (tp.n == 48 && tiled)
         hipLaunchKernelGGL((par_affinity_reg_kernel<6, true>), grid, dim3(256), 0, st, img, aff, H, W, 0.3f, tp);
     else if (tp.n == 48)
@@ -157,7 +195,7 @@ static void launch_affinity(const float* img, float* aff, int nb, int H, int W, 
 #ifndef PAR_TAP_BATCH
 #define PAR_TAP_BATCH 8
 #endif
-template <int CG, bool TILED>
+template <int CG, bool TILED, bool H16 = false>
 __global__ __launch_bounds__(256) void par_iter_kernel(const float* __restrict__ aff,
                                                         const float* __restrict__ min,
                                                         float* __restrict__ mout, int C, int H,
@@ -170,6 +208,10 @@ __global__ __launch_bounds__(256) void par_iter_kernel(const float* __restrict__
     const int T = taps.n;
     long ts;
     const float* A = aff + aff_base(TILED, blockIdx.z, T, H, W, y, x, &ts);
+    const unsigned* A2 = reinterpret_cast<const unsigned*>(aff) +
+                         (((long)blockIdx.z * H + y) * ((W + 63) >> 6) + (x >> 6)) * (long)PAR_Q_SLOTS(T) * 64 + (x & 63);   // H16 layout
+    float qscale = 1.f;
+    if constexpr (H16) qscale = __uint_as_float(A2[(T / 2) * 64]);
     const float* M = min + (long)blockIdx.z * C * HW;
     float* O = mout + (long)blockIdx.z * C * HW + p;
     for (int cb = 0; cb < C; cb += CG) {
@@ -186,12 +228,24 @@ __global__ __launch_bounds__(256) void par_iter_kernel(const float* __restrict__
         int t = 0;
         for (; t + TB_ <= T; t += TB_) {
             float a[TB_], m[TB_][CG];
+            unsigned a2[TB_ / 2];
+            if constexpr (H16) {
+#pragma unroll
+                for (int u = 0; u < TB_ / 2; ++u) a2[u] = A2[((t >> 1) + u) * 64];
+            }
 #pragma unroll
             for (int u = 0; u < TB_; ++u) {
-                a[u] = A[(t + u) * ts];
+                if constexpr (!H16) a[u] = A[(t + u) * ts];
                 const int o = clampi(y + taps.dy[t + u], H - 1) * W + clampi(x + taps.dx[t + u], W - 1);
 #pragma unroll
                 for (int k = 0; k < CG; ++k) m[u][k] = Mc[k][o];
+            }
+            if constexpr (H16) {
+#pragma unroll
+                for (int u = 0; u < TB_ / 2; ++u) {
+                    a[2 * u] = (float)(a2[u] & 0xffffu);
+                    a[2 * u + 1] = (float)(a2[u] >> 16);
+                }
             }
 #pragma unroll
             for (int u = 0; u < TB_; ++u)
@@ -206,7 +260,7 @@ __global__ __launch_bounds__(256) void par_iter_kernel(const float* __restrict__
         }
 #pragma unroll
         for (int k = 0; k < CG; ++k)
-            if (cb + k < C) O[(long)(cb + k) * HW] = acc[k];
+            if (cb + k < C) O[(long)(cb + k) * HW] = H16 ? acc[k] * qscale : acc[k];
     }
 }
 
@@ -272,8 +326,19 @@ extern "C" int wc_par_affinity(const float* img, float* aff, int B, int H, int W
 }
 
 static int launch_iter(const float* aff, const float* src, float* dst, int B, int C, int H, int W,
-                       const ParTaps& tp, hipStream_t st, bool tiled) {
+                       const ParTaps& tp, hipStream_t st, bool tiled, bool h16 = false) {
     dim3 grid(wc_cdiv(W, 64), wc_cdiv(H, 4), B);
+    if (h16) {       // fp16-pair affinities (tiled layout, 48 taps)
+        const int pr = wc_prof_begin(st);
+        if (C <= 2) hipLaunchKernelGGL((par_iter_kernel<2, true, true>), grid, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
+        else if (C == 3) hipLaunchKernelGGL((par_iter_kernel<3, true, true>), grid, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
+        else hipLaunchKernelGGL((par_iter_kernel<4, true, true>), grid, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
+        static const char* hn[3] = {"par_iter_kernel<2, true, true>", "par_iter_kernel<3, true, true>", "par_iter_kernel<4, true, true>"};
+        // algorithmic bytes of one sweep: T 16-bit affinities + the scale + C mask planes read, C written
+        wc_prof_end(pr, hn[C <= 2 ? 0 : (C == 3 ? 1 : 2)], B * (double)H * W * (2.0 * tp.n + 4.0 + 8.0 * C), st);
+        WC_LAUNCH_CHECK("par_iter_kernel");
+        return WC_OK;
+    }
 #define PAR_ITER_LAUNCH(CG_) \
     if (tiled) hipLaunchKernelGGL((par_iter_kernel<CG_, true>), grid, dim3(256), 0, st, aff, src, dst, C, H, W, tp); \
     else hipLaunchKernelGGL((par_iter_kernel<CG_, false>), grid, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
@@ -302,9 +367,27 @@ extern "C" int wc_par_iterate(const float* aff, const float* masks_in, float* ma
 // Images are processed in groups of `group` so that a group's aff planes (T*H*W*4 B each)
 // stay resident in the 256 MiB Infinity Cache across the num_iter sweeps.
 // Workspaces: aff_ws >= min(group,B)*T*H*ceil64(W) floats, tmp >= B*C*H*W floats.
+static int par_forward_impl(const float* img, const float* masks, float* out, float* tmp, float* aff_ws, int B, int C,
+                            int H, int W, const int* dilations, int n_dil, int num_iter, int group, void* stream, bool h16);
+
 extern "C" int wc_par_forward(const float* img, const float* masks, float* out, float* tmp,
                               float* aff_ws, int B, int C, int H, int W, const int* dilations,
                               int n_dil, int num_iter, int group, void* stream) {
+    return par_forward_impl(img, masks, out, tmp, aff_ws, B, C, H, W, dilations, n_dil, num_iter, group, stream, false);
+}
+
+// Same, with the affinities kept as 16-bit fixed-point pairs + one scale per pixel between the sweeps (half the bytes
+// per sweep; |error| <= max_t a_t * 7.7e-6 per weight): the "fast" precision mode.  Needs the 48-tap configuration
+// (6 dilations); aff_ws: (T/2 + 1) * H * ceil64(W) dwords per image of a group.
+extern "C" int wc_par_forward_h(const float* img, const float* masks, float* out, float* tmp,
+                                float* aff_ws, int B, int C, int H, int W, const int* dilations,
+                                int n_dil, int num_iter, int group, void* stream) {
+    WC_CHECK_ARG(n_dil == 6, "wc_par_forward_h: needs 6 dilations (48 taps)");
+    return par_forward_impl(img, masks, out, tmp, aff_ws, B, C, H, W, dilations, n_dil, num_iter, group, stream, true);
+}
+
+static int par_forward_impl(const float* img, const float* masks, float* out, float* tmp, float* aff_ws, int B, int C,
+                            int H, int W, const int* dilations, int n_dil, int num_iter, int group, void* stream, bool h16) {
     WC_CHECK_ARG(img && masks && out && tmp && aff_ws && B > 0 && C > 0 && H > 0 && W > 0 &&
                      num_iter >= 1 && group >= 1,
                  "wc_par_forward: bad argument");
@@ -316,12 +399,12 @@ extern "C" int wc_par_forward(const float* img, const float* masks, float* out, 
     const bool tiled = (tp.n == 48);   // strip-interleaved aff (needs aff_ws >= group*T*H*ceil64(W) floats)
     for (int b0 = 0; b0 < B; b0 += group) {
         const int nb = (B - b0 < group) ? B - b0 : group;
-        launch_affinity(img + (long)b0 * 3 * HW, aff_ws, nb, H, W, tp, st, tiled);
+        launch_affinity(img + (long)b0 * 3 * HW, aff_ws, nb, H, W, tp, st, tiled, h16 && tiled);
         WC_LAUNCH_CHECK("par_affinity_kernel");
         const float* src = masks + (long)b0 * C * HW;
         for (int i = 0; i < num_iter; ++i) {
             float* dst = (((num_iter - i) & 1) ? out : tmp) + (long)b0 * C * HW;
-            int rc = launch_iter(aff_ws, src, dst, nb, C, H, W, tp, st, tiled);
+            int rc = launch_iter(aff_ws, src, dst, nb, C, H, W, tp, st, tiled, h16 && tiled);
             if (rc) return rc;
             src = dst;
         }
