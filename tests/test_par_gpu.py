@@ -77,7 +77,7 @@ def test_par_full_size_properties(PAR, tol):
     out = mod(img, masks)
     ratio = (out.sum() / masks.sum()).item()
     assert abs(ratio - 1.01 ** 20) < 5e-3
-    # fast mode: the fp16 rounding of the 48 weights moves a row sum by ~3e-5 per sweep
+    # fast mode: the 16-bit rounding of the 48 weights is error-diffused, a row sum moves by at most one quantum per sweep
     ones = torch.ones(B, C, H, W, device="cuda")
     out1 = mod(img, ones)
     assert (out1 - 1.01 ** 20).abs().max().item() < tol(1e-4, fast=3e-3)  # linear operator with row sums 1.01
