@@ -110,11 +110,37 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         const bool full = gcol + 3 < g.N;
         const bool has_lo = g.C16lo != nullptr;
         const bool has_sc = g.scale_cols > 0 || g.cscale != nullptr;     // uniform: most launches carry no column scale
+        // act 4: the fp32 aux rows (row-mapped, 16 B per lane and row) of chunk c+1 are requested before chunk c is
+        // processed, so their HBM latency hides behind one chunk of epilogue work instead of stalling every chunk
+        float ua[2][4][4];
+        auto aux_load = [&](int c, float (&dst)[4][4]) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int grow = m0 + wr * 64 + c * 16 + it * 4 + (lane >> 4);
+                dst[it][0] = dst[it][1] = dst[it][2] = dst[it][3] = 0.f;
+                if (grow < g.M && gcol < g.N) {
+                    const long arow = g.rowmap ? (long)g.rowmap[(grow + g.row0) / g.rpg] * g.rpg + (grow + g.row0) % g.rpg : grow;
+                    const float* up = g.aux + arow * g.ldaux + gcol;
+                    if (full) {
+                        const float4 u4 = *reinterpret_cast<const float4*>(up);
+                        dst[it][0] = u4.x; dst[it][1] = u4.y; dst[it][2] = u4.z; dst[it][3] = u4.w;
+                    } else {
+                        for (int k = 0; k < 4 && gcol + k < g.N; ++k) dst[it][k] = up[k];
+                    }
+                }
+            }
+        };
+        if constexpr (AUX) {
+            if (act == 4) aux_load(0, ua[0]);
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {            // rows [16c, 16c+16) of the wave's 64x64 sub-tile
             const int mi = c >> 1, rq0 = (c & 1) * 8;
             float* tile = tile0 + (c & 1) * 1024;
             float v[16];
+            if constexpr (AUX) {
+                if (act == 4 && c + 1 < 4) aux_load(c + 1, ua[(c + 1) & 1]);
+            }
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -152,11 +178,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                     if (!ok[it]) continue;
                     const int grow = m0 + wr * 64 + c * 16 + it * 4 + (lane >> 4);
                     if (act == 4) {
-                        const long arow = g.rowmap ? (long)g.rowmap[(grow + g.row0) / g.rpg] * g.rpg + (grow + g.row0) % g.rpg : grow;
-                        const float* up = g.aux + arow * g.ldaux + gcol;
-                        float u[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (full) { const float4 u4 = *reinterpret_cast<const float4*>(up); u[0] = u4.x; u[1] = u4.y; u[2] = u4.z; u[3] = u4.w; }
-                        else for (int k = 0; k < 4 && gcol + k < g.N; ++k) u[k] = up[k];
+                        const float (&u)[4] = ua[c & 1][it];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u[k]));
