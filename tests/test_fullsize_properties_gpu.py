@@ -75,6 +75,29 @@ def test_par_operator_identities_at_512():
     assert torch.equal(par(img, a).argmax(1), par(img, 4.0 * a).argmax(1))
 
 
+def test_par_fixed_point_affinities_agree_with_fp32_at_512(monkeypatch):
+    """`fast` precision keeps the PAR affinities as error-diffused 16-bit fixed point between the 20 sweeps
+    (wc_par_forward_h).  At the benchmark size, on CAM-like masks (a 32x32 score map up-sampled to 512x512, the real
+    input of PAR): refined masks within 5e-4 of the fp32 sweep (the tolerance of tests/test_par_gpu.py) and the same
+    arg-max labels on all but 0.01 % of the pixels (near-ties between two refined scores)."""
+    import torch.nn.functional as F
+    from weclip_vit_comer_amd import config
+    from weclip_vit_comer_amd.WeCLIP_model.PAR import PAR
+    par = PAR([1, 2, 4, 8, 12, 24], 20).cuda()
+    img = synth.make_images(4, 512, 512, seed=31).cuda()
+    g = torch.Generator().manual_seed(8)
+    low = torch.rand(4, 3, 32, 32, generator=g).cuda()
+    masks = F.interpolate(low, size=(512, 512), mode="bilinear", align_corners=False).contiguous()
+    out = {}
+    for mode in ("exact", "fast"):
+        monkeypatch.setattr(config, "precision", mode)
+        out[mode] = par(img, masks)
+    err = (out["fast"] - out["exact"]).abs().max().item()
+    mism = (out["fast"].argmax(1) != out["exact"].argmax(1)).float().mean().item()
+    print(f"PAR 512^2 fixed-point vs fp32 affinities: max abs {err:.2e}, label mismatch {mism:.4%}")
+    assert err < 5e-4 and mism < 1e-4          # measured: 1.6e-4, 0.0012 % of the pixels
+
+
 def test_training_step_is_deterministic_and_finite_at_512():
     from weclip_vit_comer_amd.WeCLIP_model.model_attn_aff_voc import WeCLIP
     from weclip_vit_comer_amd.train_step import TrainStep
