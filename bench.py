@@ -163,7 +163,9 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f16 MFMA operands / f32 accumulate, f32 residual+softmax+LN+PAR (precision=%s)" % config.precision,
+        "dtype": ("f16 MFMA operands / f32 accumulate, f32 residual+softmax+LN, PAR f32 arithmetic on 16-bit fixed-point "
+                  "affinities (precision=fast)") if config.precision == "fast" else
+                 "f16 hi+lo MFMA operands / f32 accumulate, f32 residual+softmax+LN+PAR (precision=%s)" % config.precision,
         "data": "synthetic",
         "config": {"workload": f"WeCLIP VOC full train step, batch {B}/GPU at {S}x{S}, K={K} classes/image "
                                f"(BASELINE configs[2]{'/[3] DP' if world > 1 else ''})" + (" + ViT-CoMer inserts" if args.comer else ""),
