@@ -137,6 +137,36 @@ def test_gemm_ragged_rows_split(ops):
     assert _rel(out.cpu().double(), ref4) < 2e-6
 
 
+def test_gemm_grouped_two_level_batch(ops):
+    """wc_gemm_f16_grouped: batch index z = group * zdiv + member.  (a) groups x members with per-group weights / biases
+    and outputs written side by side (the adapters' first Linear: blocks x images); (b) groups only, A taken as column
+    slices of one matrix, act 5 with a per-group fp16 aux (the adapters' ReLU backward)."""
+    g = torch.Generator().manual_seed(21)
+    G, Bm, Mi, N, K = 3, 4, 192, 128, 192             # groups, members, rows per member
+    a = torch.randn(G, Bm, Mi + 1, K, generator=g).half()        # one extra leading row per member (like the CLS row)
+    w = (torch.randn(G, N, K, generator=g) * 0.05).half()
+    bias = torch.randn(G, N, generator=g)
+    out = torch.zeros(Bm * Mi, G * N, device="cuda", dtype=torch.float16)
+    ad = a.cuda()
+    ops.gemm(ad.view(-1)[K:], w.cuda(), Mi, N, K, bias=bias.cuda(), out16=out, act=2, batch=G * Bm, zdiv=Bm,
+             sA=(Mi + 1) * K, sA2=Bm * (Mi + 1) * K, sW=0, sW2=N * K, sC=Mi * G * N, sC2=N, sB2=N, ldc=G * N)
+    for gi in range(G):
+        ref = torch.relu(a[gi, :, 1:].double() @ w[gi].double().t() + bias[gi].double()).reshape(Bm * Mi, N)
+        got = out[:, gi * N:(gi + 1) * N].cpu().double()
+        assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item(), gi
+    # (b)
+    M = 512
+    dcat = torch.randn(M, G * N, generator=g).half()
+    w2t = (torch.randn(G, N, N, generator=g) * 0.05).half()          # (out, k) per group
+    t1 = torch.randn(G, M, N, generator=g).half()
+    dt1 = torch.zeros(G, M, N, device="cuda", dtype=torch.float16)
+    ops.gemm(dcat.cuda(), w2t.cuda(), M, N, N, lda=G * N, out16=dt1, act=5, auxh=t1.cuda(), ldaux=N, batch=G, zdiv=1,
+             sA2=N, sW2=N * N, sC2=M * N, sX2=M * N)
+    for gi in range(G):
+        ref = (dcat[:, gi * N:(gi + 1) * N].double() @ w2t[gi].double().t()) * (t1[gi].double() > 0)
+        assert (dt1[gi].cpu().double() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item(), gi
+
+
 def test_gemm_batched(ops):
     Bn, M, N, K = 3, 130, 70, 64
     g = torch.Generator().manual_seed(1)
