@@ -138,6 +138,35 @@ def test_weight_gradient_gemm_row_major_operands(M, N, K, lda, slices):
     assert (got[:, K] - refb).abs().max() / refb.abs().max() < 2e-6
 
 
+def test_grouped_weight_gradient_and_slice_reduction():
+    """wc_gemm_km_f16_grouped + wc_sum_slices_wb_grouped: G weight gradients of one shape in one launch each (the
+    adapters): dY taken as column slices of one matrix, X from a stacked (G, B, 1 + hw, C) token buffer through the row
+    map, results written at a uniform stride into one flat buffer (the gradient bucket layout)."""
+    from weclip_vit_comer_amd import _lib as L, ops
+    G, B, hw, C, N = 3, 2, 160, 192, 64
+    M = B * hw
+    g = torch.Generator().manual_seed(17)
+    dy = torch.randn(M, G * N, generator=g).half()
+    tok = torch.randn(G, B, 1 + hw, C, generator=g).half()
+    part, ns = ops.wgrad_partials(dy.cuda(), tok.cuda(), M, N, C, lda=G * N, ldx=C, slices=3, bias=True, xmap=(hw, 1 + hw, 1),
+                                  groups=G, gA=N, gX=B * (1 + hw) * C)
+    assert tuple(part.shape) == (G, ns, N, C + 1)
+    stride = N * C + N + 40                      # weight, bias, then unrelated parameters of the group
+    flat = torch.full((G * stride,), 7.0, device="cuda")
+    gw, gb = flat[:N * C], flat[N * C:N * C + N]
+    L.lib().wc_sum_slices_wb_grouped(L.ptr(part, torch.float32), L.ptr(gw, torch.float32), L.ptr(gb, torch.float32), ns, N, C,
+                                     0.5, G, stride, stride, L.stream())
+    flat = flat.cpu().double()
+    for gi in range(G):
+        dyg = dy[:, gi * N:(gi + 1) * N].double()
+        ref = 0.5 * dyg.t() @ tok[gi, :, 1:].reshape(M, C).double()
+        refb = 0.5 * dyg.sum(0)
+        o = gi * stride
+        assert (flat[o:o + N * C].view(N, C) - ref).abs().max() / ref.abs().max() < 2e-6
+        assert (flat[o + N * C:o + N * C + N] - refb).abs().max() / refb.abs().max() < 2e-6
+        assert (flat[o + N * C + N:o + stride] == 7.0).all()          # nothing else touched
+
+
 def test_weight_gradient_gemm_skips_cls_rows():
     """X = the patch rows of a (B, 1 + hw, C) token tensor, addressed through the row map."""
     from weclip_vit_comer_amd import ops
