@@ -8,23 +8,29 @@ adapters/decoder, (DP: one RCCL all-reduce of the 5.99 M gradients), AdamW step.
 BASELINE.json metric: images/sec (train fwd+bwd) ViT-B/16 512x512; per-GPU batch 16 (configs[2]).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 4 ...          (starts 4 rank processes itself when WORLD_SIZE is unset)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  `roofline`: dominant kernel family timed with HIP events on the
-launch stream during the timed steps; `cpu_baseline`: the CPU oracle (oracle/weclip_oracle.py, a
-port of the reference's CPU path) on a bounded sample of the same workload.
+Prints ONE JSON line on rank 0.
+  * `value`: the timed region replays the HIP graph of the step (train_step.TrainStep(graph=True)); every step gets
+    another batch from the per-rank seeded loader.
+  * `roofline`: dominant kernel family timed with HIP events on the launch stream, recorded by the C library at its
+    launch sites during `--roof-steps` EAGER steps of the same workload right after the timed region (a captured
+    graph has no per-launch call sites to put the event pairs at).
+  * `cpu_baseline`: the CPU oracle (oracle/weclip_oracle.py, a port of the reference's CPU path) on a bounded sample.
+  * extra legs at N=1 (`--no-extras` skips them): `seg_trans_branch` (the iter > 15000 affinity branch),
+    `exact_precision` (fp16 hi+lo operands, fp32 PAR), `with_comer` (BASELINE configs[2] as written: + ViT-CoMer
+    inserts; parity unpinned, no reference code), `encoder_only_b32` (BASELINE configs[1]).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 
 def parse():
@@ -37,17 +43,40 @@ def parse():
     ap.add_argument("--classes-per-image", type=int, default=2)
     ap.add_argument("--precision", default=None, choices=[None, "fast", "exact"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the seg-trans / exact / CoMer / encoder-only legs")
+    ap.add_argument("--no-graph", action="store_true", help="time eager steps (every launch through Python)")
     ap.add_argument("--comer", action="store_true",
-                    help="enable the ViT-CoMer inserts (no reference code exists for them; off = the reference model)")
+                    help="main leg with the ViT-CoMer inserts (no reference code exists for them; off = the reference model)")
+    ap.add_argument("--seg-trans", action="store_true", help="main leg in the seg-trans affinity branch (iter > 15000)")
     ap.add_argument("--timer-stride", type=int, default=7,
                     help="HIP-event pair around 1 of every n instrumented kernel launches (0: none, roofline = null)")
+    ap.add_argument("--roof-steps", type=int, default=8, help="eager instrumented steps for the roofline leg")
     ap.add_argument("--cpu-images", type=int, default=2, help="images in the bounded CPU-oracle sample")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) BEFORE this process
+    makes any GPU call, wait for them, pass rank 0's JSON line through.  Never re-execs a GPU-initialised process."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
 
 
 def cpu_baseline(args):
     """Oracle (port of the reference CPU path) on `cpu_images` images of the same workload:
     forward + losses + backward of the trainable heads."""
+    import torch
     from oracle import synth
     from oracle import weclip_oracle as O
     n = args.cpu_images
@@ -68,48 +97,34 @@ def cpu_baseline(args):
                       f"(encoder, GradCAM, affinity, PAR) + losses + head backward, {dt:.1f} s"}
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-    import __graft_entry__
-    if rank == 0:
-        __graft_entry__.build()
-    if world > 1:
-        dist.barrier()
-    from weclip_vit_comer_amd import config, ops, synth
+def make_model(dev, comer=False, seg_trans=False):
+    import torch
+    from weclip_vit_comer_amd import synth
     from weclip_vit_comer_amd.WeCLIP_model.model_attn_aff_voc import WeCLIP
-    from weclip_vit_comer_amd.train_step import TrainStep
-    if args.precision:
-        config.precision = args.precision
-
-    dev = torch.device("cuda", local)
     sd = synth.make_clip_state_dict(seed=0, with_text=False)
     bg, fg = synth.make_text_features(20, 25, 512)
     fuse, dec = synth.make_head_state_dicts()
+    torch.manual_seed(0)
     model = WeCLIP(num_classes=21, clip_model=sd, embedding_dim=256, in_channels=[768] * 4,
-                   dataset_root_path=None, device=dev, text_features=(bg.to(dev), fg.to(dev)), comer=args.comer)
+                   dataset_root_path=None, device=dev, text_features=(bg.to(dev), fg.to(dev)), comer=comer)
     model.decoder_fts_fuse.load_state_dict(fuse)
     model.decoder.load_state_dict(dec)
     model.train()
-    step = TrainStep(model)
-    B, S, K = args.batch, args.size, args.classes_per_image
-    img = synth.make_images(B, S, S, seed=100 + rank).to(dev)
-    labels = synth.make_label_lists(B, K, seed=7 + rank)
+    if seg_trans:
+        model.iter_num = 20000
+    return model
 
-    for _ in range(args.warmup):
-        step(img, labels=labels)
+
+def timed_steps(step, loader, n, world, dev):
+    """EXACTLY n steps between barrier + synchronize on both sides; returns (seconds [max over ranks], host seconds)."""
+    import torch
+    import torch.distributed as dist
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    ops.KernelTimer.enable(args.timer_stride)       # HIP-event pair around every launch of the dominant kernels (csrc/core.hip)
-    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(n):
+        img, labels = loader.next()
         step(img, labels=labels)
     t_enq = time.perf_counter() - t0          # host time to enqueue the steps (the GPU may still be running)
     torch.cuda.synchronize()
@@ -120,24 +135,69 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
+    return dt, t_enq
 
+
+def run_leg(args, dev, rank, world, *, comer=False, seg_trans=False, steps=None, warmup=None, graph=True):
+    """Build a model + TrainStep, warm up, time `steps` steps.  -> (dict, step, loader)"""
+    from weclip_vit_comer_amd.data import SyntheticVOCLoader
+    from weclip_vit_comer_amd.train_step import TrainStep
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    model = make_model(dev, comer=comer, seg_trans=seg_trans)
+    use_graph = graph and not comer          # the CoMer inserts run stock torch modules (cuDNN-style lazy workspaces): eager
+    step = TrainStep(model, graph=use_graph)
+    loader = SyntheticVOCLoader(args.batch, args.size, args.classes_per_image, rank=rank, world=world, device=dev)
+    for _ in range(2 if use_graph else 0):   # set-up of the graph mode: one eager step, then the capturing step
+        img, labels = loader.next()
+        step(img, labels=labels)
+    for _ in range(warmup):
+        img, labels = loader.next()
+        step(img, labels=labels)
+    dt, t_enq = timed_steps(step, loader, steps, world, dev)
+    res = {"value": round(world * args.batch * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3),
+           "host_enqueue_ms_per_step": round(t_enq / steps * 1e3, 3), "steps": steps,
+           "launch_mode": "hipGraph replay" if use_graph else "eager"}
+    return res, step, loader
+
+
+def roofline_leg(args, step, loader, dev):
+    """Eager instrumented steps of the same TrainStep: HIP-event pairs at the C library's launch sites."""
+    import torch
+    from weclip_vit_comer_amd import ops
+    B, S, K = args.batch, args.size, args.classes_per_image
+    step.graph = False
+    for _ in range(2):
+        img, labels = loader.next()
+        step(img, labels=labels)
+    torch.cuda.synchronize()
+    ops.KernelTimer.enable(args.timer_stride)
+    n = args.roof_steps
+    t0 = time.perf_counter()
+    for _ in range(n):
+        img, labels = loader.next()
+        step(img, labels=labels)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
     summ = ops.KernelTimer.summary()
     ops.KernelTimer.enable(0)
     stride = max(args.timer_stride, 1)
+
     # peaks from guides/MI355X_MICROARCH.md: dense fp16 MFMA 2.5 PFLOP/s, HBM3E 8 TB/s
+    HBM = ("par_", "matvec", "aff_", "tsym", "sinkhorn")
+
     def peak_of(name):
-        return ("hbm", 8000.0, "GB/s") if name.startswith("par_") else ("mfma", 2500.0, "TFLOP/s")
+        return ("hbm", 8000.0, "GB/s") if name.startswith(HBM) else ("mfma", 2500.0, "TFLOP/s")
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
-    # (tools/refresh_profiles.sh + tools/pmc_traffic.py -> profiles/r01_traffic.json; 2*FETCH_SIZE + WRITE_SIZE, KiB,
-    # per the MI355X guide); keyed by the same kernel names
-    traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath) and B == 16 and S == 512 and K == 2:
-        traffic = {k: round(v["hbm_bytes_per_launch"]) for k, v in json.load(open(tpath)).items()}
+    # (tools/refresh_profiles.sh + tools/pmc_traffic.py -> profiles/r02_traffic.json; 2*FETCH_SIZE + WRITE_SIZE, KiB,
+    # per the MI355X guide); keyed by the same kernel names.  null when no pass exists for this configuration.
+    traffic, tsrc = {}, None
+    for fn in ("r02_traffic.json", "r01_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", fn)
+        if os.path.exists(tpath) and B == 16 and S == 512 and K == 2:
+            traffic = {k: round(v["hbm_bytes_per_launch"]) for k, v in json.load(open(tpath)).items()}
+            tsrc = "profiles/" + fn + " (committed rocprofv3 --pmc passes of this command, not this run)"
+            break
     roofs = []
     for name, r in summ.items():
         bound, peak, unit = peak_of(name)
@@ -147,32 +207,130 @@ def main():
         ach = r["work"] / sec / (1e12 if bound == "mfma" else 1e9)
         roofs.append({"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                       "frac": round(ach / peak, 4), "traffic": traffic.get(name), "launches_timed": r["launches"],
-                      "sampling": f"1 of {stride} launches",
+                      "sampling": f"1 of {stride} launches, {n} eager steps",
                       "avg_launch_us": round(r["ms"] * 1e3 / max(r["launches"], 1), 2),
-                      "share_of_step": round(r["ms"] * stride * 1e-3 / dt, 4)})
-    roofs.sort(key=lambda x: -x["share_of_step"])
+                      "share_of_eager_step": round(r["ms"] * stride * 1e-3 / dt, 4)})
+    roofs.sort(key=lambda x: -x["share_of_eager_step"])
+    # the north-star group "ViT attention" = in-projection + QK^T/softmax/PV + head-mean maps + out-projection is
+    # reported by the library under its own tag when the launch sites carry it (csrc/core.hip wc_prof groups)
+    return roofs, {"eager_instrumented_ms_per_step": round(dt / n * 1e3, 3), "traffic_source": tsrc}
+
+
+def encoder_leg(args, dev):
+    """BASELINE configs[1]: frozen encoder forward (11 blocks + all head-mean maps), batch 32 at 512x512."""
+    import torch
+    from weclip_vit_comer_amd import synth
+    model = make_model(dev)
+    model.eval()
+    img = synth.make_images(32, args.size, args.size, seed=300).to(dev)
+    with torch.no_grad():
+        for _ in range(2):
+            model.encode(img, False)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            xs, maps, _, _ = model.encode(img, False)
+        g.replay()
+        torch.cuda.synchronize()
+        n = 10
+        t0 = time.perf_counter()
+        for _ in range(n):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    gf = 196.3e9 * (args.size / 512) ** 2      # SURVEY §8d: 196.3 GF per image at 512^2 (approximate away from it)
+    return {"value": round(32 * n / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / n * 1e3, 3),
+            "workload": f"ViT-B/16 encoder forward, batch 32 at {args.size}x{args.size}, maps of the last 8 of 12 layers",
+            "mfma_tflops": round(32 * n * gf / dt / 1e12, 1), "frac_of_2500": round(32 * n * gf / dt / 2.5e15, 4)}
+
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+        if dist.get_world_size() != world:
+            sys.exit("bench.py: RCCL reports a different world size than the launcher")
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+    from weclip_vit_comer_amd import config
+    if args.precision:
+        config.precision = args.precision
+
+    res, step, loader = run_leg(args, dev, rank, world, comer=args.comer, seg_trans=args.seg_trans, graph=not args.no_graph)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    B, S, K = args.batch, args.size, args.classes_per_image
+    roofs, roof_meta = ([], {})
+    if args.timer_stride > 0 and args.roof_steps > 0 and world == 1:
+        roofs, roof_meta = roofline_leg(args, step, loader, dev)
+    del step, loader
+    torch.cuda.empty_cache()
     out = {
         "metric": "images/sec (train fwd+bwd) ViT-B/16 512x512 VOC",
-        "value": round(world * B * args.steps / dt, 3),
+        "value": res["value"],
         "unit": "images/sec",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
+        "ms_per_step": res["ms_per_step"],
+        "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"],
+        "launch_mode": res["launch_mode"],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": ("f16 MFMA operands / f32 accumulate, f32 residual+softmax+LN, PAR f32 arithmetic on 16-bit fixed-point "
                   "affinities (precision=fast)") if config.precision == "fast" else
                  "f16 hi+lo MFMA operands / f32 accumulate, f32 residual+softmax+LN+PAR (precision=%s)" % config.precision,
-        "data": "synthetic",
-        "config": {"workload": f"WeCLIP VOC full train step, batch {B}/GPU at {S}x{S}, K={K} classes/image "
-                               f"(BASELINE configs[2]{'/[3] DP' if world > 1 else ''})" + (" + ViT-CoMer inserts" if args.comer else ""),
+        "data": "synthetic (per-rank seeded loader, a different batch every step)",
+        "config": {"workload": f"WeCLIP VOC full train step (the reference's model: frozen CLIP ViT-B/16 + adapters + decoder + "
+                               f"GradCAM/affinity/PAR pseudo-labels), batch {B}/GPU at {S}x{S}, K={K} classes/image "
+                               f"(BASELINE configs[2]{'/[3] DP' if world > 1 else ''}"
+                               + (" with" if args.comer else " without") + " the ViT-CoMer inserts, for which the reference has no code"
+                               + ("; seg-trans affinity branch" if args.seg_trans else "") + ")",
                    "global_batch": world * B, "parallelism": f"dp{world}"},
         "roofline": roofs[0] if roofs else None,
         "roofline_other": roofs[1:],
     }
+    out.update(roof_meta)
+    if world == 1 and not args.no_extras:
+        few = max(4, min(10, args.steps))
+        if not args.seg_trans:
+            r, _, _ = run_leg(args, dev, rank, world, seg_trans=True, steps=few, warmup=2)
+            out["seg_trans_branch"] = r
+            torch.cuda.empty_cache()
+        if config.precision == "fast":
+            config.precision = "exact"
+            try:
+                r, _, _ = run_leg(args, dev, rank, world, steps=few, warmup=2)
+                r["dtype"] = "f16 hi+lo MFMA operands / f32 accumulate, f32 PAR (precision=exact)"
+                out["exact_precision"] = r
+            finally:
+                config.precision = "fast"
+            torch.cuda.empty_cache()
+        if not args.comer:
+            r, _, _ = run_leg(args, dev, rank, world, comer=True, steps=few, warmup=2)
+            r["note"] = "BASELINE configs[2] as written (+ ViT-CoMer inserts); parity unpinned: the reference ships no CoMer code"
+            out["with_comer"] = r
+            torch.cuda.empty_cache()
+        out["encoder_only_b32"] = encoder_leg(args, dev)
+        torch.cuda.empty_cache()
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(out))

@@ -11,6 +11,10 @@ Outputs (committed, data only -- no reference source):
   tiny_voc_seg.npz same with the seg-trans branch (iter_num > 15000)
   vitb_224.npz     BASELINE config 0: ViT-B/16-sized synthetic weights, one 224x224 image,
                    encode + GradCAM(2 classes) + transition matrix + refinement
+  vitb_512.npz     the benchmark size: whole `WeCLIP.forward` (VOC model, ViT-B/16-sized synthetic
+  vitb_512_seg.npz weights) on image 3 of bench.py's B=16 512x512 batch, normal / seg-trans branch;
+                   every stage of the CAM chain recorded by wrapping (not editing) the reference's own
+                   functions: class probabilities, CAM maps, affinity, T rows, refined CAMs, PAR rows, labels
 Inputs are regenerated from oracle/synth.py seeds; each fixture stores a checksum of the
 weights and the image so a drifting RNG is detected instead of silently mis-compared.
 """
@@ -206,10 +210,101 @@ def make_vitb_224():
     print("vitb_224.npz written; probs[:3] =", probs[0, :3])
 
 
+BENCH_IMG = 3          # image of bench.py's batch (synth.make_images(16, 512, 512, seed=100)) the 512x512 fixture is made of
+
+
+def make_vitb_512(seg_trans):
+    """Whole reference `WeCLIP.forward` at the benchmark size on ONE image of the benchmark batch.  The
+    intermediate stages are recorded by wrapping the reference's own callables at generation time
+    (GradCAM.__call__, compute_trans_mat, perform_single_voc_cam, PAR.forward); nothing is edited."""
+    from PIL import Image
+    import clip.clip_tool as ref_ct
+    import WeCLIP_model.model_attn_aff_voc as ref_voc
+    from pytorch_grad_cam.base_cam import BaseCAM
+
+    H = W = 512
+    sd = synth.make_clip_state_dict(seed=0, with_text=True)
+    img = synth.make_images(16, H, W, seed=100)[BENCH_IMG:BENCH_IMG + 1].contiguous()
+    ids = synth.make_label_lists(16, 2, seed=7)[BENCH_IMG]
+    bg, fg = synth.make_text_features(20, 25, 512)
+    fuse_sd, dec_sd = synth.make_head_state_dicts()
+    rec = {"cam": [], "probs": [], "attn_last": [], "trans_in": [], "trans_out": [], "refined": [], "par_in": [], "par_out": []}
+
+    orig_call, orig_tm, orig_single = BaseCAM.__call__, ref_ct.compute_trans_mat, ref_voc.perform_single_voc_cam
+
+    def call(self, *a, **k):
+        out = orig_call(self, *a, **k)
+        rec["cam"].append(np.array(out[0][0])); rec["probs"].append(out[1].detach().numpy()[0].copy())
+        rec["attn_last"].append(out[2].detach().numpy()[0].copy())
+        return out
+
+    def tm(x):
+        out = orig_tm(x)
+        rec["trans_in"].append(x.detach().numpy().copy()); rec["trans_out"].append(out.detach().numpy().copy())
+        return out
+
+    def single(*a, **k):
+        out = orig_single(*a, **k)
+        rec["refined"].append(torch.stack([c.detach() for c in out[0]]).numpy())
+        return out
+
+    BaseCAM.__call__, ref_ct.compute_trans_mat, ref_voc.perform_single_voc_cam = call, tm, single
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            ck = os.path.join(tmp, "clip_vitb.pt")
+            torch.save(sd, ck)
+            os.makedirs(os.path.join(tmp, "SegmentationClassAug"))
+            png = np.zeros((H, W), np.uint8)
+            for j, c in enumerate(ids):
+                png[32 + 64 * j: 96 + 64 * j, 32:160] = c + 1
+            png[-3:, -3:] = 255
+            Image.fromarray(png).save(os.path.join(tmp, "SegmentationClassAug", "im.png"))
+            model = ref_voc.WeCLIP(num_classes=21, clip_model=ck, embedding_dim=256, in_channels=[768] * 4,
+                                   dataset_root_path=tmp, device="cpu")
+            model.bg_text_features, model.fg_text_features = bg, fg
+            model.decoder_fts_fuse.load_state_dict(fuse_sd)
+            model.decoder.load_state_dict(dec_sd)
+            model.eval()
+            model.par.register_forward_hook(lambda m, i, o: (rec["par_in"].append(i[1].detach().numpy().copy()),
+                                                             rec["par_out"].append(o.detach().numpy().copy())) and None)
+            if seg_trans:
+                model.iter_num = 20000
+            with torch.no_grad():
+                fts, attns = model.encoder.encode_image(img, H, W, require_all_fts=True)
+            seg, cam_labels, ap = model(img, ["im"])
+    finally:
+        BaseCAM.__call__, ref_ct.compute_trans_mat, ref_voc.perform_single_voc_cam = orig_call, orig_tm, orig_single
+    T = rec["trans_out"][0]
+    Wa = rec["trans_in"][0]
+    out = dict(weights_ck=checksum([sd[k] for k in sorted(sd) if k.startswith("visual")]), img_ck=checksum([img]),
+               img_index=np.int64(BENCH_IMG), ids=np.array(ids),
+               fts_last_rows=fts[-1][::64, 0].numpy().astype(np.float32),       # (17, 768): every 64th token of block 11
+               fts5_rows=fts[5][::128, 0].numpy().astype(np.float32),
+               attn10_rows=attns[10][0, ::128].numpy(), attn_last_rows=rec["attn_last"][0][::128],
+               probs=np.stack(rec["probs"]), cams=np.stack(rec["cam"]),
+               aff_rows=Wa[::64].astype(np.float32), aff_rowsum=Wa.sum(1).astype(np.float32),
+               trans_rows=T[::64].astype(np.float32), trans_diag=np.diagonal(T).astype(np.float32),
+               trans_rowsum=T.sum(1).astype(np.float32),
+               refined=rec["refined"][0].astype(np.float32),
+               par_in_rows=rec["par_in"][0][0][:, ::16].astype(np.float32),      # (3, 32, 512): every 16th pixel row
+               par_out_rows=rec["par_out"][0][0][:, ::16].astype(np.float32),
+               cam_labels=cam_labels[0].numpy().astype(np.uint8),
+               seg=seg[0].detach().numpy().astype(np.float32), attn_pred_rows=ap[0, ::64].detach().numpy().astype(np.float32))
+    fn = "vitb_512_seg.npz" if seg_trans else "vitb_512.npz"
+    np.savez_compressed(os.path.join(OUT, fn), **out)
+    print(fn, "written; probs:", out["probs"][:, :2], "labels:", np.unique(out["cam_labels"], return_counts=True))
+
+
 if __name__ == "__main__":
     refharness.install()
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "512":        # only the benchmark-size fixtures
+        make_vitb_512(False)
+        make_vitb_512(True)
+        sys.exit(0)
     make_tiny_func()
     make_tiny_whole(False)
     make_tiny_whole(True)
     make_vitb_224()
+    make_vitb_512(False)
+    make_vitb_512(True)

@@ -43,8 +43,9 @@ def test_tiny_gradcam_matches_reference(golden, precision):
             ec = np.abs(cam - g["cams"][n]).max()
             ea = np.abs(attn - g["attn_last"][n]).max() / g["attn_last"][n].max()
             print(f"[{precision}] tiny pair {n}: probs rel {ep:.2e}  cam abs {ec:.2e}  attn rel {ea:.2e}")
-            assert ep < 5e-3 and ea < 5e-3
-            assert ec < 3e-2
+            # north-star bound on the CAM logits (class probabilities): 1e-3 relative; measured 5.9e-4 fast / 4.3e-4 exact
+            assert ep < 1e-3 and ea < 2e-3          # attention rows measured 7.4e-4 / 4.5e-4
+            assert ec < 8e-3                        # CAM map on [0,1]: measured 1.7e-3 / 2.9e-3
     finally:
         config.precision = "fast"
 
@@ -62,7 +63,8 @@ def test_vitb_224_gradcam_matches_reference(golden, precision):
             ep = (np.abs(probs - g["probs"][0]) / g["probs"][0]).max()
             ec = np.abs(cam - g["cams"][j]).max()
             print(f"[{precision}] vitb224 class {j}: CAM-logit rel err {ep:.2e}  CAM map abs err {ec:.2e}")
-            assert ep < 1e-2 and ec < 5e-2
+            # north-star bound: CAM logits within 1e-3 relative (measured 5.2e-4 fast / 1.9e-4 exact); map 1.3e-3 / 9.7e-4
+            assert ep < 1e-3 and ec < 4e-3
     finally:
         config.precision = "fast"
 
@@ -86,4 +88,4 @@ def test_gradcam_cls_remainder_path_matches_oracle():
         ec = np.abs(cam - rcam).max()
         ea = np.abs(attn - rpm.numpy()[0]).max() / rpm.numpy().max()
         print(f"L=133 class {j}: probs rel {ep:.2e}  cam abs {ec:.2e}  attn rel {ea:.2e}")
-        assert ep < 5e-3 and ea < 5e-3 and ec < 3e-2
+        assert ep < 1e-3 and ea < 2e-3 and ec < 1e-2

@@ -41,8 +41,9 @@ def test_whole_forward_backward_matches_reference(golden, seg_trans, head):
     e_ap = np.abs(ap.detach().cpu().numpy() - g["attn_pred"]).max()
     mism = (labels.cpu().numpy() != g["cam_labels"]).mean()
     print(f"[{head} seg_trans={seg_trans}] seg rel {e_seg:.2e}  attn_pred abs {e_ap:.2e}  label mismatch {mism:.3%}")
-    assert e_seg < 5e-3 and e_ap < 5e-3
-    assert mism < 0.02, "pseudo-label map differs from the reference on more than 2% of the pixels"
+    # measured (hip head): seg 1.0e-3, attn_pred 2.6e-4, labels 0.008 % / 0.041 %; torch head: 7.2e-4, 7.3e-4, 0.008 % / 0.38 %
+    assert e_seg < 3e-3 and e_ap < 2.5e-3
+    assert mism < (1.5e-3 if head == "hip" else 1e-2), "pseudo-label map differs from the reference"
     # losses + backward on the reference's own labels (isolates the trainable path)
     ref_labels = torch.from_numpy(g["cam_labels"].astype(np.int64)).cuda()
     segs = torch.nn.functional.interpolate(seg, size=(H, W), mode="bilinear", align_corners=False)
@@ -55,14 +56,17 @@ def test_whole_forward_backward_matches_reference(golden, seg_trans, head):
     (seg_loss + 0.1 * attn_loss).backward()
     grads = dict(m.decoder.named_parameters())
     grads.update(dict(m.decoder_fts_fuse.named_parameters()))
+    worst_entry = 0.0
     for k in g.files:
         if k.startswith("grad:"):
             ref = g[k]
             got = grads[k[5:]].grad.cpu().numpy()
+            worst_entry = max(worst_entry, float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12)))
             # gradients pass twice through fp16 tensors (forced-fp16 out-projection of the decoder,
             # myAtt.py:321): values ~1e-5 are fp16-subnormal there, so CPU-vs-GPU half GEMMs differ
             # by a few % of the largest entry on the 48-token tiny case.
             assert np.abs(got - ref).max() <= 5e-2 * np.abs(ref).max() + 1e-7, k
+    print(f"[{head} seg_trans={seg_trans}] worst gradient entry error {worst_entry:.2e} of the tensor's largest entry")
     names = [str(n) for n in g["grad_names"]]
     norms = np.array([float(grads[n].grad.norm()) for n in names])
     worst = np.abs(norms - g["grad_norms"]).max() / g["grad_norms"].max()

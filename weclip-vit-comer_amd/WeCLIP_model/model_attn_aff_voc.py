@@ -104,9 +104,10 @@ class WeCLIP(nn.Module):
             maps.append(m)
         return xs, maps, B, Lq
 
-    def forward(self, img, img_names="2007_000032", mode="train", labels=None):
+    def forward(self, img, img_names="2007_000032", mode="train", labels=None, plan=None):
         """-> (seg (B,nc,h,w), cam_labels (B,H,W) int64 [list of per-image maps in 'val' when the
-        original sizes differ], attn_pred (B,hw,hw))."""
+        original sizes differ], attn_pred (B,hw,hw)).  `plan`: a ready clip_tool.PairPlan for `labels`
+        (TrainStep's graph mode keeps one per batch signature and refills it in place)."""
         B, _, H, W = img.shape
         h, w = H // 16, W // 16
         self.encoder.eval()
@@ -143,18 +144,21 @@ class WeCLIP(nn.Module):
             return seg, None, attn_pred
         with torch.no_grad():
             cam_labels = self.cam_labels(img, xs[-1], maps, attn_pred.detach(), img_names, labels, mode,
-                                         seg_trans, h, w)
+                                         seg_trans, h, w, plan=plan)
         return seg, cam_labels, attn_pred
 
-    def cam_labels(self, img, last_rows, maps, attn_pred, img_names, labels, mode, seg_trans, h, w):
+    def cam_labels(self, img, last_rows, maps, attn_pred, img_names, labels, mode, seg_trans, h, w, plan=None):
         if self.bg_text_features is None or self.fg_text_features is None:
             raise RuntimeError("WeCLIP needs text_features=(bg, fg) (see __init__)")
         B, _, H, W = img.shape
         if isinstance(img_names, str):
             img_names = [img_names]
-        label_lists, sizes = self._labels_for(img_names, labels, (H, W))
         dev = img.device
-        plan = CT.PairPlan(label_lists, self.fg_text_features.shape[0], self.bg_text_features.shape[0], dev)
+        if plan is None:
+            label_lists, sizes = self._labels_for(img_names, labels, (H, W))
+            plan = CT.PairPlan(label_lists, self.fg_text_features.shape[0], self.bg_text_features.shape[0], dev)
+        else:
+            sizes = [(H, W)] * plan.B
         text_hat = CT.normalised_text(self.fg_text_features, self.bg_text_features, dev)
         R, _, _, _ = CT.batch_refined_cams(self.encoder, last_rows, maps, attn_pred if seg_trans else None,
                                            plan, text_hat, h, w, self.cam_threshold, seg_trans,

@@ -43,44 +43,86 @@ def read_image_labels(img_path):
 
 
 class PairPlan:
-    """Flattened (image, class) pairs of a batch and the index tensors the kernels consume."""
+    """Flattened (image, class) pairs of a batch and the index tensors the kernels consume.
+
+    The device tensors are allocated once; `update(label_lists)` refills them in place for another batch with the
+    same signature (B, P, K) -- what a captured HIP graph of the step needs (train_step.TrainStep(graph=True)):
+    the graph's kernels keep reading the same addresses, only their contents change."""
 
     def __init__(self, label_lists, n_fg, n_bg, device):
+        self.n_fg, self.n_bg, self.device = n_fg, n_bg, torch.device(device)
+        host, vk = self._host_arrays(label_lists)
+        cuda = self.device.type == "cuda"
+        # ONE pinned, asynchronous host->device copy for all the int32 index arrays (a pageable
+        # torch.tensor(..., device=cuda) per array is a synchronising copy: it stalls the launch queue)
+        self._host = host.pin_memory() if cuda else host
+        self._host_vk = vk.pin_memory() if cuda else vk
+        self._dev_all = self._host.to(self.device, non_blocking=True)
+        self.valid_key = self._host_vk.to(self.device, non_blocking=True)
+        views, off = [], 0
+        for n in self._part_len:
+            views.append(self._dev_all[off:off + n])
+            off += n
+        self.pair_img, self.pair_cls, self.pair_slot, text_idx, self.n_text, self.nk, self.nch = views
+        self.text_idx = text_idx.view(self.P, self.Tmax)
+
+    @staticmethod
+    def signature(label_lists):
+        """(B, P, K): batches with equal signatures can share one set of device index tensors."""
+        return len(label_lists), sum(len(l) for l in label_lists), max(len(l) for l in label_lists)
+
+    def _host_arrays(self, label_lists):
         self.label_lists = [list(map(int, l)) for l in label_lists]
         if any(len(l) == 0 for l in self.label_lists):
             raise RuntimeError("every image needs at least one foreground class id")
         self.B = len(self.label_lists)
         self.K = max(len(l) for l in self.label_lists)
-        self.Tmax = self.K + n_bg
+        self.Tmax = self.K + self.n_bg
         pi, pc, ps, ti, nt = [], [], [], [], []
         for i, ids in enumerate(self.label_lists):
-            rows = ids + [n_fg + r for r in range(n_bg)]
+            rows = ids + [self.n_fg + r for r in range(self.n_bg)]
             for j in range(len(ids)):
                 pi.append(i); pc.append(j); ps.append(j)
                 ti.append(rows + [0] * (self.Tmax - len(rows)))
                 nt.append(len(rows))
-        # ONE pinned, asynchronous host->device copy for all the int32 index arrays (a pageable
-        # torch.tensor(..., device=cuda) per array is a synchronising copy: it stalls the launch queue)
         nk = [len(l) for l in self.label_lists]
         flat_ti = [v for row in ti for v in row]
         parts = [pi, pc, ps, flat_ti, nt, nk, [k + 1 for k in nk]]
+        self._part_len = [len(p) for p in parts]
+        self.P = len(pi)
         host = torch.tensor([v for part in parts for v in part], dtype=I32)
         vk = torch.zeros(self.B, self.K + 1, dtype=torch.int64)
         for i, ids in enumerate(self.label_lists):
             vk[i, 1:1 + len(ids)] = torch.tensor(ids) + 1
-        if torch.device(device).type == "cuda":
-            dev_all = host.pin_memory().to(device, non_blocking=True)
-            self.valid_key = vk.pin_memory().to(device, non_blocking=True)
-        else:
-            dev_all = host.to(device)
-            self.valid_key = vk.to(device)
-        self.P = len(pi)
-        views, off = [], 0
-        for part in parts:
-            views.append(dev_all[off:off + len(part)])
-            off += len(part)
-        self.pair_img, self.pair_cls, self.pair_slot, text_idx, self.n_text, self.nk, self.nch = views
-        self.text_idx = text_idx.view(self.P, self.Tmax)
+        return host, vk
+
+    def update(self, label_lists):
+        """Refill the device index tensors for another batch of the same signature (asynchronous copies from the
+        pinned staging buffers, ordered on the current stream)."""
+        if self.signature(label_lists) != (self.B, self.P, self.K):
+            raise RuntimeError(f"PairPlan.update: signature {self.signature(label_lists)} != {(self.B, self.P, self.K)}")
+        host, vk = self._host_arrays(label_lists)
+        if self.device.type != "cuda":
+            self._dev_all.copy_(host)
+            self.valid_key.copy_(vk)
+            return self
+        # two pinned staging sets used alternately, each guarded by the event recorded after its last copy: the host
+        # only waits if it is two updates ahead of the device (never a full-stream synchronisation per step)
+        if not hasattr(self, "_ring"):
+            self._ring = [(self._host, self._host_vk, None), (self._host.clone().pin_memory(), self._host_vk.clone().pin_memory(), None)]
+            self._slot = 0
+        self._slot ^= 1
+        h, v, ev = self._ring[self._slot]
+        if ev is not None:
+            ev.synchronize()
+        h.copy_(host)
+        v.copy_(vk)
+        self._dev_all.copy_(h, non_blocking=True)
+        self.valid_key.copy_(v, non_blocking=True)
+        ev = ev or torch.cuda.Event()
+        ev.record()
+        self._ring[self._slot] = (h, v, ev)
+        return self
 
 
 def normalised_text(fg_text, bg_text, device):
