@@ -98,7 +98,8 @@ def test_par_fixed_point_affinities_agree_with_fp32_at_512(monkeypatch):
     assert err < 5e-4 and mism < 1e-4          # measured: 1.6e-4, 0.0012 % of the pixels
 
 
-def test_training_step_is_deterministic_and_finite_at_512():
+@pytest.mark.parametrize("seg_trans", [False, True])
+def test_training_step_is_deterministic_and_finite_at_512(seg_trans):
     from weclip_vit_comer_amd.WeCLIP_model.model_attn_aff_voc import WeCLIP
     from weclip_vit_comer_amd.train_step import TrainStep
     img = synth.make_images(2, 512, 512, seed=14).cuda()
@@ -114,6 +115,8 @@ def test_training_step_is_deterministic_and_finite_at_512():
         m.decoder_fts_fuse.load_state_dict(fuse)
         m.decoder.load_state_dict(dec)
         m.train()
+        if seg_trans:                      # the iter > 15000 affinity branch: layer selection by a fixed-order reduction
+            m.iter_num = 20000
         step = TrainStep(m)
         torch.manual_seed(1)
         out = [step(img, labels=labels)[0].item() for _ in range(2)]

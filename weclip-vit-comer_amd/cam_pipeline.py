@@ -35,8 +35,8 @@ def affinity_weight(maps, seg=None, seg_trans=False, n_last=6):
     seg = seg.detach().float().contiguous()
     diff = torch.empty(B, len(sel), device=dev, dtype=F32)
     wgt = torch.empty(B, len(sel), device=dev, dtype=F32)
-    lib.wc_aff_seg_weights(_map_array(sel), len(sel), L.ptr(seg, F32, "seg"), L.ptr(diff), L.ptr(wgt), B, Lq,
-                           L.stream())
+    rowsum = torch.empty(B, len(sel), hw, device=dev, dtype=F32)
+    lib.wc_aff_seg_weights(_map_array(sel), len(sel), L.ptr(rowsum), L.ptr(diff), L.ptr(wgt), B, Lq, L.stream())
     lib.wc_aff_weight(_map_array(sel), len(sel), L.ptr(wgt), L.ptr(seg), L.ptr(W), B, Lq, L.stream())
     return W
 

@@ -44,27 +44,46 @@ __global__ __launch_bounds__(256) void aff_weight_kernel(MapPtrs maps, int nmaps
     W[dst] = s;
 }
 
-// diff[b,l] = sum_ij (seg[b,i,j] - maps[l][b,i+1,j+1])   (clip_tool.py:158-159)
-__global__ __launch_bounds__(256) void aff_diff_kernel(MapPtrs maps, int nmaps, const float* __restrict__ seg,
-                                                        float* __restrict__ diff, int L) {
+// Layer selection of the seg-trans branch (clip_tool.py:158-167): keep layer l iff
+//   diff_l <= mean_l diff,   diff_l = sum_ij (seg[b,i,j] - maps[l][b,i+1,j+1]) = S - A_l.
+// The seg term S is the same for every layer and cancels: diff_l <= mean(diff)  <=>  A_l >= mean(A) with
+// A_l = sum_ij maps[l][b,i+1,j+1].  Only A_l is reduced (~1e3, where fp32 spacing is 1e-4, instead of S - A_l ~5e5
+// with spacing 0.03-0.06), in a FIXED order: one partial per (image, layer, row), then a serial sum over the rows --
+// no atomics, so the decision (and with it the pseudo labels) is reproducible run to run.
+// rowsum[(b*nmaps + l)*hw + i] = sum_j maps[l][b,i+1,j+1]
+__global__ __launch_bounds__(256) void aff_rowsum_kernel(MapPtrs maps, int nmaps, float* __restrict__ rowsum, int L) {
     __shared__ float red[16];
     const int hw = L - 1, i = blockIdx.x, l = blockIdx.y, b = blockIdx.z;
+    const float* row = maps.p[l] + (long)b * L * L + (long)(i + 1) * L + 1;
     float s = 0.f;
-    for (int j = threadIdx.x; j < hw; j += 256)
-        s += seg[((long)b * hw + i) * hw + j] - maps.p[l][(long)b * L * L + (long)(i + 1) * L + (j + 1)];
+    for (int j = threadIdx.x; j < hw; j += 256) s += row[j];
     s = block_sum(s, red);
-    if (threadIdx.x == 0) atomicAdd(&diff[b * nmaps + l], s);
+    if (threadIdx.x == 0) rowsum[((long)b * nmaps + l) * hw + i] = s;
 }
 
-// wgt[b,l] = keep / (nkeep + 1e-5), keep = diff[b,l] <= mean_l diff[b,:]   (clip_tool.py:160-167)
-__global__ void aff_keep_kernel(const float* __restrict__ diff, float* __restrict__ wgt, int nmaps) {
-    const int b = blockIdx.x;
+// diff[b,l] = -A_l (same ordering as the reference's S - A_l);  wgt[b,l] = keep / (nkeep + 1e-5)
+__global__ __launch_bounds__(64) void aff_keep_kernel(const float* __restrict__ rowsum, float* __restrict__ diff,
+                                                       float* __restrict__ wgt, int nmaps, int hw) {
+    __shared__ float A[12];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    for (int l = 0; l < nmaps; ++l) {
+        const float* rs = rowsum + ((long)b * nmaps + l) * hw;
+        float s = 0.f;
+        for (int i = lane; i < hw; i += 64) s += rs[i];      // fixed lane-strided order, then a fixed butterfly
+        s = wave_sum(s);
+        if (lane == 0) A[l] = s;
+    }
+    __syncthreads();
+    if (lane != 0) return;
     float m = 0.f;
-    for (int l = 0; l < nmaps; ++l) m += diff[b * nmaps + l];
+    for (int l = 0; l < nmaps; ++l) m += A[l];
     m /= nmaps;
     float n = 0.f;
-    for (int l = 0; l < nmaps; ++l) n += (diff[b * nmaps + l] <= m) ? 1.f : 0.f;
-    for (int l = 0; l < nmaps; ++l) wgt[b * nmaps + l] = ((diff[b * nmaps + l] <= m) ? 1.f : 0.f) / (n + 1e-5f);
+    for (int l = 0; l < nmaps; ++l) n += (A[l] >= m) ? 1.f : 0.f;
+    for (int l = 0; l < nmaps; ++l) {
+        diff[b * nmaps + l] = -A[l];
+        wgt[b * nmaps + l] = ((A[l] >= m) ? 1.f : 0.f) / (n + 1e-5f);
+    }
 }
 
 // out[b,j,k] = f( sum_i W[b,i,j] * X[b,i,k] * (sin ? sin[b,i] : 1) )      (W^T x)
@@ -340,17 +359,16 @@ extern "C" int wc_aff_weight(const float* const* h_maps, int nmaps, const float*
     return WC_OK;
 }
 
-extern "C" int wc_aff_seg_weights(const float* const* h_maps, int nmaps, const float* seg, float* diff, float* wgt,
+extern "C" int wc_aff_seg_weights(const float* const* h_maps, int nmaps, float* rowsum, float* diff, float* wgt,
                                   int B, int L, void* stream) {
-    WC_CHECK_ARG(h_maps && nmaps >= 1 && nmaps <= 12 && seg && diff && wgt && B > 0 && L > 1,
+    WC_CHECK_ARG(h_maps && nmaps >= 1 && nmaps <= 12 && rowsum && diff && wgt && B > 0 && L > 1,
                  "wc_aff_seg_weights: bad argument");
     MapPtrs mp;
     for (int i = 0; i < 12; ++i) mp.p[i] = i < nmaps ? h_maps[i] : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(diff, 0, sizeof(float) * B * nmaps, st);
-    hipLaunchKernelGGL(aff_diff_kernel, dim3(L - 1, nmaps, B), dim3(256), 0, st, mp, nmaps, seg, diff, L);
-    WC_LAUNCH_CHECK("aff_diff_kernel");
-    hipLaunchKernelGGL(aff_keep_kernel, dim3(B), dim3(1), 0, st, diff, wgt, nmaps);
+    hipLaunchKernelGGL(aff_rowsum_kernel, dim3(L - 1, nmaps, B), dim3(256), 0, st, mp, nmaps, rowsum, L);
+    WC_LAUNCH_CHECK("aff_rowsum_kernel");
+    hipLaunchKernelGGL(aff_keep_kernel, dim3(B), dim3(64), 0, st, rowsum, diff, wgt, nmaps, L - 1);
     WC_LAUNCH_CHECK("aff_keep_kernel");
     return WC_OK;
 }
