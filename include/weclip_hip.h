@@ -330,6 +330,25 @@ int wc_dwconv_fwd(const float* x, const float* w, const float* bias, float* y, i
 int wc_dwconv_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, float* part,
                   int N, int C, int H, int W, int k, void* stream);
 
+/* ---- multi-scale + flip inference and the confusion histogram ----------------------------- */
+/* test_msc_flip_coco.py:61-96 (`validate`: [img, flip] at every scale, flip-average, mean over scales, bilinear to
+ * the label size, argmax) and utils/evaluate.py:10-16 (_fast_hist), per image, on the device.
+ * wc_scale_flip_pair: dst (2,C,Hd,Wd) = [bilinear(src (C,Hs,Ws)), its horizontal flip]; scale_y/x = the source step
+ *                     per destination pixel (in/out for F.interpolate(size=), 1/s for F.interpolate(scale_factor=s));
+ *                     plain copy + flip when nothing is resized.
+ * wc_flip_avg:        out (C,Hd,Wd) = (accumulate ? out : 0) + weight * (R(segs[0]) + flip(R(segs[1]))) / 2 with
+ *                     segs (2,C,Hs,Ws) and R = F.interpolate(size=(Hd,Wd), bilinear, align_corners=False).
+ * wc_resize_argmax:   pred (Hd,Wd) int64 = argmax_c R(seg (C,Hs,Ws)); the (C,Hd,Wd) logits are never materialised.
+ * wc_confusion_hist:  hist (nc,nc) int64 += counts of (true, pred) pairs over n pixels whose true label is in
+ *                     [0,nc); *flag is set to 1 if a prediction is outside [0,nc) (int32, caller-zeroed). */
+int wc_scale_flip_pair(const float* src, float* dst, int C, int Hs, int Ws, int Hd, int Wd, float scale_y,
+                       float scale_x, void* stream);
+int wc_flip_avg(const float* segs, float* out, int C, int Hs, int Ws, int Hd, int Wd, float weight, int accumulate,
+                void* stream);
+int wc_resize_argmax(const float* seg, long* pred, int C, int Hs, int Ws, int Hd, int Wd, void* stream);
+int wc_confusion_hist(const long* label_true, const long* label_pred, long* hist, int* flag, long n, int nc,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

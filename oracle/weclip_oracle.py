@@ -399,6 +399,51 @@ def weclip_forward(img, label_lists, clip_sd, fuse_sd, dec_sd, bg_text, fg_text,
     return out + (aux,) if return_aux else out
 
 
+def seg_logits(img, clip_sd, fuse_sd, dec_sd, heads=12, dec_heads=8, mm=None):
+    """`WeCLIP.forward(mode='val')` of the COCO model (model_attn_aff_coco.py:100-132): encoder -> adapters ->
+    decoder, returned right after the decoder (no CAM stage).  -> seg (B, nc, h, w)."""
+    B, _, H, W = img.shape
+    h, w = H // 16, W // 16
+    xs, _ = encode_image(img, clip_sd, heads, mm)
+    stack = torch.stack(xs, 0)
+    toks = stack[:, 1:].permute(0, 2, 3, 1).reshape(len(xs), B, -1, h, w)
+    seg, _ = decoder(segformer_head(toks, fuse_sd, mm), dec_sd, dec_heads, mm)
+    return seg
+
+
+def msc_flip_predict(model_fn, inputs, label_hw, scales=(1.0, 0.75), resize_long=512):
+    """One image of `validate`, test_msc_flip_coco.py:52-94: long side -> resize_long (:52-57); [img, flip] at
+    scale 1 (:60-68); every other scale through F.interpolate(scale_factor=s), its logits resized to the scale-1
+    logit grid, un-flipped and pair-averaged (:72-86); mean over scales (:88); bilinear to the label size + arg-max
+    for the plain scale-1 logits and for the multi-scale average (:90-94).
+    model_fn(x (2,3,H,W)) -> seg (2,nc,h,w).  Returns (seg_pred, msc_pred) int64 (Hl, Wl)."""
+    _, _, h, w = inputs.shape
+    if resize_long:
+        ratio = resize_long / max(h, w)
+        inputs = F.interpolate(inputs, size=(int(h * ratio), int(w * ratio)), mode="bilinear", align_corners=False)
+    segs_cat = model_fn(torch.cat([inputs, inputs.flip(-1)], 0))
+    segs = segs_cat[0].unsqueeze(0)
+    seg_list = [(segs_cat[0] + segs_cat[1].flip(-1)) / 2]
+    gh, gw = segs_cat.shape[2:]
+    for s in scales:
+        if s != 1.0:
+            x = F.interpolate(inputs, scale_factor=s, mode="bilinear", align_corners=False)
+            sc = model_fn(torch.cat([x, x.flip(-1)], 0))
+            sc = F.interpolate(sc, size=(gh, gw), mode="bilinear", align_corners=False)
+            seg_list.append((sc[0] + sc[1].flip(-1)) / 2)
+    msc = torch.mean(torch.stack(seg_list, 0), 0).unsqueeze(0)
+    up = lambda t: torch.argmax(F.interpolate(t, size=tuple(label_hw), mode="bilinear", align_corners=False), dim=1)[0]
+    return up(segs), up(msc)
+
+
+def fast_hist(label_true, label_pred, num_classes):
+    """utils/evaluate.py:10-16."""
+    lt = np.asarray(label_true).reshape(-1).astype(np.int64)
+    lp = np.asarray(label_pred).reshape(-1).astype(np.int64)
+    keep = (lt >= 0) & (lt < num_classes)
+    return np.bincount(num_classes * lt[keep] + lp[keep], minlength=num_classes ** 2).reshape(num_classes, num_classes)
+
+
 # ----------------------------------------------------------------------------- A.10
 
 def radius_mask(h, w, radius=8):

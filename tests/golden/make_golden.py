@@ -11,6 +11,9 @@ Outputs (committed, data only -- no reference source):
   tiny_voc_seg.npz same with the seg-trans branch (iter_num > 15000)
   vitb_224.npz     BASELINE config 0: ViT-B/16-sized synthetic weights, one 224x224 image,
                    encode + GradCAM(2 classes) + transition matrix + refinement
+  tiny_coco_msc.npz the reference's own `validate` (test_msc_flip_coco.py:33-121, executed from the script's source
+                   without importing the script) on a tiny 81-class COCO-headed model and three synthetic images of
+                   different sizes at scales (1, 0.75): per-image predictions, both confusion histograms, scores
   vitb_512.npz     the benchmark size: whole `WeCLIP.forward` (VOC model, ViT-B/16-sized synthetic
   vitb_512_seg.npz weights) on image 3 of bench.py's B=16 512x512 batch, normal / seg-trans branch;
                    every stage of the CAM chain recorded by wrapping (not editing) the reference's own
@@ -276,7 +279,14 @@ def make_vitb_512(seg_trans):
         BaseCAM.__call__, ref_ct.compute_trans_mat, ref_voc.perform_single_voc_cam = orig_call, orig_tm, orig_single
     T = rec["trans_out"][0]
     Wa = rec["trans_in"][0]
-    out = dict(weights_ck=checksum([sd[k] for k in sorted(sd) if k.startswith("visual")]), img_ck=checksum([img]),
+    # the seg-trans layer selection, recomputed with the reference's own expressions (clip_tool.py:152-162) from the
+    # tensors it was given, plus the same sums in fp64: at |diff| ~ 1e6 the fp32 sums are quantised to 1/8
+    aw = torch.cat([torch.stack(attns, 0)[:, 0], torch.from_numpy(rec["attn_last"][0])[None]], 0)[:, 1:, 1:][-6:]
+    seg_attn = ap.detach()[0:1]
+    attn_diff = torch.sum((seg_attn - aw).flatten(1), dim=1)
+    keep_ref = attn_diff <= torch.mean(attn_diff)
+    A64 = aw.double().flatten(1).sum(1)
+    out = dict(keep_ref=keep_ref.numpy(), diff_ref=attn_diff.numpy(), A64=A64.numpy(), weights_ck=checksum([sd[k] for k in sorted(sd) if k.startswith("visual")]), img_ck=checksum([img]),
                img_index=np.int64(BENCH_IMG), ids=np.array(ids),
                fts_last_rows=fts[-1][::64, 0].numpy().astype(np.float32),       # (17, 768): every 64th token of block 11
                fts5_rows=fts[5][::128, 0].numpy().astype(np.float32),
@@ -295,9 +305,89 @@ def make_vitb_512(seg_trans):
     print(fn, "written; probs:", out["probs"][:, :2], "labels:", np.unique(out["cam_labels"], return_counts=True))
 
 
+COCO_SIZES = [(80, 112), (96, 64), (71, 100)]      # synthetic "original" image sizes (the last one is odd on purpose)
+COCO_LONG = 96                                     # --resize_long
+
+
+def _msc_script_fn(name, ns):
+    """One function of test_msc_flip_coco.py, compiled from the script's source without importing the script
+    (it parses argv and imports omegaconf / joblib / imageio / pydensecrf at import time)."""
+    src = open(os.path.join(refharness.REF, "test_msc_flip_coco.py")).read()
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            exec(compile(ast.Module([node], []), "test_msc_flip_coco.py", "exec"), ns)
+            return ns[name]
+    raise KeyError(name)
+
+
+def coco_inputs():
+    """(name, image (3,H,W), label (H,W) uint8) triples shared by the generator and the tests."""
+    out = []
+    for i, (H, W) in enumerate(COCO_SIZES):
+        img = synth.make_images(1, H, W, seed=400 + i)[0]
+        g = torch.Generator().manual_seed(500 + i)
+        lab = torch.randint(0, 81, (max(H // 8, 1), max(W // 8, 1)), generator=g)
+        lab = lab.repeat_interleave(8, 0).repeat_interleave(8, 1)[:H, :W].contiguous()
+        lab[:3, :5] = 255
+        out.append((f"im{i}", img, lab.to(torch.uint8)))
+    return out
+
+
+def make_tiny_coco_msc():
+    import types
+    from WeCLIP_model.model_attn_aff_coco import WeCLIP
+    from utils import evaluate
+
+    sd = synth.make_clip_state_dict(**TINY)
+    fuse_sd, dec_sd = synth.make_head_state_dicts(width=TINY["width"], num_classes=81, seed=3)
+    data = coco_inputs()
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(data)
+
+        def __getitem__(self, i):
+            n, img, lab = data[i]
+            return n, img, lab.long(), torch.zeros(80)
+
+    with tempfile.TemporaryDirectory() as tmp:
+        ck = os.path.join(tmp, "clip_tiny.pt")
+        torch.save(sd, ck)
+        model = WeCLIP(num_classes=81, clip_model=ck, embedding_dim=256, in_channels=[TINY["width"]] * 4,
+                       dataset_root_path=tmp, device="cpu")
+        model.decoder_fts_fuse.load_state_dict(fuse_sd)
+        model.decoder.load_state_dict(dec_sd)
+        model.eval()
+        tu = types.SimpleNamespace(data=types.SimpleNamespace(
+            DataLoader=lambda ds, **kw: torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False, num_workers=0)))
+        tproxy = types.SimpleNamespace(**{k: getattr(torch, k) for k in ("cat", "mean", "stack", "argmax")}, utils=tu)
+        ns = {"np": np, "torch": tproxy, "F": torch.nn.functional, "tqdm": lambda it, **kw: it, "evaluate": evaluate,
+              "args": types.SimpleNamespace(resize_long=COCO_LONG)}
+        validate = _msc_script_fn("validate", ns)
+        with torch.no_grad():
+            gts, preds, msc_preds, cams, h1, h2, h3 = validate(model, DS(), test_scales=[1.0, 0.75])
+    assert len(preds) == len(data) and not h1.any()          # the script only folds the lists into its histograms every 2000 images
+    hist, score = evaluate.scores(gts, preds, np.zeros((81, 81)), 81)
+    msc_hist, msc_score = evaluate.scores(gts, msc_preds, np.zeros((81, 81)), 81)
+    out = dict(weights_ck=checksum(sd.values()), head_ck=checksum(list(fuse_sd.values()) + list(dec_sd.values())),
+               img_ck=checksum([d[1] for d in data]), sizes=np.array(COCO_SIZES), resize_long=np.int64(COCO_LONG),
+               hist=hist.astype(np.int64), msc_hist=msc_hist.astype(np.int64),
+               miou=np.float64(score["miou"]), msc_miou=np.float64(msc_score["miou"]),
+               pacc=np.float64(score["pAcc"]), msc_pacc=np.float64(msc_score["pAcc"]))
+    for i in range(len(data)):
+        out[f"pred{i}"] = np.asarray(preds[i]).astype(np.uint8)
+        out[f"msc_pred{i}"] = np.asarray(msc_preds[i]).astype(np.uint8)
+    np.savez_compressed(os.path.join(OUT, "tiny_coco_msc.npz"), **out)
+    print("tiny_coco_msc.npz written; mIoU", score["miou"], "msc mIoU", msc_score["miou"],
+          "classes predicted:", len(np.unique(np.concatenate([np.asarray(p).ravel() for p in msc_preds]))))
+
+
 if __name__ == "__main__":
     refharness.install()
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "coco":
+        make_tiny_coco_msc()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "512":        # only the benchmark-size fixtures
         make_vitb_512(False)
         make_vitb_512(True)
@@ -308,3 +398,4 @@ if __name__ == "__main__":
     make_vitb_224()
     make_vitb_512(False)
     make_vitb_512(True)
+    make_tiny_coco_msc()

@@ -31,8 +31,10 @@ def _rel(a, b):
     return np.abs(a - b).max() / np.abs(b).max()
 
 
-@pytest.mark.parametrize("seg_trans", [False, True])
-def test_cam_chain_at_512_matches_reference(golden, bench_model, seg_trans):
+@pytest.mark.parametrize("seg_trans,precision", [(False, "fast"), (True, "fast"), (True, "exact")])
+def test_cam_chain_at_512_matches_reference(golden, bench_model, seg_trans, precision, monkeypatch):
+    from weclip_vit_comer_amd import config
+    monkeypatch.setattr(config, "precision", precision)
     from weclip_vit_comer_amd import cam_pipeline as CP
     from weclip_vit_comer_amd.clip import clip_tool as CT
     g = golden("vitb_512_seg.npz" if seg_trans else "vitb_512.npz")
@@ -45,7 +47,34 @@ def test_cam_chain_at_512_matches_reference(golden, bench_model, seg_trans):
     img = img.cuda()
     h = w = S // 16
     m.iter_num = 20000 if seg_trans else 0
+    keep = None
     with torch.no_grad():
+        if seg_trans:
+            # The layer selection keep_l = [sum(seg - map_l) <= mean] is a DISCRETE decision.  With these synthetic
+            # weights every layer has A_l = sum(map_l[1:,1:]) = 1023.7 +- 0.04, while the reference forms the sums at
+            # magnitude 1e6, where fp32 is quantised to 1/8: its own decision is set by its summation's rounding, not by
+            # the data (make_golden.py stores its sums, its decision and the fp64 sums).  So: (1) the HIP selection must
+            # equal the exact (fp64) one wherever the margin exceeds the error of its fixed-order fp32 reduction of A_l;
+            # (2) every layer on which the reference differs from exact arithmetic must lie inside its own fp32
+            # quantisation; (3) the arithmetic downstream is compared with the reference's selection fed in.
+            xs0, maps0, _, _ = m.encode(img, True)
+            st0 = CT.last_layer_forward(m.encoder, xs0[-1], B, xs0[-1].shape[0] // B)
+            hip_keep = CP.seg_layer_keep(list(maps0) + [st0.mean], m.seg_trans_last)
+            A64 = g["A64"]
+            exact_keep = A64 >= A64.mean()
+            margin = np.abs(A64 - A64.mean())
+            mine = hip_keep[i].cpu().numpy() > 0
+            assert (mine == exact_keep)[margin > 2e-3].all(), (mine, exact_keep, margin)
+            ref_keep = g["keep_ref"]
+            quantum = float(np.spacing(np.float32(np.abs(g["diff_ref"]).max())))
+            assert (margin[ref_keep != exact_keep] < 2 * quantum).all(), (ref_keep, exact_keep, margin, quantum)
+            print(f"seg-trans selection: exact {exact_keep.astype(int)}, HIP {mine.astype(int)}, reference {ref_keep.astype(int)}; "
+                  f"margins {np.round(margin, 4)} vs the reference's fp32 quantum {quantum}")
+            keep = hip_keep.clone()
+            keep[i] = torch.from_numpy(ref_keep.astype(np.float32)).to(keep.device)
+            del xs0, maps0, st0
+            orig_aw = CP.affinity_weight
+            monkeypatch.setattr(CP, "affinity_weight", lambda *a, **k: orig_aw(*a, **{**k, "keep": keep}))
         seg, cam_labels, ap = m(img, [""] * B, labels=labels)
         # the same stages once more through the package's stage functions, to look at the intermediates
         xs, maps, _, Lq = m.encode(img, seg_trans)
@@ -75,9 +104,14 @@ def test_cam_chain_at_512_matches_reference(golden, bench_model, seg_trans):
     e["seg"] = _rel(seg[i].cpu().numpy(), g["seg"])
     e["attn_pred"] = np.abs(ap[i, ::64].cpu().numpy() - g["attn_pred_rows"]).max()
     e["labels"] = float((cam_labels[i].cpu().numpy() != g["cam_labels"]).mean())
-    print(f"512^2 image {i} of {B}, seg_trans={seg_trans}: " + "  ".join(f"{k} {v:.2e}" for k, v in e.items()))
+    print(f"512^2 image {i} of {B}, seg_trans={seg_trans} [{precision}]: " + "  ".join(f"{k} {v:.2e}" for k, v in e.items()))
     assert e["cam_logits"] < 1e-3, "north-star bound: CAM logits within 1e-3 relative of the reference CPU path"
-    lim = dict(tokens=2e-3, attn10=5e-3, attn_last=5e-3, cam_map=1e-2, affinity=5e-3, aff_rowsum=2e-3, trans_rows=1e-2,
-               trans_diag=1e-2, refined=1e-2, par_in=1e-2, par_out=1e-2, seg=3e-3, attn_pred=3e-3, labels=2e-3)
+    # ~3x the errors measured on the MI355X (fast precision, normal branch: tokens 3.0e-4, attn10 2.7e-4, attn_last 9.6e-5,
+    # cam_map 4.9e-4, affinity 1.8e-4, trans_rows 2.0e-4, refined 2.2e-4, par 3.4e-4, seg 8.4e-4, attn_pred 5.5e-3 abs
+    # (sigmoid of a 256-long Gram product of fp16-rounded adapter outputs), labels 0.012 % of the pixels)
+    lim = dict(tokens=1e-3, attn10=1e-3, attn_last=5e-4, cam_map=2e-3, affinity=6e-4, aff_rowsum=1e-5, trans_rows=6e-4,
+               trans_diag=5e-4, refined=7e-4, par_in=1e-3, par_out=1e-3, seg=3e-3, attn_pred=1.5e-2, labels=5e-4)
+    if seg_trans:       # W = (masked layer mean) * attn_pred; measured fast / exact: affinity 1.9e-4 / 6.3e-5, trans 2.3e-4 / 1.3e-4,
+        lim.update(affinity=7e-4, trans_rows=8e-4, trans_diag=8e-4, refined=9e-4, par_in=1.5e-3)      # par 4.6e-4 / 1.6e-4, labels 0.013 % / 0.002 %
     bad = {k: (v, lim[k]) for k, v in e.items() if k in lim and not v < lim[k]}
     assert not bad, bad

@@ -91,12 +91,13 @@ class WeCLIP(nn.Module):
         first = 12 - n                      # index into the 12 maps (11 encoder + last block)
         return [i >= first for i in range(11)]
 
-    def encode(self, img, seg_trans, x16=None):
-        """Frozen encoder: token rows of blocks 1..11 and the head-mean maps the affinity needs.
+    def encode(self, img, seg_trans, x16=None, want_maps=True):
+        """Frozen encoder: token rows of blocks 1..11 and the head-mean maps the affinity needs (none when the
+        caller returns before the CAM stage: the COCO model in 'val', model_attn_aff_coco.py:131-132).
         `x16` (a list) additionally receives fp16 copies of the block outputs (adapter operands)."""
         vis = self.encoder.visual
         rows, B, Lq = vis.embed(img)
-        need = self._maps_needed(seg_trans)
+        need = self._maps_needed(seg_trans) if want_maps else [False] * 11
         xs, maps = [], []
         for i in range(vis.transformer.layers - 1):
             rows, m = VE.run_block(vis.transformer.resblocks[i].pack(), rows, B, Lq, want_mean=need[i], x16_out=x16)
@@ -117,7 +118,8 @@ class WeCLIP(nn.Module):
         hip_head = self.head_impl == "hip" and self.comer is None
         x16 = VE.X16Stack(self.encoder.visual.transformer.layers - 1) if hip_head else None
         with torch.no_grad():
-            xs, maps, _, Lq = self.encode(img, seg_trans, x16)
+            want_cam = not (mode == "val" and not self.val_runs_cam)
+            xs, maps, _, Lq = self.encode(img, seg_trans, x16, want_maps=want_cam)
         if hip_head:
             # adapters + decoder + attn_pred, forward and backward as HIP launches (head_engine.py)
             drop = None

@@ -16,10 +16,28 @@ def _map_array(maps):
     return arr
 
 
-def affinity_weight(maps, seg=None, seg_trans=False, n_last=6):
+def seg_layer_keep(maps, n_last=6):
+    """Layer selection of the seg-trans branch (clip_tool.py:158-167) for a batch: (B, n_last) f32 of 0/1.
+    keep_l = [diff_l <= mean diff], diff_l = sum(seg - map_l[1:,1:]); the seg term is common to all layers, so the
+    decision is taken on A_l = sum(map_l[1:,1:]) alone, reduced in a fixed order (csrc/affinity.hip)."""
+    sel = maps[-n_last:]
+    B, Lq, _ = sel[0].shape
+    hw = Lq - 1
+    dev = sel[0].device
+    for m in sel:
+        L.ptr(m, F32, "attention map")
+    diff = torch.empty(B, len(sel), device=dev, dtype=F32)
+    wgt = torch.empty(B, len(sel), device=dev, dtype=F32)
+    rowsum = torch.empty(B, len(sel), hw, device=dev, dtype=F32)
+    L.lib().wc_aff_seg_weights(_map_array(sel), len(sel), L.ptr(rowsum), L.ptr(diff), L.ptr(wgt), B, Lq, L.stream())
+    return (wgt > 0).float()
+
+
+def affinity_weight(maps, seg=None, seg_trans=False, n_last=6, keep=None):
     """maps: list of head-mean attention maps (B,L,L) f32 in layer order (11 encoder + last block).
     Normal branch (clip_tool.py:169-173): mean of the last 8 [1:,1:].  Seg-trans branch
-    (:152-168, n_last 6 VOC / 10 COCO): masked mean of the last n_last times seg (B,hw,hw)."""
+    (:152-168, n_last 6 VOC / 10 COCO): masked mean of the last n_last times seg (B,hw,hw).
+    keep (B, n_last) 0/1, optional: a caller-supplied layer selection instead of seg_layer_keep's."""
     sel = maps[-n_last:] if seg_trans else maps[-8:]      # entries outside the selection may be None
     B, Lq, _ = sel[0].shape
     hw = Lq - 1
@@ -33,10 +51,14 @@ def affinity_weight(maps, seg=None, seg_trans=False, n_last=6):
         lib.wc_aff_weight(_map_array(sel), len(sel), L.ptr(wgt), None, L.ptr(W), B, Lq, L.stream())
         return W
     seg = seg.detach().float().contiguous()
-    diff = torch.empty(B, len(sel), device=dev, dtype=F32)
-    wgt = torch.empty(B, len(sel), device=dev, dtype=F32)
-    rowsum = torch.empty(B, len(sel), hw, device=dev, dtype=F32)
-    lib.wc_aff_seg_weights(_map_array(sel), len(sel), L.ptr(rowsum), L.ptr(diff), L.ptr(wgt), B, Lq, L.stream())
+    if keep is not None:
+        keep = keep.to(dev).float()
+        wgt = (keep / (keep.sum(1, keepdim=True) + 1e-5)).contiguous()
+    else:
+        diff = torch.empty(B, len(sel), device=dev, dtype=F32)
+        wgt = torch.empty(B, len(sel), device=dev, dtype=F32)
+        rowsum = torch.empty(B, len(sel), hw, device=dev, dtype=F32)
+        lib.wc_aff_seg_weights(_map_array(sel), len(sel), L.ptr(rowsum), L.ptr(diff), L.ptr(wgt), B, Lq, L.stream())
     lib.wc_aff_weight(_map_array(sel), len(sel), L.ptr(wgt), L.ptr(seg), L.ptr(W), B, Lq, L.stream())
     return W
 

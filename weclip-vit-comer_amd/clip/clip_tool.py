@@ -131,7 +131,7 @@ def normalised_text(fg_text, bg_text, device):
 
 
 def batch_refined_cams(clip_model, last_rows, maps11, seg_attn, plan, text_hat, h, w, thr,
-                       seg_trans, n_last):
+                       seg_trans, n_last, keep=None):
     """GradCAM for every pair + affinity refinement.  last_rows (B*L, E): block layers-1 output;
     maps11: list of that many head-mean maps (entries may be None where unused).
     Returns (R (B, hw, K) refined CAMs, cams (P, hw), probs (P, Tmax), state)."""
@@ -142,7 +142,7 @@ def batch_refined_cams(clip_model, last_rows, maps11, seg_attn, plan, text_hat, 
     need = maps[-n_last:] if seg_trans else maps[-8:]
     if any(m is None for m in need):
         raise RuntimeError("attention maps needed by the affinity were not computed")
-    W = CP.affinity_weight(maps, seg_attn, seg_trans, n_last)
+    W = CP.affinity_weight(maps, seg_attn, seg_trans, n_last, keep=keep)
     R = CP.refine(W, cams, plan.pair_img, plan.pair_slot, plan.K, h, w, thr)
     return R, cams, probs, st
 

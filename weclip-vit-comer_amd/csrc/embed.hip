@@ -20,9 +20,14 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
         const long r2 = r / w;
         const int py = r2 % h;
         const long b = r2 / h;
-        const float4 v = *reinterpret_cast<const float4*>(
-            img + ((b * 3 + c) * H + (long)py * P + ky) * W + (long)px * P + kx4 * 4);
-        const float f[4] = {v.x, v.y, v.z, v.w};
+        const float* src = img + ((b * 3 + c) * H + (long)py * P + ky) * W + (long)px * P + kx4 * 4;
+        float f[4];
+        if (W % 4 == 0) {        // rows 16-byte aligned
+            const float4 v = *reinterpret_cast<const float4*>(src);
+            f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+        } else {
+            f[0] = src[0]; f[1] = src[1]; f[2] = src[2]; f[3] = src[3];
+        }
         __half hh[4], ll[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -41,8 +46,9 @@ __global__ __launch_bounds__(256) void cls_rows_kernel(float* __restrict__ x, co
 }
 
 extern "C" int wc_patchify(const float* img, void* hi, void* lo, int B, int H, int W, int P, void* stream) {
-    WC_CHECK_ARG(img && hi && B > 0 && P > 0 && P % 4 == 0 && H % P == 0 && W % P == 0 && W % 4 == 0,
-                 "wc_patchify: need H,W multiples of the patch size, patch %% 4 == 0");
+    // a stride-P convolution ignores the H % P bottom rows / W % P right columns (multi-scale inference feeds such sizes)
+    WC_CHECK_ARG(img && hi && B > 0 && P > 0 && P % 4 == 0 && H >= P && W >= P,
+                 "wc_patchify: need H, W >= patch size and patch %% 4 == 0");
     const long total4 = (long)B * (H / P) * (W / P) * 3 * P * (P / 4);
     int blocks = wc_cdiv(total4, 256);
     if (blocks > 8192) blocks = 8192;

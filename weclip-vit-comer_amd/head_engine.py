@@ -194,13 +194,13 @@ class HeadEngine:
         # ---- linear_pred
         x3h = ctx["blocks"][-1]["x2h"]
         if dseg is not None:
-            d = torch.zeros(M, 64, device=dev, dtype=F32)
+            wpT, ldT = self.wcache.wT("pred")          # (E, ldT): the nc class columns, zero padded to a multiple of 64
+            d = torch.zeros(M, ldT, device=dev, dtype=F32)
             d[:, :nc] = dseg.permute(0, 2, 3, 1).reshape(M, nc)
             _, dS = ops.colscale_split(d, None, M, alpha=GS, want32=False, with_lo=ex)
-            wpT, ldT = self.wcache.wT("pred")          # (E, 64): the nc class columns, zero padded
             dx = torch.empty(M, E, device=dev, dtype=F32)
             ops.gemm(dS, wpT, M, E, ldT, out32=dx)
-            wg(dS.hi, x3h.hi, nc, E, "dec.linear_pred.weight", "dec.linear_pred.bias", lda=64)
+            wg(dS.hi, x3h.hi, nc, E, "dec.linear_pred.weight", "dec.linear_pred.bias", lda=ldT)
         else:
             dx = torch.zeros(M, E, device=dev, dtype=F32)
             grads["dec.linear_pred.weight"] = torch.zeros(nc, E, 1, 1, device=dev)

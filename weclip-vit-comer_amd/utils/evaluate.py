@@ -21,7 +21,8 @@ def confusion_hist(label_true, label_pred, num_classes, out=None):
     """Device version of `_fast_hist` summed over a batch: CUDA integer tensors of equal shape ->
     (nc, nc) int64 CUDA tensor (added into `out` if given).  Pixels whose true label is outside
     [0, nc) are skipped; a predicted label outside [0, nc) is an error in the reference too
-    (np.bincount would grow the histogram), here it raises on the host-side check of the kernel's flag."""
+    (np.bincount would grow the histogram): the kernel skips the pixel and raises a device flag that
+    `check_predictions_in_range` reads back."""
     from .. import _lib as L
     L.require_gpu()
     lt = label_true.contiguous()
@@ -34,9 +35,23 @@ def confusion_hist(label_true, label_pred, num_classes, out=None):
         lp = lp.long()
     if out is None:
         out = torch.zeros(num_classes, num_classes, device=lt.device, dtype=torch.int64)
+    flag = _flags.get(lt.device)
+    if flag is None:
+        flag = _flags[lt.device] = torch.zeros(1, device=lt.device, dtype=torch.int32)
     L.lib().wc_confusion_hist(L.ptr(lt, torch.int64, "label_true"), L.ptr(lp, torch.int64, "label_pred"),
-                              L.ptr(out, torch.int64, "hist"), lt.numel(), int(num_classes), L.stream())
+                              L.ptr(out, torch.int64, "hist"), L.ptr(flag, torch.int32, "flag"), lt.numel(),
+                              int(num_classes), L.stream())
     return out
+
+
+_flags = {}
+
+
+def check_predictions_in_range(device):
+    """True unless a confusion_hist call on `device` saw a predicted label outside [0, nc) since start-up (one
+    device->host read; call it once after the evaluation loop, not per image)."""
+    f = _flags.get(torch.device(device))
+    return f is None or int(f.item()) == 0
 
 
 def scores_from_hist(hist):
