@@ -149,7 +149,8 @@ def run_leg(args, dev, rank, world, *, comer=False, seg_trans=False, steps=None,
     model = make_model(dev, comer=comer, seg_trans=seg_trans)
     use_graph = graph and not comer          # the CoMer inserts run stock torch modules (cuDNN-style lazy workspaces): eager
     step = TrainStep(model, graph=use_graph)
-    loader = SyntheticVOCLoader(args.batch, args.size, args.classes_per_image, rank=rank, world=world, device=dev)
+    loader = SyntheticVOCLoader(args.batch, args.size, args.classes_per_image, rank=rank, world=world, device=dev,
+                                source="uint8")      # device-side rescale / flip / crop / normalise inside every step
     for _ in range(2 if use_graph else 0):   # set-up of the graph mode: one eager step, then the capturing step
         img, labels = loader.next()
         step(img, labels=labels)
@@ -302,7 +303,8 @@ def main():
         "dtype": ("f16 MFMA operands / f32 accumulate, f32 residual+softmax+LN, PAR f32 arithmetic on 16-bit fixed-point "
                   "affinities (precision=fast)") if config.precision == "fast" else
                  "f16 hi+lo MFMA operands / f32 accumulate, f32 residual+softmax+LN+PAR (precision=%s)" % config.precision,
-        "data": "synthetic (per-rank seeded loader, a different batch every step)",
+        "data": "synthetic (per-rank seeded loader: uint8 375x500 images resident on the device, random rescale / flip / "
+                "crop / normalise by the HIP input-pipeline kernel inside every step; a different batch every step)",
         "config": {"workload": f"WeCLIP VOC full train step (the reference's model: frozen CLIP ViT-B/16 + adapters + decoder + "
                                f"GradCAM/affinity/PAR pseudo-labels), batch {B}/GPU at {S}x{S}, K={K} classes/image "
                                f"(BASELINE configs[2]{'/[3] DP' if world > 1 else ''}"

@@ -349,6 +349,15 @@ int wc_resize_argmax(const float* seg, long* pred, int C, int Hs, int Ws, int Hd
 int wc_confusion_hist(const long* label_true, const long* label_pred, long* hist, int* flag, long n, int nc,
                       void* stream);
 
+/* ---- device-side input pipeline ------------------------------------------------------------ */
+/* datasets/transforms.py:26-49 (random_scaling), :70-84 (random_fliplr), :119-176 (random_crop, zero padding),
+ * :8-15 (normalize_img) + HWC->CHW (datasets/voc.py:137-143) for a batch in one gather kernel.
+ * src_u8 (B,Hs,Ws,3) uint8; params: B records of 8 x 32 bit {float scale; int flip, rh, rw, pad_y, pad_x, crop_y, crop_x}
+ * (device memory; the random draws are made on the host); dst (B,3,crop,crop) f32; mean3 / std3: HOST float[3].
+ * Half-pixel bilinear resampling, rounded to the uint8 grid like the reference's resize output. */
+int wc_augment_normalize(const void* src_u8, const void* params, float* dst, int B, int Hs, int Ws, int crop,
+                         const float* mean3, const float* std3, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

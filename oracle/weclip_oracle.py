@@ -444,6 +444,28 @@ def fast_hist(label_true, label_pred, num_classes):
     return np.bincount(num_classes * lt[keep] + lp[keep], minlength=num_classes ** 2).reshape(num_classes, num_classes)
 
 
+def augment_normalize(img_u8, scale, flip, pad_y, pad_x, crop_y, crop_x, crop, mean=(123.675, 116.28, 103.53),
+                      std=(58.395, 57.12, 57.375)):
+    """One image of the train-time input chain, datasets/voc.py:108-143 with the random draws given:
+    random_scaling (transforms.py:26-49; bilinear to (int(s*h), int(s*w)), rounded to uint8 -- half-pixel bilinear
+    here, which is PIL's BILINEAR for s >= 1 only), random_fliplr (:70-84), random_crop (:119-176, zero canvas),
+    normalize_img (:8-15), HWC -> CHW.  img_u8 (H,W,3) uint8 -> (3,crop,crop) f32."""
+    H, W, _ = img_u8.shape
+    rh, rw = int(scale * H), int(scale * W)
+    x = img_u8.permute(2, 0, 1).float()[None]
+    x = F.interpolate(x, size=(rh, rw), mode="bilinear", align_corners=False)[0]
+    x = torch.clamp(torch.floor(x + 0.5), 0, 255)
+    if flip:
+        x = x.flip(-1)
+    ch, cw = max(crop, rh), max(crop, rw)
+    canvas = torch.zeros(3, ch, cw)
+    canvas[:, pad_y:pad_y + rh, pad_x:pad_x + rw] = x
+    out = canvas[:, crop_y:crop_y + crop, crop_x:crop_x + crop]
+    m = torch.tensor(mean).view(3, 1, 1)
+    s = torch.tensor(std).view(3, 1, 1)
+    return (out - m) / s
+
+
 # ----------------------------------------------------------------------------- A.10
 
 def radius_mask(h, w, radius=8):

@@ -43,6 +43,13 @@ class PAR(nn.Module):
         return aff
 
     def forward(self, imgs, masks):
+        """Dispatched as the registered custom op `torch.ops.weclip.par_forward` (torch_ops.py) for CUDA tensors."""
+        if masks.is_cuda and not torch.cuda.is_current_stream_capturing():
+            from .. import torch_ops  # noqa: F401  (registers the op)
+            return torch.ops.weclip.par_forward(imgs, masks, self.dilations, self.num_iter)
+        return self._forward_impl(imgs, masks)
+
+    def _forward_impl(self, imgs, masks):
         L.require_gpu()
         masks = masks.float().contiguous()
         b, C, h, w = masks.shape

@@ -15,7 +15,13 @@ library or a GPU is missing.
 """
 import sys
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
+
+
+def register_torch_ops():
+    """Register the hot-path operators with the PyTorch dispatcher (`torch.ops.weclip.*`, torch_ops.py)."""
+    from . import torch_ops
+    return torch_ops.OPS
 
 
 DROPIN_NAMES = ("clip", "pytorch_grad_cam", "WeCLIP_model", "utils")

@@ -28,7 +28,8 @@ def generate_clip_fts(image, model, require_all_fts=True):
 
 def compute_trans_mat(attn_weight):
     """(hw, hw) affinity -> Sinkhorn x3, symmetrise, square (reference clip_tool.py:64-80)."""
-    return CP.trans_mat(attn_weight.detach().float().contiguous()[None].cuda())[0]
+    from .. import torch_ops  # noqa: F401  (registers torch.ops.weclip.*)
+    return torch.ops.weclip.trans_mat(attn_weight.detach().float().contiguous()[None].cuda())[0]
 
 
 def read_image_labels(img_path):

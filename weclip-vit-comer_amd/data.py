@@ -13,17 +13,28 @@ from . import synth
 
 class SyntheticVOCLoader:
     """Iterable of (images (B,3,S,S) f32 CUDA, label lists) -- `DistributedSampler`-like: rank r of `world` draws
-    from its own seed stream, so no two ranks (and no two consecutive steps) see the same tensor."""
+    from its own seed stream, so no two ranks (and no two consecutive steps) see the same tensor.
+
+    source="float": the pool holds ready normalised batches (what the parity tests feed).
+    source="uint8": the pool holds uint8 (B, 375, 500, 3) "decoded JPEGs" on the device and every next() runs the
+    device-side input pipeline (DeviceAugment: random rescale / flip / pad + crop / normalise, csrc/augment.hip) --
+    the per-step work of the reference's loader, minus JPEG decoding, on the GPU and inside the timed step."""
 
     def __init__(self, batch, size, classes_per_image=2, rank=0, world=1, seed=100, pool=4, device="cuda",
-                 n_classes=20):
-        self.batch, self.size, self.rank, self.world = batch, size, rank, world
+                 n_classes=20, source="float", src_hw=(375, 500)):
+        self.batch, self.size, self.rank, self.world, self.source = batch, size, rank, world, source
         self.images, self.labels = [], []
         for j in range(pool):
             s = seed + 1000 * j + rank            # j = 0, rank = 0 is bench.py's historical batch (seed 100 / 7)
-            self.images.append(synth.make_images(batch, size, size, seed=s).to(device))
+            if source == "uint8":
+                f = synth.make_images(batch, src_hw[0], src_hw[1], seed=s)
+                u8 = (f * 58.0 + 118.0).clamp_(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+                self.images.append(u8.to(device))
+            else:
+                self.images.append(synth.make_images(batch, size, size, seed=s).to(device))
             self.labels.append(synth.make_label_lists(batch, classes_per_image, n_classes=n_classes,
                                                       seed=7 + 1000 * j + rank))
+        self.aug = DeviceAugment(crop_size=size, seed=seed + rank) if source == "uint8" else None
         self._i = 0
 
     def __len__(self):
@@ -32,8 +43,59 @@ class SyntheticVOCLoader:
     def next(self):
         i = self._i % len(self.images)
         self._i += 1
+        if self.aug is not None:
+            return self.aug(self.images[i]), self.labels[i]
         return self.images[i], self.labels[i]
 
     def __iter__(self):
         while True:
             yield self.next()
+
+
+MEAN = (123.675, 116.28, 103.53)       # datasets/transforms.py:8
+STD = (58.395, 57.12, 57.375)
+
+
+class DeviceAugment:
+    """The reference's train-time augmentation (datasets/voc.py:108-143: random_scaling -> random_fliplr -> random_crop
+    -> normalize_img -> CHW) with the random draws on the host and the pixel work in ONE HIP kernel per batch
+    (csrc/augment.hip): uint8 (B,H,W,3) on the device in, float32 (B,3,crop,crop) normalised out.  The host never
+    touches a pixel, so the loader cannot serialise the step."""
+
+    def __init__(self, crop_size=512, rescale_range=(0.5, 2.0), fliplr=True, seed=0, mean=MEAN, std=STD):
+        import numpy as np
+        self.crop, self.range, self.fliplr = int(crop_size), tuple(rescale_range), bool(fliplr)
+        self.rng = np.random.RandomState(seed)
+        self.mean, self.std = tuple(float(v) for v in mean), tuple(float(v) for v in std)
+
+    def draw(self, B, H, W):
+        """Host-side random parameters of one batch -> int32 tensor (B, 8) in the kernel's record layout."""
+        import numpy as np
+        rec = np.zeros((B, 8), np.int32)
+        for b in range(B):
+            s = self.rng.uniform(*self.range) if self.range else 1.0
+            rh, rw = int(s * H), int(s * W)
+            flip = int(self.fliplr and self.rng.rand() > 0.5)
+            ch, cw = max(self.crop, rh), max(self.crop, rw)                  # canvas (transforms.py:123-124)
+            pad_y, pad_x = int(self.rng.randint(ch - rh + 1)), int(self.rng.randint(cw - rw + 1))
+            crop_y, crop_x = int(self.rng.randint(ch - self.crop + 1)), int(self.rng.randint(cw - self.crop + 1))
+            rec[b, 0] = np.float32(s).view(np.int32)
+            rec[b, 1:] = (flip, rh, rw, pad_y, pad_x, crop_y, crop_x)
+        return torch.from_numpy(rec)
+
+    def __call__(self, images_u8, params=None):
+        """images_u8 (B,H,W,3) uint8 CUDA; params: a draw() result (default: a fresh draw).  -> (B,3,crop,crop) f32."""
+        import ctypes
+        from . import _lib as L
+        L.require_gpu()
+        B, H, W, C = images_u8.shape
+        if C != 3 or images_u8.dtype != torch.uint8:
+            raise RuntimeError("DeviceAugment expects uint8 (B, H, W, 3) images")
+        if params is None:
+            params = self.draw(B, H, W)
+        p = params.pin_memory().to(images_u8.device, non_blocking=True) if not params.is_cuda else params
+        out = torch.empty(B, 3, self.crop, self.crop, device=images_u8.device, dtype=torch.float32)
+        L.lib().wc_augment_normalize(L.ptr(images_u8.contiguous(), torch.uint8, "images"), L.ptr(p, torch.int32, "params"),
+                                     L.ptr(out), B, H, W, self.crop, (ctypes.c_float * 3)(*self.mean),
+                                     (ctypes.c_float * 3)(*self.std), L.stream())
+        return out
