@@ -315,11 +315,13 @@ int wc_colscale_split(const float* x, const float* cs, float* out32, void* hi, v
  * value (N,S,M,D) f32, S = sum_l H_l*W_l (h_shapes: HOST array of n_levels (H,W) pairs);
  * loc (N,Lq,M,nL,P,2) f32 in [0,1] as (x,y); attn (N,Lq,M,nL,P) f32; out (N,Lq,M*D) f32:
  * out = sum_l sum_p attn * bilinear_zero_pad(value_l, loc*size - 0.5).
- * wc_msda_bwd: gvalue (ZERO-INITIALISED by the caller, accumulated with atomics), gloc, gattn. */
+ * wc_msda_bwd: gvalue (every element written once: no initialisation needed), gloc, gattn.  grad_value is scattered
+ *              in LDS as fixed point (scale 2^30 / max|gout|) with integer adds: no global float atomics, the
+ *              result is independent of the execution order.  gmax: workspace of one uint32. */
 int wc_msda_fwd(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
                 float* out, int N, int Lq, int M, int D, int P, void* stream);
 int wc_msda_bwd(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
-                const float* gout, float* gvalue, float* gloc, float* gattn, int N, int Lq, int M, int D,
+                const float* gout, float* gvalue, float* gloc, float* gattn, void* gmax, int N, int Lq, int M, int D,
                 int P, void* stream);
 
 /* Depth-wise conv2d (stride 1, zero "same" padding k/2, odd k <= 7) of the MRFP block of the ViT-CoMer inserts
@@ -329,6 +331,21 @@ int wc_dwconv_fwd(const float* x, const float* w, const float* bias, float* y, i
                   void* stream);
 int wc_dwconv_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, float* part,
                   int N, int C, int H, int W, int k, void* stream);
+
+/* ---- ViT-CoMer spatial-prior conv stem on token rows (no reference code) ---- */
+/* Activations are rows x[(n*H + y)*W + x][c] (NHWC).  A 3x3 / stride-s / pad-1 convolution = wc_im2col3x3 + wc_gemm_f16
+ * against Wmat[o][(ky*3+kx)*C + c] = w[o][c][ky][kx] (zero padded to Kp); its input gradient = wc_gemm_f16 (dY W) +
+ * wc_col2im3x3 (a deterministic gather).  wc_groupnorm_relu_*: nn.GroupNorm(G, C) followed by ReLU, all reductions in
+ * a fixed order.  stats: N*G*2 f32 (mean, rstd); part: N*ceil(HW/64)*G*2 f32; gpart like part; cpart:
+ * N*ceil(HW/64)*C*2 f32; gsum: N*G*2 f32. */
+int wc_im2col3x3(const float* x, void* cols_hi, void* cols_lo, int N, int H, int W, int C, int stride, int Kp,
+                 void* stream);
+int wc_col2im3x3(const float* dcols, float* dx, int N, int H, int W, int C, int stride, int Kp, void* stream);
+int wc_groupnorm_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* part,
+                          int N, int HW, int C, int G, float eps, void* stream);
+int wc_groupnorm_relu_bwd(const float* x, const float* y, const float* dy, const float* stats, const float* gamma,
+                          float* dx, float* dgamma, float* dbeta, float* gpart, float* cpart, float* gsum, int N,
+                          int HW, int C, int G, void* stream);
 
 /* ---- multi-scale + flip inference and the confusion histogram ----------------------------- */
 /* test_msc_flip_coco.py:61-96 (`validate`: [img, flip] at every scale, flip-average, mean over scales, bilinear to

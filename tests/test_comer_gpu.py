@@ -116,3 +116,91 @@ def test_comer_hip_decoder_matches_stock_autograd_decoder():
                      m.decoder.linear_pred.weight.grad.clone(), m.comer.cti[0].to_v.value_proj.weight.grad.clone())
     for a, b, tol in zip(res["hip"], res["torch"], (5e-3, 5e-3, 5e-2, 5e-2, 5e-2)):
         assert (a - b).abs().max().item() <= tol * max(b.abs().max().item(), 1e-6), (a - b).abs().max().item()
+
+
+@pytest.mark.parametrize("M,K,N,act,bias", [(700, 256, 192, 0, True), (300, 128, 256, 2, True), (520, 64, 96, 0, False), (1000, 1024, 256, 0, True)])
+def test_hip_linear_and_layernorm_match_torch_autograd(M, K, N, act, bias):
+    """hip_functional.linear / layer_norm (the Linear, 1x1-conv and LayerNorm layers of the CoMer inserts): forward and the
+    three gradients vs stock torch in fp64."""
+    from weclip_vit_comer_amd import hip_functional as HF
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g) if bias else None
+    gy = torch.randn(M, N, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if bias else None
+    xg, wg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    bg = b.cuda().requires_grad_(True) if bias else None
+    y = HF.linear(xg, wg, bg, act)
+    y.backward(gy.cuda())
+    yr = torch.nn.functional.linear(xr, wr, br)
+    if act == 2:       # the ReLU mask of the HIP forward: a pre-activation within fp16 rounding of 0 may land on either side
+        yr = yr * (y.detach().cpu() > 0)
+    yr.backward(gy.double())
+    rel = lambda a, r: (a.cpu().double() - r).abs().max().item() / r.abs().max().item()
+    e = [rel(y.detach(), yr.detach()), rel(xg.grad, xr.grad), rel(wg.grad, wr.grad)] + ([rel(bg.grad, br.grad)] if bias else [])
+    print(f"hip linear {M}x{K}->{N} act={act}: fwd {e[0]:.1e} dx {e[1]:.1e} dW {e[2]:.1e}" + (f" db {e[3]:.1e}" if bias else ""))
+    assert max(e) < 3e-3, e                 # fp16 MFMA operands, fp32 accumulate
+    lnw, lnb = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    xr2 = x.double().requires_grad_(True)
+    lwr, lbr = lnw.double().requires_grad_(True), lnb.double().requires_grad_(True)
+    gl = torch.randn(M, K, generator=g)
+    torch.nn.functional.layer_norm(xr2, (K,), lwr, lbr).backward(gl.double())       # (LayerNorm dims of the inserts: 256)
+    xg2 = x.cuda().requires_grad_(True)
+    lwg, lbg = lnw.cuda().requires_grad_(True), lnb.cuda().requires_grad_(True)
+    HF.layer_norm(xg2, lwg, lbg).backward(gl.cuda())
+    assert rel(xg2.grad, xr2.grad) < 1e-4 and rel(lwg.grad, lwr.grad) < 1e-4 and rel(lbg.grad, lbr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("N,C,O,H,W,stride", [(2, 3, 32, 32, 48, 2), (2, 32, 64, 17, 23, 2), (1, 64, 128, 16, 16, 1)])
+def test_conv_stem_kernels_match_torch(N, C, O, H, W, stride):
+    """3x3 / pad-1 convolution (im2col + MFMA GEMM, col2im) and GroupNorm + ReLU on NHWC rows vs torch modules in fp64."""
+    import torch.nn as nn
+    from weclip_vit_comer_amd import hip_functional as HF
+    torch.manual_seed(C + O)
+    conv = nn.Conv2d(C, O, 3, stride, 1, bias=False)
+    gn = nn.GroupNorm(8, O)
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.normal_(0, 0.2)
+    x = torch.randn(N, C, H, W)
+    rc, rg = nn.Conv2d(C, O, 3, stride, 1, bias=False).double(), nn.GroupNorm(8, O).double()
+    rc.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    rg.load_state_dict({k: v.double() for k, v in gn.state_dict().items()})
+    conv, gn = conv.cuda(), gn.cuda()
+    xg = x.cuda().permute(0, 2, 3, 1).reshape(N * H * W, C).requires_grad_(True)
+    z, Ho, Wo = HF.conv3x3_rows(xg, conv.weight, N, H, W, stride)
+    y = HF.groupnorm_relu_rows(z, gn, N)
+    # fp64 reference through the ReLU mask of the HIP forward (a pre-activation within rounding of 0 may land on either side)
+    mask = (y.detach().cpu() > 0).view(N, Ho, Wo, O).permute(0, 3, 1, 2)
+    xr = x.double().requires_grad_(True)
+    zr = rc(xr)
+    yr = rg(zr) * mask
+    assert (Ho, Wo) == tuple(yr.shape[-2:])
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    y.backward(gy.permute(0, 2, 3, 1).reshape(-1, O).float().cuda())
+    nhwc = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+    rel = lambda a, r: (a.detach().cpu().double() - r).abs().max().item() / r.abs().max().item()
+    e = dict(conv=rel(z, nhwc(zr.detach())), out=rel(y, nhwc(yr.detach())), dx=rel(xg.grad, nhwc(xr.grad)),
+             dw=rel(conv.weight.grad, rc.weight.grad), dgamma=rel(gn.weight.grad, rg.weight.grad), dbeta=rel(gn.bias.grad, rg.bias.grad))
+    print(f"conv stem {C}->{O} s{stride} {H}x{W}: " + "  ".join(f"{k} {v:.1e}" for k, v in e.items()))
+    assert max(e.values()) < 5e-3, e
+
+
+def test_msda_backward_is_bit_reproducible():
+    """grad_value is scattered with LDS integer adds (64-bit fixed point), not global float atomics: two runs give the
+    same bits, whatever order the workgroups run in."""
+    from weclip_vit_comer_amd.WeCLIP_model.comer import ms_deform_attn_core
+    shapes = [(64, 64), (32, 32), (16, 16)]
+    value, loc, attn = _inputs(2, shapes, 1024, 8, 32, 4, seed=5)
+    loc = (loc * 0.2 + 0.4)                       # crowd the samples: many contributions per pixel
+    g = torch.randn(2, 1024, 256, generator=torch.Generator().manual_seed(2)).cuda()
+    grads = []
+    for _ in range(2):
+        vg, lg, ag = [t.cuda().requires_grad_(True) for t in (value, loc, attn)]
+        (ms_deform_attn_core(vg, shapes, lg, ag) * g).sum().backward()
+        grads.append((vg.grad.clone(), lg.grad.clone(), ag.grad.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*grads))
+    assert grads[0][0].abs().max().item() > 0

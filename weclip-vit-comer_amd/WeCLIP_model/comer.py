@@ -9,9 +9,11 @@ bidirectional CTI exchanges features with the ViT branch through multi-scale def
 Per the brief the ViT stays frozen and the *WeCLIP adapter outputs* (256-d maps of those blocks) are
 the ViT-side features; the 8 CTI outputs (4 toV maps + 4 toC 1/16 maps) are channel-concatenated and
 fused by a 1x1 conv into the decoder input.  Everything here is trainable.  The deformable-attention
-core runs on the HIP kernels of csrc/msdeform.hip (forward gather + backward scatter); the small
-Linear / conv layers around it are stock PyTorch-ROCm modules.  Parity is pinned only against
-oracle/comer_oracle.py (no reference exists).
+core runs on the HIP kernels of csrc/msdeform.hip (forward gather + backward scatter); every Linear / 1x1
+conv / LayerNorm around it goes through hip_functional.py (MFMA GEMM forward, input / weight / bias gradients,
+LayerNorm forward / backward); the depth-wise convs are csrc/dwconv.hip and the 3x3 stride-2 stem convs +
+GroupNorm + ReLU are csrc/convstem.hip.  Parity is pinned only against oracle/comer_oracle.py and stock torch
+modules (no reference exists).
 """
 import math
 
@@ -20,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib as L
+from ..hip_functional import module_layer_norm as _ln, module_linear as _lin
 
 F32 = torch.float32
 
@@ -43,10 +46,11 @@ class _MSDAFunction(torch.autograd.Function):
         value, loc, attn = ctx.saved_tensors
         N, S, M, D = value.shape
         Lq, nL, P = loc.shape[1], loc.shape[3], loc.shape[4]
-        gv, gl, ga = torch.zeros_like(value), torch.empty_like(loc), torch.empty_like(attn)
+        gv, gl, ga = torch.empty_like(value), torch.empty_like(loc), torch.empty_like(attn)
+        gmax = torch.empty(1, device=value.device, dtype=torch.int32)
         hs = L.int_array([v for hw in ctx.shapes for v in hw])
         L.lib().wc_msda_bwd(L.ptr(value), hs, nL, L.ptr(loc), L.ptr(attn), L.ptr(gout.float().contiguous(), F32, "gout"),
-                            L.ptr(gv), L.ptr(gl), L.ptr(ga), N, Lq, M, D, P, L.stream())
+                            L.ptr(gv), L.ptr(gl), L.ptr(ga), L.ptr(gmax), N, Lq, M, D, P, L.stream())
         return gv, gl, ga, None
 
 
@@ -78,12 +82,12 @@ class MSDeformAttn(nn.Module):
         """query (N,Lq,C); reference_points (N,Lq,nL,2) in [0,1]; feat (N,S,C), S = sum H_l*W_l."""
         N, Lq, C = query.shape
         M, nL, P = self.n_heads, self.n_levels, self.n_points
-        value = self.value_proj(feat).view(N, feat.shape[1], M, C // M)
-        off = self.sampling_offsets(query).view(N, Lq, M, nL, P, 2)
-        aw = F.softmax(self.attention_weights(query).view(N, Lq, M, nL * P), -1).view(N, Lq, M, nL, P)
+        value = _lin(self.value_proj, feat).view(N, feat.shape[1], M, C // M)
+        off = _lin(self.sampling_offsets, query).view(N, Lq, M, nL, P, 2)
+        aw = F.softmax(_lin(self.attention_weights, query).view(N, Lq, M, nL * P), -1).view(N, Lq, M, nL, P)
         norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32, device=query.device)
         loc = reference_points[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
-        return self.output_proj(ms_deform_attn_core(value, shapes, loc, aw))
+        return _lin(self.output_proj, ms_deform_attn_core(value, shapes, loc, aw))
 
 
 def _ref_points(h, w, device):
@@ -141,14 +145,14 @@ class MRFP(nn.Module):
         self.dw5 = nn.Conv2d(hidden // 2, hidden // 2, 5, padding=2, groups=hidden // 2)
 
     def forward(self, c, shapes):
-        x = self.fc1(c)
+        x = _lin(self.fc1, c)
         outs, s = [], 0
         for h, w in shapes:
             t = x[:, s:s + h * w].transpose(1, 2).reshape(x.shape[0], -1, h, w)
             a, b = t.chunk(2, dim=1)
             outs.append(torch.cat([_dwconv(self.dw3, a), _dwconv(self.dw5, b)], 1).flatten(2).transpose(1, 2))
             s += h * w
-        return c + self.fc2(F.gelu(torch.cat(outs, 1)))
+        return c + _lin(self.fc2, F.gelu(torch.cat(outs, 1)))
 
 
 class CTI(nn.Module):
@@ -167,10 +171,10 @@ class CTI(nn.Module):
         h, w = hw
         dev = v.device
         rv = _ref_points(h, w, dev)[None, :, None, :].expand(v.shape[0], -1, 3, -1)
-        v = v + self.gamma * self.to_v(self.nv_q(v), rv, self.nv_f(c), shapes)
+        v = v + self.gamma * self.to_v(_ln(self.nv_q, v), rv, _ln(self.nv_f, c), shapes)
         rc = torch.cat([_ref_points(a, b, dev) for a, b in shapes], 0)[None, :, None, :].expand(v.shape[0], -1, 1, -1)
-        c = c + self.to_c(self.nc_q(c), rc, self.nc_f(v), [(h, w)])
-        c = c + self.ffn(self.ffn_norm(c))
+        c = c + self.to_c(_ln(self.nc_q, c), rc, _ln(self.nc_f, v), [(h, w)])
+        c = c + _lin(self.ffn[2], self.ffn[1](_lin(self.ffn[0], _ln(self.ffn_norm, c))))
         return v, c
 
 
@@ -188,13 +192,31 @@ class SpatialPrior(nn.Module):
         self.p2, self.p3, self.p4 = nn.Conv2d(2 * inplanes, dim, 1), nn.Conv2d(4 * inplanes, dim, 1), nn.Conv2d(4 * inplanes, dim, 1)
 
     def forward(self, img):
+        if img.is_cuda:
+            return self._forward_hip(img)
         x = self.stem(img)
         c2 = self.c2(x)
         c3 = self.c3(c2)
         c4 = self.c4(c3)
-        feats = [self.p2(c2), self.p3(c3), self.p4(c4)]
-        shapes = [tuple(f.shape[-2:]) for f in feats]
-        return torch.cat([f.flatten(2).transpose(1, 2) for f in feats], 1), shapes
+        shapes = [tuple(f.shape[-2:]) for f in (c2, c3, c4)]
+        toks = [_lin(p, f.flatten(2).transpose(1, 2)) for p, f in ((self.p2, c2), (self.p3, c3), (self.p4, c4))]
+        return torch.cat(toks, 1), shapes
+
+    def _forward_hip(self, img):
+        """The same five conv -> GroupNorm -> ReLU blocks on NHWC token rows: im2col + MFMA GEMM, fixed-order GroupNorm
+        (hip_functional.conv3x3_rows / groupnorm_relu_rows); the 1x1 projections are GEMMs on the same rows."""
+        from ..hip_functional import conv3x3_rows, groupnorm_relu_rows
+        N, _, H, W = img.shape
+        x = img.float().permute(0, 2, 3, 1).reshape(N * H * W, 3)
+        feats = []
+        for blk in (self.stem[0], self.stem[1], self.c2, self.c3, self.c4):
+            conv, gn = blk[0], blk[1]
+            x, H, W = conv3x3_rows(x, conv.weight, N, H, W, conv.stride[0])
+            x = groupnorm_relu_rows(x, gn, N)
+            feats.append((x, H, W))
+        shapes = [(h, w) for _, h, w in feats[2:]]
+        toks = [_lin(p, f.view(N, h * w, -1)) for p, (f, h, w) in zip((self.p2, self.p3, self.p4), feats[2:])]
+        return torch.cat(toks, 1), shapes
 
 
 class CoMerInteraction(nn.Module):
@@ -220,5 +242,5 @@ class CoMerInteraction(nn.Module):
             n16 = shapes[0][0] * shapes[0][1]
             outs += [v, c[:, n16:n16 + shapes[1][0] * shapes[1][1]]]
         cat = torch.cat(outs, 2)                                                        # (B, hw, 8*dim)
-        y = F.linear(cat, self.fuse.weight.flatten(1), self.fuse.bias)
+        y = _lin(self.fuse, cat)
         return y.transpose(1, 2).reshape(img.shape[0], -1, h, w)

@@ -23,6 +23,9 @@ class MLP(nn.Module):
         return self.tokens(x.flatten(2).transpose(1, 2))
 
     def tokens(self, t):
+        if t.is_cuda:          # MFMA GEMM forward / backward (hip_functional.py): used where the grouped HeadEngine is not
+            from ..hip_functional import module_linear
+            return module_linear(self.proj_2, module_linear(self.proj, t, act=2))
         return self.proj_2(F.relu(self.proj(t)))
 
 

@@ -1,0 +1,279 @@
+// Conv stem of the ViT-CoMer spatial-prior branch on token rows (NHWC): 3x3 / stride-s / pad-1 convolutions as an
+// im2col gather + the MFMA GEMM (csrc/gemm.hip), and GroupNorm + ReLU, forward and backward.
+// (No reference code exists for the CoMer inserts; these replace the nn.Conv2d / nn.GroupNorm /
+// nn.ReLU modules of WeCLIP_model/comer.py's SpatialPrior, which otherwise run MIOpen's fp32 kernels.)
+//
+// Activations are rows x[(n*H + y)*W + x][c] (the layout the 1x1 projections and the GEMM want).
+//   im2col_kernel      : cols[(n*Ho + oy)*Wo + ox][(ky*3 + kx)*C + c] = x[n, oy*s - 1 + ky, ox*s - 1 + kx, c] (0 outside),
+//                        written as fp16 hi (+ lo), zero padded to Kp columns (a multiple of 64: the GEMM's K).
+//                        The weight matrix is laid out to match: Wmat[o][(ky*3 + kx)*C + c] = w[o][c][ky][kx].
+//   col2im_kernel      : dx[n, iy, ix, c] = sum over the (ky, kx, oy, ox) with oy*s - 1 + ky == iy, ox*s - 1 + kx == ix
+//                        of dcols[...]: a gather per input pixel (at most ceil(3/s)^2 terms), deterministic.
+//   gn_stats_kernel    : per (n, group) mean and rstd over H*W*(C/G) values, fixed-order two-stage reduction.
+//   gn_relu_fwd_kernel : y = relu((x - mean) * rstd * gamma + beta)
+//   gn_relu_bwd_*      : GroupNorm backward through the ReLU mask: per-(n, g) sums of g and g*xhat (two-stage,
+//                        fixed order), then dx; per-channel dgamma / dbeta partials per (n, row block), summed in order.
+#include "common.h"
+
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, __half* __restrict__ hi,
+                                                      __half* __restrict__ lo, int N, int H, int W, int C, int Ho, int Wo,
+                                                      int stride, int Kp, long total) {
+    const int K = 9 * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int col = (int)(i % Kp);
+        const long row = i / Kp;
+        float v = 0.f;
+        if (col < K) {
+            const int tap = col / C, c = col - tap * C;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int ox = (int)(row % Wo);
+            const long r2 = row / Wo;
+            const int oy = (int)(r2 % Ho);
+            const long n = r2 / Ho;
+            const int iy = oy * stride - 1 + ky, ix = ox * stride - 1 + kx;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((n * H + iy) * W + ix) * C + c];
+        }
+        const __half h = __float2half(v);
+        hi[i] = h;
+        if (lo) lo[i] = __float2half(v - __half2float(h));
+    }
+}
+
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcols, float* __restrict__ dx, int N, int H,
+                                                      int W, int C, int Ho, int Wo, int stride, int Kp, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long p = i / C;
+        const int ix = (int)(p % W);
+        const long p2 = p / W;
+        const int iy = (int)(p2 % H);
+        const long n = p2 / H;
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = iy + 1 - ky;
+            if (ty < 0 || ty % stride) continue;
+            const int oy = ty / stride;
+            if (oy >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = ix + 1 - kx;
+                if (tx < 0 || tx % stride) continue;
+                const int ox = tx / stride;
+                if (ox >= Wo) continue;
+                acc += dcols[((n * Ho + oy) * Wo + ox) * Kp + (ky * 3 + kx) * C + c];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
+// ---- GroupNorm + ReLU on rows (n, HW, C), G groups of Cg = C / G channels --------------------------------------
+#define GN_ROWS 64      // rows of one partial block
+
+// part[(n*nblk + blk)*G + g] = (sum, sumsq) of rows [blk*GN_ROWS, ...) of image n, group g       (grid: nblk, N)
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, float2* __restrict__ part, int HW,
+                                                          int C, int G) {
+    __shared__ float red[16];
+    const int blk = blockIdx.x, n = blockIdx.y, nblk = gridDim.x;
+    const int Cg = C / G;
+    const int r0 = blk * GN_ROWS, r1 = min(r0 + GN_ROWS, HW);
+    for (int g = 0; g < G; ++g) {
+        float s = 0.f, q = 0.f;
+        const int cnt = (r1 - r0) * Cg;
+        for (int e = threadIdx.x; e < cnt; e += 256) {
+            const int r = r0 + e / Cg, c = g * Cg + e % Cg;
+            const float v = x[((long)n * HW + r) * C + c];
+            s += v;
+            q += v * v;
+        }
+        s = block_sum(s, red);
+        q = block_sum(q, red);
+        if (threadIdx.x == 0) part[((long)n * nblk + blk) * G + g] = make_float2(s, q);
+    }
+}
+
+// stats[n*G + g] = (mean, rstd): serial, fixed-order sum of the partials                       (grid: N*G threads)
+__global__ void gn_finish_kernel(const float2* __restrict__ part, float2* __restrict__ stats, int nblk, int G, int N,
+                                 float count, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * G) return;
+    const int n = i / G, g = i - n * G;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        const float2 p = part[((long)n * nblk + b) * G + g];
+        s += p.x;
+        q += p.y;
+    }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[i] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+}
+
+__global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restrict__ x, const float2* __restrict__ stats,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ y, int HW, int C, int G, long total) {
+    const int Cg = C / G;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long n = i / ((long)HW * C);
+        const float2 st = stats[n * G + c / Cg];
+        const float v = (x[i] - st.x) * st.y * gamma[c] + beta[c];
+        y[i] = v > 0.f ? v : 0.f;
+    }
+}
+
+// backward partials: per (n, blk): group sums (sum g, sum g*xhat) with g = dy*mask*gamma, and per channel
+// (sum dy*mask*xhat, sum dy*mask)                                                                (grid: nblk, N)
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                              const float* __restrict__ dy, const float2* __restrict__ stats,
+                                                              const float* __restrict__ gamma, float2* __restrict__ gpart,
+                                                              float2* __restrict__ cpart, int HW, int C, int G) {
+    __shared__ float red[16];
+    const int blk = blockIdx.x, n = blockIdx.y, nblk = gridDim.x;
+    const int Cg = C / G;
+    const int r0 = blk * GN_ROWS, r1 = min(r0 + GN_ROWS, HW);
+    for (int g = 0; g < G; ++g) {
+        const float2 st = stats[n * G + g];
+        float s = 0.f, q = 0.f;
+        const int cnt = (r1 - r0) * Cg;
+        for (int e = threadIdx.x; e < cnt; e += 256) {
+            const int r = r0 + e / Cg, c = g * Cg + e % Cg;
+            const long o = ((long)n * HW + r) * C + c;
+            const float gg = (y[o] > 0.f ? dy[o] : 0.f) * gamma[c];
+            s += gg;
+            q += gg * (x[o] - st.x) * st.y;
+        }
+        s = block_sum(s, red);
+        q = block_sum(q, red);
+        if (threadIdx.x == 0) gpart[((long)n * nblk + blk) * G + g] = make_float2(s, q);
+    }
+    for (int c = threadIdx.x; c < C; c += 256) {           // channel sums over this block's rows, serial per channel
+        const float2 st = stats[n * G + c / Cg];
+        float a = 0.f, b = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            const long o = ((long)n * HW + r) * C + c;
+            const float d = y[o] > 0.f ? dy[o] : 0.f;
+            a += d * (x[o] - st.x) * st.y;
+            b += d;
+        }
+        cpart[((long)n * nblk + blk) * C + c] = make_float2(a, b);
+    }
+}
+
+// gsum[n*G + g] = sum of the group partials; dgamma/dbeta[c] = sum over (n, blk) of the channel partials.
+// One workgroup per output; thread t sums partials t, t+256, ... and block_sum combines them: a fixed order.
+// grid: N*G + C workgroups
+__global__ __launch_bounds__(256) void gn_bwd_finish_kernel(const float2* __restrict__ gpart, const float2* __restrict__ cpart,
+                                                             float2* __restrict__ gsum, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int nblk, int G, int N, int C) {
+    __shared__ float red[16];
+    const int i = blockIdx.x;
+    float a = 0.f, b = 0.f;
+    if (i < N * G) {
+        const int n = i / G, g = i - n * G;
+        for (int k = threadIdx.x; k < nblk; k += 256) {
+            const float2 p = gpart[((long)n * nblk + k) * G + g];
+            a += p.x;
+            b += p.y;
+        }
+    } else {
+        const int c = i - N * G;
+        for (long k = threadIdx.x; k < (long)N * nblk; k += 256) {
+            const float2 p = cpart[k * C + c];
+            a += p.x;
+            b += p.y;
+        }
+    }
+    a = block_sum(a, red);
+    b = block_sum(b, red);
+    if (threadIdx.x == 0) {
+        if (i < N * G) gsum[i] = make_float2(a, b);
+        else { dgamma[i - N * G] = a; dbeta[i - N * G] = b; }
+    }
+}
+
+// dx = rstd * (g - (sum_g + xhat * sum_gx) / count)
+__global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ dy, const float2* __restrict__ stats,
+                                                         const float2* __restrict__ gsum, const float* __restrict__ gamma,
+                                                         float* __restrict__ dx, int HW, int C, int G, float count,
+                                                         long total) {
+    const int Cg = C / G;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long n = i / ((long)HW * C);
+        const int g = c / Cg;
+        const float2 st = stats[n * G + g], gs = gsum[n * G + g];
+        const float xh = (x[i] - st.x) * st.y;
+        const float gg = (y[i] > 0.f ? dy[i] : 0.f) * gamma[c];
+        dx[i] = st.y * (gg - (gs.x + xh * gs.y) / count);
+    }
+}
+
+static int grid_for(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+}
+
+extern "C" int wc_im2col3x3(const float* x, void* cols_hi, void* cols_lo, int N, int H, int W, int C, int stride, int Kp,
+                            void* stream) {
+    WC_CHECK_ARG(x && cols_hi && N > 0 && H > 0 && W > 0 && C > 0 && (stride == 1 || stride == 2) && Kp >= 9 * C && Kp % 64 == 0,
+                 "wc_im2col3x3: bad argument (stride 1 or 2, Kp >= 9 C and a multiple of 64)");
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const long total = (long)N * Ho * Wo * Kp;
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (__half*)cols_hi, (__half*)cols_lo,
+                       N, H, W, C, Ho, Wo, stride, Kp, total);
+    WC_LAUNCH_CHECK("im2col_kernel");
+    return WC_OK;
+}
+
+extern "C" int wc_col2im3x3(const float* dcols, float* dx, int N, int H, int W, int C, int stride, int Kp, void* stream) {
+    WC_CHECK_ARG(dcols && dx && N > 0 && H > 0 && W > 0 && C > 0 && (stride == 1 || stride == 2) && Kp >= 9 * C,
+                 "wc_col2im3x3: bad argument");
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const long total = (long)N * H * W * C;
+    hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dcols, dx, N, H, W, C, Ho, Wo,
+                       stride, Kp, total);
+    WC_LAUNCH_CHECK("col2im_kernel");
+    return WC_OK;
+}
+
+extern "C" int wc_groupnorm_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                                     float* part, int N, int HW, int C, int G, float eps, void* stream) {
+    WC_CHECK_ARG(x && gamma && beta && y && stats && part && N > 0 && N <= 65535 && HW > 0 && C > 0 && G > 0 && C % G == 0,
+                 "wc_groupnorm_relu_fwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = wc_cdiv(HW, GN_ROWS);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, N), dim3(256), 0, st, x, (float2*)part, HW, C, G);
+    WC_LAUNCH_CHECK("gn_partial_kernel");
+    hipLaunchKernelGGL(gn_finish_kernel, dim3(wc_cdiv(N * G, 64)), dim3(64), 0, st, (const float2*)part, (float2*)stats, nblk, G, N,
+                       (float)((double)HW * (C / G)), eps);
+    WC_LAUNCH_CHECK("gn_finish_kernel");
+    const long total = (long)N * HW * C;
+    hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, (const float2*)stats, gamma, beta, y, HW, C,
+                       G, total);
+    WC_LAUNCH_CHECK("gn_relu_fwd_kernel");
+    return WC_OK;
+}
+
+extern "C" int wc_groupnorm_relu_bwd(const float* x, const float* y, const float* dy, const float* stats, const float* gamma,
+                                     float* dx, float* dgamma, float* dbeta, float* gpart, float* cpart, float* gsum, int N,
+                                     int HW, int C, int G, void* stream) {
+    WC_CHECK_ARG(x && y && dy && stats && gamma && dx && dgamma && dbeta && gpart && cpart && gsum && N > 0 && N <= 65535 &&
+                 HW > 0 && C > 0 && G > 0 && C % G == 0, "wc_groupnorm_relu_bwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = wc_cdiv(HW, GN_ROWS);
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nblk, N), dim3(256), 0, st, x, y, dy, (const float2*)stats, gamma,
+                       (float2*)gpart, (float2*)cpart, HW, C, G);
+    WC_LAUNCH_CHECK("gn_bwd_partial_kernel");
+    hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3(N * G + C), dim3(256), 0, st, (const float2*)gpart, (const float2*)cpart,
+                       (float2*)gsum, dgamma, dbeta, nblk, G, N, C);
+    WC_LAUNCH_CHECK("gn_bwd_finish_kernel");
+    const long total = (long)N * HW * C;
+    hipLaunchKernelGGL(gn_bwd_dx_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, y, dy, (const float2*)stats,
+                       (const float2*)gsum, gamma, dx, HW, C, G, (float)((double)HW * (C / G)), total);
+    WC_LAUNCH_CHECK("gn_bwd_dx_kernel");
+    return WC_OK;
+}

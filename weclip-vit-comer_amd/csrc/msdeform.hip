@@ -10,8 +10,13 @@
 //
 // Layout: value (N, S, M, D) with S = sum_l H_l*W_l; one 64*k-thread block per query, thread = (head m,
 // channel d): the D channels of a sampled corner are D consecutive floats, so every gather is a
-// coalesced D*4-byte read.  Backward scatters grad_value with float atomics (one dword per lane,
-// contiguous per head) and reduces the location / weight gradients across the D lanes of a head.
+// coalesced D*4-byte read.  Backward: the location / weight gradients are reduced across the D lanes of a head
+// (msda_bwd_kernel); grad_value is a scatter (many samples land on one pixel), done WITHOUT global float atomics:
+// msda_bwd_value_kernel gives every (image, head, block of <= 16384/D consecutive pixels of one level) to one
+// workgroup that keeps the block's gradient in LDS as fixed point (scale 2^30 / max|grad_out|, two 32-bit halves), scans the
+// image's samples and adds the corners that fall into its block with LDS integer adds -- integer addition is
+// associative, so the result does not depend on the order the waves run in (bit-reproducible gradients) -- and
+// finally writes its pixels once (no zero-initialisation, no read-modify-write of HBM).
 #include "common.h"
 
 #define MSDA_MAX_LEVELS 8
@@ -21,7 +26,7 @@ struct MsdaShapes {
     int H[MSDA_MAX_LEVELS], W[MSDA_MAX_LEVELS], start[MSDA_MAX_LEVELS];
 };
 
-__global__ void msda_fwd_kernel(const float* __restrict__ value, const float* __restrict__ loc,
+__global__ __launch_bounds__(1024) void msda_fwd_kernel(const float* __restrict__ value, const float* __restrict__ loc,
                                 const float* __restrict__ attn, float* __restrict__ out, MsdaShapes sh, int S, int Lq,
                                 int M, int D, int P) {
     const long nq = blockIdx.x;                  // n * Lq + q
@@ -58,9 +63,9 @@ __device__ __forceinline__ float head_sum(float v, int D) {   // sum over the D 
     return v;
 }
 
-__global__ void msda_bwd_kernel(const float* __restrict__ value, const float* __restrict__ loc,
+__global__ __launch_bounds__(1024) void msda_bwd_kernel(const float* __restrict__ value, const float* __restrict__ loc,
                                 const float* __restrict__ attn, const float* __restrict__ gout,
-                                float* __restrict__ gvalue, float* __restrict__ gloc, float* __restrict__ gattn,
+                                float* __restrict__ gloc, float* __restrict__ gattn,
                                 MsdaShapes sh, int S, int Lq, int M, int D, int P) {
     const long nq = blockIdx.x;
     const int n = nq / Lq;
@@ -85,22 +90,18 @@ __global__ void msda_bwd_kernel(const float* __restrict__ value, const float* __
                 if (y0 >= 0 && x0 >= 0) {
                     const long o = lvl + ((long)y0 * W + x0) * M * D;
                     v00 = value[o];
-                    atomicAdd(gvalue + o, gw * hy * hx);
                 }
                 if (y0 >= 0 && x0 + 1 < W) {
                     const long o = lvl + ((long)y0 * W + x0 + 1) * M * D;
                     v01 = value[o];
-                    atomicAdd(gvalue + o, gw * hy * lx);
                 }
                 if (y0 + 1 < H && x0 >= 0) {
                     const long o = lvl + ((long)(y0 + 1) * W + x0) * M * D;
                     v10 = value[o];
-                    atomicAdd(gvalue + o, gw * ly * hx);
                 }
                 if (y0 + 1 < H && x0 + 1 < W) {
                     const long o = lvl + ((long)(y0 + 1) * W + x0 + 1) * M * D;
                     v11 = value[o];
-                    atomicAdd(gvalue + o, gw * ly * lx);
                 }
                 ga = go * (hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11));
                 gx = gw * W * (hy * (v01 - v00) + ly * (v11 - v10));     // d/dloc_x (pixel x = loc_x*W - 0.5)
@@ -113,6 +114,91 @@ __global__ void msda_bwd_kernel(const float* __restrict__ value, const float* __
                 gattn[(nq * M + m) * sh.n_levels * P + l * P + p] = ga;
             }
         }
+    }
+}
+
+// max |gout| as the bit pattern of a non-negative float (unsigned compare == float compare); *gmax zeroed by the caller
+__global__ __launch_bounds__(256) void msda_absmax_kernel(const float* __restrict__ g, unsigned int* __restrict__ gmax, long n) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(g[i]));
+    __shared__ float red[16];
+    m = block_max(m, red);
+    if (threadIdx.x == 0) atomicMax(gmax, __float_as_uint(m));
+}
+
+// grid (pixel blocks over all levels, M, N); 1024 threads = (1024 / D) sample slots x D channels (16 waves per CU:
+// the block owns the CU's LDS, so its own waves have to hide the latency of the sample loads).
+// LDS: RB x D accumulators of 2 x 32 bit, RB = pixels per block.
+#define MSDA_VT 1024
+__global__ __launch_bounds__(MSDA_VT) void msda_bwd_value_kernel(const float* __restrict__ loc, const float* __restrict__ attn,
+                                                              const float* __restrict__ gout, const unsigned int* __restrict__ gmax,
+                                                              float* __restrict__ gvalue, MsdaShapes sh, int S, int Lq, int M,
+                                                              int D, int P, int RB) {
+    // Fixed point v = round(g * 2^30 / max|gout|) (|v| <= 2^30), accumulated as two 32-bit halves v = hi * 4096 + lo with
+    // lo in [0, 4096): 32-bit LDS adds (the 64-bit LDS add measured ~20x slower); lo cannot overflow below 2^20 terms,
+    // hi (|hi| <= 2^18) below 2^13 terms per element -- far above the number of samples that can land on one pixel.
+    extern __shared__ unsigned int acc32[];          // [RB*D] lo | [RB*D] hi
+    const int m = blockIdx.y, n = blockIdx.z;
+    // which level / pixel range this block owns
+    int l = 0, blk = blockIdx.x;
+    for (; l < sh.n_levels; ++l) {
+        const int nb = (sh.H[l] * sh.W[l] + RB - 1) / RB;
+        if (blk < nb) break;
+        blk -= nb;
+    }
+    const int H = sh.H[l], W = sh.W[l];
+    const int p0 = blk * RB, p1 = min(p0 + RB, H * W);
+    unsigned int* acc_lo = acc32;
+    int* acc_hi = reinterpret_cast<int*>(acc32 + RB * D);
+    for (int i = threadIdx.x; i < (p1 - p0) * D; i += MSDA_VT) { acc_lo[i] = 0u; acc_hi[i] = 0; }
+    __syncthreads();
+    const float gm = __uint_as_float(*gmax);
+    const float scale = gm > 0.f ? 1073741824.0f / gm : 0.f;          // 2^30 / max|gout|
+    const int slots = MSDA_VT / D, slot = threadIdx.x / D, d = threadIdx.x - slot * D;
+    const long nsamp = (long)Lq * P;
+    // rows of the block's pixel range: a sample can only contribute if its 2x2 footprint touches them
+    const int ylo = p0 / W - 1, yhi = (p1 - 1) / W;
+    for (long e0 = slot; e0 < nsamp; e0 += 2L * slots) {
+        float sx[2], sy[2], sg[2];
+        bool live[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                  // both samples' loads are in flight before either is used
+            const long e = e0 + (long)u * slots;
+            live[u] = e < nsamp;
+            const long ee = live[u] ? e : e0;
+            const int q = (int)(ee / P), p = (int)(ee - (long)q * P);
+            const long qm = ((long)n * Lq + q) * M + m;
+            const float* lb = loc + (qm * sh.n_levels + l) * P * 2 + p * 2;
+            sx[u] = lb[0] * W - 0.5f;
+            sy[u] = lb[1] * H - 0.5f;
+            const int yy = (int)floorf(sy[u]);
+            live[u] = live[u] && sy[u] > -1.f && sx[u] > -1.f && sy[u] < H && sx[u] < W && yy >= ylo && yy <= yhi;
+            sg[u] = live[u] ? gout[qm * D + d] * attn[(qm * sh.n_levels + l) * P + p] * scale : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!live[u]) continue;
+            const int y0 = (int)floorf(sy[u]), x0 = (int)floorf(sx[u]);
+            const float ly = sy[u] - y0, lx = sx[u] - x0, hy = 1.f - ly, hx = 1.f - lx;
+            const int px[4] = {x0, x0 + 1, x0, x0 + 1}, py[4] = {y0, y0, y0 + 1, y0 + 1};
+            const float cw[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (px[c] < 0 || px[c] >= W || py[c] < 0 || py[c] >= H) continue;
+                const int pix = py[c] * W + px[c];
+                if (pix < p0 || pix >= p1) continue;
+                const int v = (int)rintf(sg[u] * cw[c]);
+                atomicAdd(&acc_lo[(pix - p0) * D + d], (unsigned int)(v & 4095));
+                atomicAdd(&acc_hi[(pix - p0) * D + d], v >> 12);           // arithmetic shift: v = (v >> 12) * 4096 + (v & 4095)
+            }
+        }
+    }
+    __syncthreads();
+    const float inv = gm > 0.f ? gm / 1073741824.0f : 0.f;
+    for (int i = threadIdx.x; i < (p1 - p0) * D; i += MSDA_VT) {
+        const int pix = p0 + i / D, dd = i - (i / D) * D;
+        const long long tot = (long long)acc_hi[i] * 4096 + (long long)acc_lo[i];
+        gvalue[(((long)n * S + sh.start[l] + pix) * M + m) * D + dd] = (float)tot * inv;
     }
 }
 
@@ -145,19 +231,37 @@ extern "C" int wc_msda_fwd(const float* value, const int* h_shapes, int n_levels
     return WC_OK;
 }
 
-// gvalue must be zero-initialised by the caller (it is accumulated with atomics).
+// gvalue needs no initialisation (every element is written exactly once); gmax: 1 x u32 workspace.
 extern "C" int wc_msda_bwd(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
-                           const float* gout, float* gvalue, float* gloc, float* gattn, int N, int Lq, int M, int D,
-                           int P, void* stream) {
+                           const float* gout, float* gvalue, float* gloc, float* gattn, void* gmax, int N, int Lq, int M,
+                           int D, int P, void* stream) {
     MsdaShapes sh;
     int S = 0;
-    WC_CHECK_ARG(value && h_shapes && loc && attn && gout && gvalue && gloc && gattn && N > 0 && Lq > 0 && M > 0 && P > 0,
+    WC_CHECK_ARG(value && h_shapes && loc && attn && gout && gvalue && gloc && gattn && gmax && N > 0 && Lq > 0 && M > 0 && P > 0,
                  "wc_msda_bwd: bad argument");
     WC_CHECK_ARG(fill_shapes(&sh, h_shapes, n_levels, &S) == 0, "wc_msda_bwd: 1..8 levels with positive sizes");
-    WC_CHECK_ARG((D == 16 || D == 32 || D == 64) && M * D <= 1024 && (M * D) % 64 == 0,
+    WC_CHECK_ARG((D == 16 || D == 32 || D == 64) && M * D <= 1024 && (M * D) % 64 == 0 && M <= 65535 && N <= 65535,
                  "wc_msda_bwd: head dim 16/32/64, heads*dim a multiple of 64 and <= 1024");
-    hipLaunchKernelGGL(msda_bwd_kernel, dim3((unsigned)((long)N * Lq)), dim3(M * D), 0, (hipStream_t)stream, value, loc, attn,
-                       gout, gvalue, gloc, gattn, sh, S, Lq, M, D, P);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(msda_bwd_kernel, dim3((unsigned)((long)N * Lq)), dim3(M * D), 0, st, value, loc, attn, gout, gloc, gattn,
+                       sh, S, Lq, M, D, P);
     WC_LAUNCH_CHECK("msda_bwd_kernel");
+    hipMemsetAsync(gmax, 0, sizeof(unsigned int), st);
+    const long ng = (long)N * Lq * M * D;
+    hipLaunchKernelGGL(msda_absmax_kernel, dim3((unsigned)(ng / 256 / 8 + 1 > 512 ? 512 : ng / 256 / 8 + 1)), dim3(256), 0, st, gout,
+                       (unsigned int*)gmax, ng);
+    WC_LAUNCH_CHECK("msda_absmax_kernel");
+    const int RB = 16384 / D;                       // 128 KiB of 64-bit accumulators per workgroup
+    int nblk = 0;
+    for (int l = 0; l < n_levels; ++l) nblk += wc_cdiv(sh.H[l] * sh.W[l], RB);
+    static bool attr_set = false;
+    if (!attr_set) {
+        WC_CHECK_ARG(hipFuncSetAttribute((const void*)msda_bwd_value_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess,
+                     "wc_msda_bwd: cannot reserve 128 KiB of LDS");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(msda_bwd_value_kernel, dim3(nblk, M, N), dim3(MSDA_VT), (size_t)RB * D * 8, st, loc, attn, gout,
+                       (const unsigned int*)gmax, gvalue, sh, S, Lq, M, D, P, RB);
+    WC_LAUNCH_CHECK("msda_bwd_value_kernel");
     return WC_OK;
 }
