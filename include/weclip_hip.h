@@ -275,6 +275,18 @@ int wc_aff_seg_weights(const float* const* h_maps, int nmaps, const float* seg, 
                        int B, int L, void* stream);
 int wc_matvec(const float* W, const float* X, const float* sin, const float* sout, const float* add,
               float* out, int B, int hw, int K, int transpose, int recip, float alpha, void* stream);
+/* Fused forms for hw %% 4 == 0 (wc_aff_fused_supported): a workgroup owns 32 complete rows of W, so one read of W serves a
+ * Sinkhorn row pass AND the next column pass, or both halves of T_sym X; W is read 5 times per batch instead of 10.
+ * wc_aff_weight_c1:     W as wc_aff_weight + c1 = 1 / colsum(W).                ws: B*ceil(hw/8)*hw f32
+ * wc_aff_sinkhorn_step: r = 1/(W c); unless last: c_next = 1/(W^T r).            ws: B*ceil(hw/32)*hw f32
+ * wc_aff_tsym_apply:    out (B,hw,K) = T_sym X, K <= 4.  y1: B*hw*K f32; ws: B*ceil(hw/32)*hw*K f32. */
+int wc_aff_fused_supported(int hw);
+int wc_aff_weight_c1(const float* const* h_maps, int nmaps, const float* wgt, const float* seg, float* W, float* c1,
+                     float* ws, int B, int L, void* stream);
+int wc_aff_sinkhorn_step(const float* W, const float* c, float* r, float* c_next, float* ws, int B, int hw, int last,
+                         void* stream);
+int wc_aff_tsym_apply(const float* W, const float* r, const float* c, const float* X, float* out, float* y1, float* ws,
+                      int B, int hw, int K, void* stream);
 int wc_tsym(const float* W, const float* r, const float* c, float* T, int B, int hw, void* stream);
 int wc_box_mask(const float* cam, const int* pair_img, const int* pair_slot, float* V, float* mask_out,
                 int* boxes, int* nbox, int maxbox, int P, int h, int w, int K, double thr, void* stream);

@@ -109,3 +109,41 @@ def test_sinkhorn_properties_full_size(P):
     Y = P.tsym_apply(W, r, c, X)
     Ts = 0.5 * (T + T.transpose(1, 2))
     assert (Y - Ts @ X).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("h,w,K,seg_trans", [(6, 8, 2, False), (4, 12, 5, True), (32, 40, 3, False)])
+def test_fused_sweeps_vs_oracle(P, h, w, K, seg_trans):
+    """hw % 4 == 0 takes the fused sweeps (aff_weight + first column scale, Sinkhorn row+column passes in one read of W,
+    both halves of T_sym X in one read; K > 4 classes in chunks of 4): W, the scale vectors and T_sym^2 V vs the oracle."""
+    B = 3
+    L = h * w + 1
+    assert P.fused_ok(h * w)
+    maps = _maps(B, L, n=12, seed=h + w)
+    g = torch.Generator().manual_seed(h * w)
+    seg = torch.sigmoid(torch.randn(B, L - 1, L - 1, generator=g))
+    Wd, c1 = P.affinity_weight([m.cuda() for m in maps], seg.cuda(), seg_trans, 6, return_c1=True)
+    assert c1 is not None
+    V = torch.rand(B, h * w, K, generator=g)
+    r, c = P.sinkhorn_scales(Wd, c1=c1)
+    Y = P.tsym_apply(Wd, r, c, P.tsym_apply(Wd, r, c, V.cuda())).cpu()
+    for b in range(B):
+        Wo = O.affinity_weight(torch.stack([m[b] for m in maps]), seg[b], seg_trans, 6)
+        np.testing.assert_allclose(Wd[b].cpu().numpy(), Wo.numpy(), rtol=2e-5, atol=1e-8)
+        T = O.compute_trans_mat(Wo)                    # = T_sym @ T_sym
+        np.testing.assert_allclose(Y[b].numpy(), (T @ V[b]).numpy(), rtol=2e-4, atol=1e-7)
+
+
+def test_fused_and_unfused_paths_agree_at_full_size(P, monkeypatch):
+    B, L = 2, 1025
+    maps = [m.cuda() for m in _maps(B, L, n=12, seed=4)]
+    X = torch.rand(B, L - 1, 2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    W, c1 = P.affinity_weight(maps, return_c1=True)
+    r, c = P.sinkhorn_scales(W, c1=c1)
+    Y = P.tsym_apply(W, r, c, X)
+    monkeypatch.setattr(P, "fused_ok", lambda hw: False)
+    W2 = P.affinity_weight(maps)
+    r2, c2 = P.sinkhorn_scales(W2)
+    Y2 = P.tsym_apply(W2, r2, c2, X)
+    assert torch.equal(W, W2)
+    assert ((r - r2).abs() / r2.abs()).max().item() < 1e-5 and ((c - c2).abs() / c2.abs()).max().item() < 1e-5
+    assert (Y - Y2).abs().max().item() < 1e-6 * max(Y2.abs().max().item(), 1.0) + 1e-7

@@ -74,7 +74,7 @@ def test_cam_chain_at_512_matches_reference(golden, bench_model, seg_trans, prec
             keep[i] = torch.from_numpy(ref_keep.astype(np.float32)).to(keep.device)
             del xs0, maps0, st0
             orig_aw = CP.affinity_weight
-            monkeypatch.setattr(CP, "affinity_weight", lambda *a, **k: orig_aw(*a, **{**k, "keep": keep}))
+            monkeypatch.setattr(CP, "affinity_weight", lambda *a, **k: orig_aw(*a, **{**k, "keep": keep}))      # (keeps return_c1)
         seg, cam_labels, ap = m(img, [""] * B, labels=labels)
         # the same stages once more through the package's stage functions, to look at the intermediates
         xs, maps, _, Lq = m.encode(img, seg_trans)

@@ -33,7 +33,16 @@ def seg_layer_keep(maps, n_last=6):
     return (wgt > 0).float()
 
 
-def affinity_weight(maps, seg=None, seg_trans=False, n_last=6, keep=None):
+def fused_ok(hw):
+    """The fused sweeps of csrc/affinity.hip need 16-byte row pieces (hw % 4 == 0) and hw <= 2048."""
+    return hw % 4 == 0 and 4 <= hw <= 2048
+
+
+def _nblk(hw):
+    return (hw + 31) // 32
+
+
+def affinity_weight(maps, seg=None, seg_trans=False, n_last=6, keep=None, return_c1=False):
     """maps: list of head-mean attention maps (B,L,L) f32 in layer order (11 encoder + last block).
     Normal branch (clip_tool.py:169-173): mean of the last 8 [1:,1:].  Seg-trans branch
     (:152-168, n_last 6 VOC / 10 COCO): masked mean of the last n_last times seg (B,hw,hw).
@@ -46,10 +55,21 @@ def affinity_weight(maps, seg=None, seg_trans=False, n_last=6, keep=None):
         L.ptr(m, F32, "attention map")
     lib = L.lib()
     W = torch.empty(B, hw, hw, device=dev, dtype=F32)
+
+    def weight(wgt, segp):
+        """W (and, on the fused path, the first Sinkhorn column scale c1 = 1 / colsum(W) from the same pass)."""
+        if return_c1 and fused_ok(hw):
+            c1 = torch.empty(B, hw, device=dev, dtype=F32)
+            ws = torch.empty(B * ((hw + 7) // 8) * hw, device=dev, dtype=F32)
+            lib.wc_aff_weight_c1(_map_array(sel), len(sel), L.ptr(wgt), L.ptr(segp), L.ptr(W), L.ptr(c1), L.ptr(ws), B, Lq,
+                                 L.stream())
+            return W, c1
+        lib.wc_aff_weight(_map_array(sel), len(sel), L.ptr(wgt), L.ptr(segp), L.ptr(W), B, Lq, L.stream())
+        return (W, None) if return_c1 else W
+
     if not seg_trans:
         wgt = torch.full((B, len(sel)), 1.0 / len(sel), device=dev, dtype=F32)
-        lib.wc_aff_weight(_map_array(sel), len(sel), L.ptr(wgt), None, L.ptr(W), B, Lq, L.stream())
-        return W
+        return weight(wgt, None)
     seg = seg.detach().float().contiguous()
     if keep is not None:
         keep = keep.to(dev).float()
@@ -59,8 +79,7 @@ def affinity_weight(maps, seg=None, seg_trans=False, n_last=6, keep=None):
         wgt = torch.empty(B, len(sel), device=dev, dtype=F32)
         rowsum = torch.empty(B, len(sel), hw, device=dev, dtype=F32)
         lib.wc_aff_seg_weights(_map_array(sel), len(sel), L.ptr(rowsum), L.ptr(diff), L.ptr(wgt), B, Lq, L.stream())
-    lib.wc_aff_weight(_map_array(sel), len(sel), L.ptr(wgt), L.ptr(seg), L.ptr(W), B, Lq, L.stream())
-    return W
+    return weight(wgt, seg)
 
 
 def _matvec(W, X, sin=None, sout=None, add=None, transpose=False, recip=False, alpha=1.0):
@@ -72,10 +91,26 @@ def _matvec(W, X, sin=None, sout=None, add=None, transpose=False, recip=False, a
     return out
 
 
-def sinkhorn_scales(W, rounds=3):
+def sinkhorn_scales(W, rounds=3, c1=None):
     """Row/column scale vectors of the 3x (col-normalise, row-normalise) of compute_trans_mat
-    (clip_tool.py:67-72): T = diag(r) W diag(c)."""
+    (clip_tool.py:67-72): T = diag(r) W diag(c).  hw % 4 == 0: fused sweeps (a row pass and the next column pass
+    share one read of W; `c1`, if given, is the first column scale that affinity_weight already produced)."""
     B, hw, _ = W.shape
+    if fused_ok(hw):
+        lib = L.lib()
+        ws = torch.empty(B * _nblk(hw) * hw, device=W.device, dtype=F32)
+        if c1 is None:
+            c1 = _matvec(W, torch.ones(B, hw, 1, device=W.device, dtype=F32), transpose=True, recip=True).view(B, hw)
+        c = c1
+        for it in range(rounds):
+            r = torch.empty(B, hw, device=W.device, dtype=F32)
+            last = it == rounds - 1
+            cn = None if last else torch.empty(B, hw, device=W.device, dtype=F32)
+            lib.wc_aff_sinkhorn_step(L.ptr(W, F32), L.ptr(c, F32), L.ptr(r), L.ptr(cn), L.ptr(ws), B, hw, 1 if last else 0,
+                                     L.stream())
+            if not last:
+                c = cn
+        return r, c
     r = torch.ones(B, hw, 1, device=W.device, dtype=F32)
     c = None
     for _ in range(rounds):
@@ -86,6 +121,21 @@ def sinkhorn_scales(W, rounds=3):
 
 def tsym_apply(W, r, c, X):
     """T_sym X with T_sym = (diag(r) W diag(c) + diag(c) W^T diag(r)) / 2  (clip_tool.py:73)."""
+    B, hw, _ = W.shape
+    K = X.shape[-1]
+    if fused_ok(hw):
+        out = torch.empty(B, hw, K, device=W.device, dtype=F32)
+        for k0 in range(0, K, 4):              # 4 classes per sweep
+            kn = min(4, K - k0)
+            Xs = X if (k0 == 0 and kn == K) else X[:, :, k0:k0 + kn].contiguous()
+            os_ = out if (k0 == 0 and kn == K) else torch.empty(B, hw, kn, device=W.device, dtype=F32)
+            y1 = torch.empty(B, hw, kn, device=W.device, dtype=F32)
+            ws = torch.empty(B * _nblk(hw) * hw * kn, device=W.device, dtype=F32)
+            L.lib().wc_aff_tsym_apply(L.ptr(W, F32), L.ptr(r.contiguous(), F32), L.ptr(c.contiguous(), F32), L.ptr(Xs, F32),
+                                      L.ptr(os_), L.ptr(y1), L.ptr(ws), B, hw, kn, L.stream())
+            if os_ is not out:
+                out[:, :, k0:k0 + kn] = os_
+        return out
     half = _matvec(W, X, sin=c, sout=r, alpha=0.5)
     return _matvec(W, X, sin=r, sout=c, add=half, transpose=True, alpha=0.5)
 
@@ -116,10 +166,10 @@ def box_masks(cams, pair_img, pair_slot, B, K, h, w, thr, want_mask=False, want_
     return V, mask, boxes, nbox
 
 
-def refine(W, cams, pair_img, pair_slot, K, h, w, thr):
+def refine(W, cams, pair_img, pair_slot, K, h, w, thr, c1=None):
     """R (B, hw, K) = T_sym^2 (boxmask * cam) for every pair (clip_tool.py:179-191)."""
     B = W.shape[0]
-    r, c = sinkhorn_scales(W)
+    r, c = sinkhorn_scales(W, c1=c1)
     V, _, _, _ = box_masks(cams, pair_img, pair_slot, B, K, h, w, thr)
     return tsym_apply(W, r, c, tsym_apply(W, r, c, V))
 

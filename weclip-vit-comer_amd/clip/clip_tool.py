@@ -143,8 +143,8 @@ def batch_refined_cams(clip_model, last_rows, maps11, seg_attn, plan, text_hat, 
     need = maps[-n_last:] if seg_trans else maps[-8:]
     if any(m is None for m in need):
         raise RuntimeError("attention maps needed by the affinity were not computed")
-    W = CP.affinity_weight(maps, seg_attn, seg_trans, n_last, keep=keep)
-    R = CP.refine(W, cams, plan.pair_img, plan.pair_slot, plan.K, h, w, thr)
+    W, c1 = CP.affinity_weight(maps, seg_attn, seg_trans, n_last, keep=keep, return_c1=True)
+    R = CP.refine(W, cams, plan.pair_img, plan.pair_slot, plan.K, h, w, thr, c1=c1)
     return R, cams, probs, st
 
 

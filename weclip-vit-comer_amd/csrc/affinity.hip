@@ -190,6 +190,167 @@ __global__ __launch_bounds__(256) void matvec_rows_kernel(const float* __restric
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused sweeps (hw % 4 == 0): a workgroup owns AF_RPB complete rows of one image's W, so ONE read of those rows serves
+// a row pass and the following column pass of the Sinkhorn iteration -- r_i = 1 / sum_j W_ij c_j, then the column partial
+// sum_{i in block} W_ij r_i with the rows still in registers -- and both halves of T_sym X (the row product and the
+// transposed product).  Column partials (one per workgroup) are combined by aff_colreduce_kernel in a fixed order.
+// W is read 5 times per batch instead of 10 (1 x with aff_weight's own column partial, 3 x Sinkhorn, 2 x T_sym) and in
+// 16-byte pieces; with 16 images it (67 MB) stays in the 256 MiB Infinity Cache across the sweeps.
+#define AF_RPB 32          // rows per workgroup of the sweeps
+#define AF_RPBW 8          // rows per workgroup of aff_weight_colpart_kernel (it streams 8-12 maps: more workgroups in flight)
+#define AF_RG 4            // rows whose loads are in flight together
+#define AF_MAXCH 2         // column chunks of 1024 (hw <= 2048)
+
+// W rows + column partial of the FIRST Sinkhorn pass (r = 1):  colpart[(b*nblk + blk)*hw + j] = sum_{i in blk} W[b,i,j]
+__global__ __launch_bounds__(256) void aff_weight_colpart_kernel(MapPtrs maps, int nmaps, const float* __restrict__ wgt,
+                                                                  const float* __restrict__ seg, float* __restrict__ W,
+                                                                  float* __restrict__ colpart, int L) {
+    const int hw = L - 1, blk = blockIdx.x, b = blockIdx.y, nblk = gridDim.x;
+    const int i0 = blk * AF_RPBW, i1 = min(i0 + AF_RPBW, hw);
+    float wl[12];
+#pragma unroll
+    for (int l = 0; l < 12; ++l) wl[l] = l < nmaps ? wgt[b * nmaps + l] : 0.f;
+    for (int j = threadIdx.x; j < hw; j += 256) {
+        float cs = 0.f;
+        for (int i = i0; i < i1; ++i) {
+            const long src = (long)b * L * L + (long)(i + 1) * L + (j + 1);
+            float v[12];
+#pragma unroll
+            for (int l = 0; l < 12; ++l) v[l] = l < nmaps ? maps.p[l][src] : 0.f;
+            float sacc = 0.f;
+#pragma unroll
+            for (int l = 0; l < 12; ++l)
+                if (l < nmaps) sacc = fmaf(wl[l], v[l], sacc);
+            const long dst = ((long)b * hw + i) * hw + j;
+            if (seg) sacc *= seg[dst];
+            W[dst] = sacc;
+            cs += sacc;
+        }
+        colpart[((long)b * nblk + blk) * hw + j] = cs;
+    }
+}
+
+// MODE 0: r = 1 / (W c) and colpart = sum_i W_ij r_i      (one Sinkhorn row pass + the next column pass)
+// MODE 1: r = 1 / (W c) only                              (the last row pass)
+// MODE 2: y1[i,k] = r_i sum_j W_ij c_j X[j,k];  colpart[blk][j,k] = sum_i W_ij r_i X[i,k]      (both halves of T_sym X)
+template <int MODE, int K>
+__global__ __launch_bounds__(256) void aff_sweep_kernel(const float* __restrict__ W, const float* __restrict__ c,
+                                                         const float* __restrict__ rin, const float* __restrict__ X,
+                                                         float* __restrict__ rout, float* __restrict__ y1,
+                                                         float* __restrict__ colpart, int hw) {
+    __shared__ float red[2][4][AF_RG][K];
+    const int blk = blockIdx.x, b = blockIdx.y, nblk = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blk * AF_RPB, i1 = min(i0 + AF_RPB, hw);
+    const float* Wb = W + (long)b * hw * hw;
+    const float* cb = c + (long)b * hw;
+    const int nch = (hw + 1023) / 1024;
+    // this thread's columns: 4 per chunk
+    float cx[AF_MAXCH][4][K];          // c_j (MODE 0/1)  or  c_j * X[j,k] (MODE 2)
+    float ca[AF_MAXCH][4][K];          // column accumulators
+    bool okc[AF_MAXCH];
+#pragma unroll
+    for (int ch = 0; ch < AF_MAXCH; ++ch) {
+        const int j = ch * 1024 + tid * 4;
+        okc[ch] = ch < nch && j < hw;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                ca[ch][q][k] = 0.f;
+                float v = 0.f;
+                if (okc[ch]) {
+                    v = cb[j + q];
+                    if (MODE == 2) v *= X[((long)b * hw + j + q) * K + k];
+                }
+                cx[ch][q][k] = v;
+            }
+    }
+    int buf = 0;
+    for (int ig = i0; ig < i1; ig += AF_RG, buf ^= 1) {
+        float4 w[AF_RG][AF_MAXCH];
+#pragma unroll
+        for (int r = 0; r < AF_RG; ++r)
+#pragma unroll
+            for (int ch = 0; ch < AF_MAXCH; ++ch) {
+                w[r][ch] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (okc[ch] && ig + r < i1) w[r][ch] = *reinterpret_cast<const float4*>(Wb + (long)(ig + r) * hw + ch * 1024 + tid * 4);
+            }
+        float p[AF_RG][K];
+#pragma unroll
+        for (int r = 0; r < AF_RG; ++r)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float a = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < AF_MAXCH; ++ch)
+                    a += w[r][ch].x * cx[ch][0][k] + w[r][ch].y * cx[ch][1][k] + w[r][ch].z * cx[ch][2][k] + w[r][ch].w * cx[ch][3][k];
+                p[r][k] = wave_sum(a);
+            }
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < AF_RG; ++r)
+#pragma unroll
+                for (int k = 0; k < K; ++k) red[buf][wave][r][k] = p[r][k];
+        }
+        __syncthreads();               // (red is double buffered: one barrier per row group)
+#pragma unroll
+        for (int r = 0; r < AF_RG; ++r) {
+            const int i = ig + r;
+            if (i >= i1) continue;
+            float rv[K];               // MODE 0/1: r_i ; MODE 2: r_i * X[i,k]
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float dot = red[buf][0][r][k] + red[buf][1][r][k] + red[buf][2][r][k] + red[buf][3][r][k];
+                if (MODE == 2) {
+                    const float ri = rin[(long)b * hw + i];
+                    if (tid == 0) y1[((long)b * hw + i) * K + k] = ri * dot;
+                    rv[k] = ri * X[((long)b * hw + i) * K + k];
+                } else {
+                    rv[k] = 1.0f / dot;
+                    if (tid == 0) rout[(long)b * hw + i] = rv[k];
+                }
+            }
+            if (MODE != 1) {
+#pragma unroll
+                for (int ch = 0; ch < AF_MAXCH; ++ch)
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        ca[ch][0][k] = fmaf(w[r][ch].x, rv[k], ca[ch][0][k]);
+                        ca[ch][1][k] = fmaf(w[r][ch].y, rv[k], ca[ch][1][k]);
+                        ca[ch][2][k] = fmaf(w[r][ch].z, rv[k], ca[ch][2][k]);
+                        ca[ch][3][k] = fmaf(w[r][ch].w, rv[k], ca[ch][3][k]);
+                    }
+            }
+        }
+    }
+    if (MODE != 1) {
+#pragma unroll
+        for (int ch = 0; ch < AF_MAXCH; ++ch) {
+            if (!okc[ch]) continue;
+            const int j = ch * 1024 + tid * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int k = 0; k < K; ++k) colpart[(((long)b * nblk + blk) * hw + j + q) * K + k] = ca[ch][q][k];
+        }
+    }
+}
+
+// mode 0: out[b,j] = 1 / sum_blk colpart[b,blk,j]                                       (column scale of the Sinkhorn pass)
+// mode 1: out[b,j,k] = 0.5 * (y1[b,j,k] + c[b,j] * sum_blk colpart[b,blk,j,k])          (T_sym X)
+__global__ __launch_bounds__(256) void aff_colreduce_kernel(const float* __restrict__ colpart, const float* __restrict__ y1,
+                                                             const float* __restrict__ c, float* __restrict__ out, int hw,
+                                                             int K, int nblk, int mode) {
+    const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;       // e = j*K + k
+    if (e >= hw * K) return;
+    float s = 0.f;
+    for (int blk = 0; blk < nblk; ++blk) s += colpart[((long)b * nblk + blk) * hw * K + e];
+    if (mode == 0) out[(long)b * hw + e] = 1.0f / s;
+    else out[(long)b * hw * K + e] = 0.5f * (y1[(long)b * hw * K + e] + c[(long)b * hw + e / K] * s);
+}
+
 // T_sym[b,i,j] = (r_i W_ij c_j + c_i W_ji r_j) / 2   (materialised only for the public compute_trans_mat)
 __global__ __launch_bounds__(256) void tsym_kernel(const float* __restrict__ W, const float* __restrict__ r,
                                                     const float* __restrict__ c, float* __restrict__ T, int hw) {
@@ -387,6 +548,72 @@ extern "C" int wc_matvec(const float* W, const float* X, const float* sin, const
                                out, hw, K, k0, recip, alpha);
         WC_LAUNCH_CHECK("matvec kernel");
     }
+    return WC_OK;
+}
+
+static bool aff_fused_ok(int hw) { return hw % 4 == 0 && hw <= 1024 * AF_MAXCH && hw >= 4; }
+
+// Whether the fused sweeps apply to this token count (hw % 4 == 0: 16-byte row pieces); else use wc_aff_weight / wc_matvec.
+extern "C" int wc_aff_fused_supported(int hw) { return aff_fused_ok(hw) ? 1 : 0; }
+
+// W (B,hw,hw) as wc_aff_weight, plus the first Sinkhorn column scale c1 = 1 / colsum(W) (B,hw).
+// ws: B * ceil(hw/8) * hw floats.
+extern "C" int wc_aff_weight_c1(const float* const* h_maps, int nmaps, const float* wgt, const float* seg, float* W, float* c1,
+                                float* ws, int B, int L, void* stream) {
+    WC_CHECK_ARG(h_maps && nmaps >= 1 && nmaps <= 12 && wgt && W && c1 && ws && B > 0 && B <= 65535 && L > 1 && aff_fused_ok(L - 1),
+                 "wc_aff_weight_c1: bad argument");
+    MapPtrs mp;
+    for (int i = 0; i < 12; ++i) mp.p[i] = i < nmaps ? h_maps[i] : nullptr;
+    const int hw = L - 1, nblk = wc_cdiv(hw, AF_RPBW);
+    hipStream_t st = (hipStream_t)stream;
+    const int pr = wc_prof_begin(stream);
+    hipLaunchKernelGGL(aff_weight_colpart_kernel, dim3(nblk, B), dim3(256), 0, st, mp, nmaps, wgt, seg, W, ws, L);
+    wc_prof_end(pr, "aff_weight_colpart_kernel", (double)B * hw * hw * 4.0 * (nmaps + 1 + (seg ? 1 : 0)), stream);
+    WC_LAUNCH_CHECK("aff_weight_colpart_kernel");
+    hipLaunchKernelGGL(aff_colreduce_kernel, dim3(wc_cdiv(hw, 256), B), dim3(256), 0, st, ws, nullptr, nullptr, c1, hw, 1, nblk, 0);
+    WC_LAUNCH_CHECK("aff_colreduce_kernel");
+    return WC_OK;
+}
+
+// One fused Sinkhorn step: r = 1 / (W c) and, unless last, c_next = 1 / (W^T r).  ws as above.
+extern "C" int wc_aff_sinkhorn_step(const float* W, const float* c, float* r, float* c_next, float* ws, int B, int hw,
+                                    int last, void* stream) {
+    WC_CHECK_ARG(W && c && r && ws && (last || c_next) && B > 0 && B <= 65535 && aff_fused_ok(hw), "wc_aff_sinkhorn_step: bad argument");
+    const int nblk = wc_cdiv(hw, AF_RPB);
+    hipStream_t st = (hipStream_t)stream;
+    const int pr = wc_prof_begin(stream);
+    if (last) hipLaunchKernelGGL((aff_sweep_kernel<1, 1>), dim3(nblk, B), dim3(256), 0, st, W, c, nullptr, nullptr, r, nullptr, ws, hw);
+    else hipLaunchKernelGGL((aff_sweep_kernel<0, 1>), dim3(nblk, B), dim3(256), 0, st, W, c, nullptr, nullptr, r, nullptr, ws, hw);
+    // algorithmic bytes: a row pass (+ a column pass) over W
+    wc_prof_end(pr, "aff_sweep_kernel", (double)B * hw * hw * 4.0 * (last ? 1 : 2), stream);
+    WC_LAUNCH_CHECK("aff_sweep_kernel");
+    if (!last) {
+        hipLaunchKernelGGL(aff_colreduce_kernel, dim3(wc_cdiv(hw, 256), B), dim3(256), 0, st, ws, nullptr, nullptr, c_next, hw, 1, nblk, 0);
+        WC_LAUNCH_CHECK("aff_colreduce_kernel");
+    }
+    return WC_OK;
+}
+
+// out (B,hw,K) = T_sym X,  T_sym = (diag(r) W diag(c) + diag(c) W^T diag(r)) / 2, in ONE read of W.  K <= 4.
+// y1: workspace B*hw*K; ws: B * ceil(hw/32) * hw * K floats.
+extern "C" int wc_aff_tsym_apply(const float* W, const float* r, const float* c, const float* X, float* out, float* y1,
+                                 float* ws, int B, int hw, int K, void* stream) {
+    WC_CHECK_ARG(W && r && c && X && out && y1 && ws && out != X && B > 0 && B <= 65535 && K >= 1 && K <= 4 && aff_fused_ok(hw),
+                 "wc_aff_tsym_apply: bad argument (K <= 4)");
+    const int nblk = wc_cdiv(hw, AF_RPB);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(nblk, B);
+    const int pr = wc_prof_begin(stream);
+    switch (K) {
+        case 1: hipLaunchKernelGGL((aff_sweep_kernel<2, 1>), grid, dim3(256), 0, st, W, c, r, X, nullptr, y1, ws, hw); break;
+        case 2: hipLaunchKernelGGL((aff_sweep_kernel<2, 2>), grid, dim3(256), 0, st, W, c, r, X, nullptr, y1, ws, hw); break;
+        case 3: hipLaunchKernelGGL((aff_sweep_kernel<2, 3>), grid, dim3(256), 0, st, W, c, r, X, nullptr, y1, ws, hw); break;
+        default: hipLaunchKernelGGL((aff_sweep_kernel<2, 4>), grid, dim3(256), 0, st, W, c, r, X, nullptr, y1, ws, hw); break;
+    }
+    wc_prof_end(pr, "aff_sweep_kernel", (double)B * hw * hw * 4.0 * 2, stream);
+    WC_LAUNCH_CHECK("aff_sweep_kernel");
+    hipLaunchKernelGGL(aff_colreduce_kernel, dim3(wc_cdiv(hw * K, 256), B), dim3(256), 0, st, ws, y1, c, out, hw, K, nblk, 1);
+    WC_LAUNCH_CHECK("aff_colreduce_kernel");
     return WC_OK;
 }
 
