@@ -127,3 +127,33 @@ def test_training_step_is_deterministic_and_finite_at_512(seg_trans):
     assert all(map(lambda v: v == v and abs(v) < 1e4, l0))        # finite
     assert l0 == l1 and torch.equal(g0, g1)                       # no atomics / races anywhere in the step
     assert g0.abs().max().item() > 0
+
+
+def test_encoder_only_batch32_at_512_config1(vitb):
+    """BASELINE configs[1]: frozen ViT-B/16 encoder forward, batch 32 at 512x512 (65 x 9 ... 129 tile rows, the XCD remap
+    and a 1.08 GB map footprint that the B = 2 tests never reach).  Properties on the whole batch (finite tokens,
+    row-stochastic non-negative head-mean maps, batch independence: image i of the batch == image i run alone) and the
+    CPU oracle on one image of the batch."""
+    from oracle import weclip_oracle as O
+    B = 32
+    img = synth.make_images(B, 512, 512, seed=300)
+    fts, attns = vitb.encode_image(img.cuda(), 512, 512, require_all_fts=True)
+    assert len(fts) == 11 and tuple(fts[-1].shape) == (1025, B, 768) and len(attns) == 11
+    assert all(torch.isfinite(f).all().item() for f in fts)
+    for a in attns[-8:]:
+        assert tuple(a.shape) == (B, 1025, 1025) and a.min().item() >= 0
+        assert (a.sum(-1) - 1).abs().max().item() < 2e-3
+    i = 29                                               # an image deep in the batch (tile row 116 of 129)
+    f1, a1 = vitb.encode_image(img[i:i + 1].cuda(), 512, 512, require_all_fts=True)
+    assert torch.equal(f1[-1][:, 0], fts[-1][:, i]) and torch.equal(a1[-1][0], attns[-1][i])
+    last = fts[-1][:, i].float().cpu()
+    map10 = attns[10][i].float().cpu()
+    del fts, attns, f1, a1
+    torch.cuda.empty_cache()
+    sd = synth.make_clip_state_dict(seed=0, with_text=False)
+    with torch.no_grad():
+        xs, maps = O.encode_image(img[i:i + 1], sd, 12)
+    e_tok = ((last - xs[-1][:, 0]).abs().max() / xs[-1].abs().max()).item()
+    e_map = ((map10 - maps[10][0]).abs().max() / maps[10].abs().max()).item()
+    print(f"B=32 512^2 encoder, image {i} vs oracle: tokens rel {e_tok:.2e}, layer-11 head-mean map rel {e_map:.2e}")
+    assert e_tok < 1e-3 and e_map < 1e-3          # measured at B = 16 against the reference fixture: 3.0e-4 / 2.7e-4

@@ -212,20 +212,37 @@ __global__ __launch_bounds__(256) void aff_weight_colpart_kernel(MapPtrs maps, i
 #pragma unroll
     for (int l = 0; l < 12; ++l) wl[l] = l < nmaps ? wgt[b * nmaps + l] : 0.f;
     for (int j = threadIdx.x; j < hw; j += 256) {
+        // all AF_RPBW rows of this column together, two maps per trip: 16 independent 4-byte loads in flight per lane
+        float sacc[AF_RPBW];
+#pragma unroll
+        for (int r = 0; r < AF_RPBW; ++r) sacc[r] = 0.f;
+        const long base = (long)b * L * L + (long)(i0 + 1) * L + (j + 1);
+#pragma unroll
+        for (int l = 0; l < 12; l += 2) {
+            if (l >= nmaps) break;
+            float v0[AF_RPBW], v1[AF_RPBW];
+            const bool two = l + 1 < nmaps;
+#pragma unroll
+            for (int r = 0; r < AF_RPBW; ++r) {
+                const long src = base + (long)(i0 + r < i1 ? r : 0) * L;
+                v0[r] = maps.p[l][src];
+                v1[r] = two ? maps.p[l + 1][src] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < AF_RPBW; ++r) {
+                sacc[r] = fmaf(wl[l], v0[r], sacc[r]);          // same order as aff_weight_kernel: l ascending
+                if (two) sacc[r] = fmaf(wl[l + 1], v1[r], sacc[r]);
+            }
+        }
         float cs = 0.f;
-        for (int i = i0; i < i1; ++i) {
-            const long src = (long)b * L * L + (long)(i + 1) * L + (j + 1);
-            float v[12];
 #pragma unroll
-            for (int l = 0; l < 12; ++l) v[l] = l < nmaps ? maps.p[l][src] : 0.f;
-            float sacc = 0.f;
-#pragma unroll
-            for (int l = 0; l < 12; ++l)
-                if (l < nmaps) sacc = fmaf(wl[l], v[l], sacc);
-            const long dst = ((long)b * hw + i) * hw + j;
-            if (seg) sacc *= seg[dst];
-            W[dst] = sacc;
-            cs += sacc;
+        for (int r = 0; r < AF_RPBW; ++r) {
+            if (i0 + r >= i1) break;
+            const long dst = ((long)b * hw + i0 + r) * hw + j;
+            float v = sacc[r];
+            if (seg) v *= seg[dst];
+            W[dst] = v;
+            cs += v;
         }
         colpart[((long)b * nblk + blk) * hw + j] = cs;
     }

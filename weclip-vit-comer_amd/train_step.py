@@ -152,7 +152,9 @@ class TrainStep:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             it = m.iter_num
-            with torch.cuda.graph(g, pool=self._pool):
+            # thread_local: other threads (RCCL's watchdog polling its events, the autograd workers allocating) must not
+            # abort the capture; the kernels the autograd workers launch on the capturing stream are captured all the same
+            with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
                 out = self._fwd_bwd(ent["img"], None, labels, plan=ent["plan"])
                 ent["out"] = torch.stack(out)
             m.iter_num = it                  # the capture ran forward()'s counter once without executing a step
