@@ -434,6 +434,16 @@ __global__ __launch_bounds__(256) void box_mask_kernel(const float* __restrict__
         if (changed) misc[1] = 1;
         __syncthreads();
         if (misc[1] == 0) break;
+        // pointer jumping: a label is also a pixel index, so lab[lab[i]] is a label of the same component that is at
+        // least as small -- the minimum then travels along whole chains per sweep (O(log diameter) sweeps instead of
+        // O(diameter)); racing reads only see other valid labels of the component, the fixed point is unchanged
+        for (int i = tid; i < hw; i += 256) {
+            const int l = lab[i];
+            if (l >= 0) {
+                const int ll = lab[l];
+                if (ll < l) lab[i] = ll;
+            }
+        }
         __syncthreads();
     }
     // labels may still be chains l -> lab[l] -> ... ; resolve to the root (fixed point lab[r] == r)

@@ -24,6 +24,7 @@
 // a lane owns one query (softmax statistics are lane-local) and then O^T = V^T P^T taking the
 // S^T accumulators as B operand directly (k order inside a 16-step: 8*(j>>2) + 4*(lane>>5) + (j&3)).
 #include "common.h"
+#include <stdlib.h>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -35,13 +36,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // The first `q_origin` query rows of every (b, h): one workgroup per row.  scores -> LDS, block max / sum,
 // P rounded to fp16 like the MFMA operand of the tiled kernel, O = P V with lanes along dh.
 // Runs as extra workgroups of attn_fwd_kernel (they fill CU slots as the tiled workgroups drain).
-// lds: >= (L + 16 + (256 / (DH / 8)) * DH) floats.
-template <int DH>
+// lds: >= (L + 16 + (NT / (DH / 8)) * DH) floats (NT = threads per workgroup).
+template <int DH, int NT>
 __device__ __forceinline__ void attn_row_body(const __half* __restrict__ qkv, __half* __restrict__ out,
                                               float* __restrict__ out32, float* __restrict__ lse, int L, int H,
                                               int E, int q, int h, int b, float* lds) {
     constexpr int NCH = DH / 8;              // 16-B chunks per row
-    constexpr int NPT = 256 / NCH;           // key slices in the P V pass
+    constexpr int NPT = NT / NCH;            // key slices in the P V pass
     float* sc = lds;                         // [L] scores, then probabilities
     float* red = lds + ((L + 3) & ~3);
     float (*part)[DH] = reinterpret_cast<float (*)[DH]>(red + 16);
@@ -52,7 +53,7 @@ __device__ __forceinline__ void attn_row_body(const __half* __restrict__ qkv, __
 #pragma unroll
     for (int c = 0; c < NCH; ++c) qv[c] = *reinterpret_cast<const f16x8*>(base + (long)q * ldq + c * 8);
     float mx = NEG_BIG;
-    for (int key = tid; key < L; key += 256) {
+    for (int key = tid; key < L; key += NT) {
         const __half* kr = base + E + (long)key * ldq;
         float s = 0.f;
 #pragma unroll
@@ -66,7 +67,7 @@ __device__ __forceinline__ void attn_row_body(const __half* __restrict__ qkv, __
     }
     mx = block_max(mx, red);
     float sum = 0.f;
-    for (int key = tid; key < L; key += 256) {
+    for (int key = tid; key < L; key += NT) {
         const float pr = __builtin_amdgcn_exp2f(sc[key] - mx);
         sum += pr;
         sc[key] = (float)(_Float16)pr;
@@ -111,19 +112,24 @@ __device__ __forceinline__ void attn_row_body(const __half* __restrict__ qkv, __
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int DH>
-__global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const __half* __restrict__ qkv,
+// NW waves per workgroup = NW * 32 queries per workgroup sharing one K/V stream: every K/V tile is staged once per
+// NW * 32 queries, so 8 waves (256 queries) halve the L2 -> LDS traffic of the 4-wave form (a (b, h) streams its
+// 2 x L x dh K/V bytes once per query block: 403 -> 202 MB per launch at B = 16, L = 1025), at the same waves per SIMD.
+template <int DH, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(const __half* __restrict__ qkv,
                                                         __half* __restrict__ out,
                                                         float* __restrict__ out32,
                                                         float* __restrict__ lse, int L, int H,
-                                                        int E, int q_origin, int nqb, int Bn) {
+                                                        int E, int q_origin, int nqb, int Bn, int k_origin) {
+    constexpr int NT = NW * 64;          // threads per workgroup
     constexpr int KS = DH / 16;          // k-steps of QK^T
     constexpr int DT = DH / 32;          // 32-row tiles of O^T
     constexpr int KROW = DH * 2 + 16;    // bytes per K row in LDS (padded)
     constexpr int VROW = DH * 2;         // bytes per V row in LDS ([key][dh], 16-B chunks XOR-swizzled)
     constexpr int KBUF = 64 * KROW, VBUF = 64 * VROW;
     constexpr int KCH = DH / 8;          // 16-B chunks per K row
-    constexpr int NKC = 64 * KCH / 256;  // K chunks per thread (2 for DH=64, 1 for DH=32)
+    constexpr int TCH = 64 * KCH;        // 16-B chunks of one K (or V) tile
+    constexpr int NKC = (TCH + NT - 1) / NT;   // K chunks per thread
     constexpr int NVC = NKC;             // V chunks per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][KBUF + VBUF]
 
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const __half* __restri
     if ((int)blockIdx.x >= main_blocks) {        // remainder rows [0, q_origin): one workgroup per (row, head, image)
         const int e = blockIdx.x - main_blocks;
         const int hb = e / q_origin;
-        attn_row_body<DH>(qkv, out, out32, lse, L, H, E, e - hb * q_origin, hb % H, hb / H, reinterpret_cast<float*>(smem));
+        attn_row_body<DH, NT>(qkv, out, out32, lse, L, H, E, e - hb * q_origin, hb % H, hb / H, reinterpret_cast<float*>(smem));
         return;
     }
     const int slot = blockIdx.x >> 3;
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const __half* __restri
     if (b >= Bn) return;
     const int rem = slot - (slot / per_img) * per_img;
     const int h = rem / nqb, qb = rem - h * nqb;
-    const int qrow = q_origin + qb * 128 + wave * 32 + l31;
+    const int qrow = q_origin + qb * (NW * 32) + wave * 32 + l31;
     const int qr = qrow < L ? qrow : L - 1;
     const long ldq = 3L * E;
     const __half* base = qkv + (long)b * L * ldq + (long)h * DH;
@@ -178,15 +184,15 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const __half* __restri
         const int t__ = (t_); \
         _Pragma("unroll") \
         for (int i = 0; i < NKC; ++i) { \
-            const int c = tid + 256 * i; \
-            int key = t__ * 64 + c / KCH; \
+            const int c = (tid + NT * i) % TCH;     /* (threads beyond the tile re-fetch a chunk they do not store) */ \
+            int key = k_origin + t__ * 64 + c / KCH; \
             if (key > L - 1) key = L - 1; \
             rk[i] = *reinterpret_cast<const u32x4*>(base + E + (long)key * ldq + (c % KCH) * 8); \
         } \
         _Pragma("unroll") \
         for (int i = 0; i < NVC; ++i) { \
-            const int c = tid + 256 * i; \
-            int key = t__ * 64 + c / KCH; \
+            const int c = (tid + NT * i) % TCH; \
+            int key = k_origin + t__ * 64 + c / KCH; \
             if (key > L - 1) key = L - 1; \
             rv[i] = *reinterpret_cast<const u32x4*>(base + 2 * E + (long)key * ldq + (c % KCH) * 8); \
         } \
@@ -199,14 +205,14 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const __half* __restri
         char* vb = kb + KBUF; \
         _Pragma("unroll") \
         for (int i = 0; i < NKC; ++i) { \
-            const int c = tid + 256 * i; \
-            *reinterpret_cast<u32x4*>(kb + (c / KCH) * KROW + (c % KCH) * 16) = rk[i]; \
+            const int c = tid + NT * i; \
+            if (c < TCH) *reinterpret_cast<u32x4*>(kb + (c / KCH) * KROW + (c % KCH) * 16) = rk[i]; \
         } \
         _Pragma("unroll") \
         for (int i = 0; i < NVC; ++i) { \
-            const int c = tid + 256 * i; \
+            const int c = tid + NT * i; \
             const int key__ = c / KCH; \
-            *reinterpret_cast<u32x4*>(vb + key__ * VROW + (((c % KCH) ^ VSWZ(key__)) << 4)) = rv[i]; \
+            if (c < TCH) *reinterpret_cast<u32x4*>(vb + key__ * VROW + (((c % KCH) ^ VSWZ(key__)) << 4)) = rv[i]; \
         } \
     }
 
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const __half* __restri
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m = NEG_BIG, lsum = 0.f;
 
-    const int nt = (L + 63) / 64;
+    const int nt = (L - k_origin + 63) / 64;     // keys [k_origin, L) in tiles of 64; keys [0, k_origin) are folded in below
     GLOAD(0);
     LSTORE(0);
     __syncthreads();
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const __half* __restri
             for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = t * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const int key = k_origin + t * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                     if (key >= L) s[ti][r] = NEG_BIG;
                 }
         }
@@ -295,6 +301,35 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const __half* __restri
         }
         if (t + 1 < nt) LSTORE(buf ^ 1);
         __syncthreads();
+    }
+    // The first k_origin keys (L % 64 <= ATT_EDGE_MAX: the CLS token of a 1 + 32*32 sequence must not cost a 17th K/V tile
+    // that holds one key): one online-softmax step per key on the VALU.  The lane pair (hh = 0, 1) of a query holds the
+    // two halves of every 16-wide k-step of q; o[d][r] is dh row d*32 + (r&3) + 8*(r>>2) + 4*hh of this lane's query.
+    for (int kx = 0; kx < k_origin; ++kx) {
+        const __half* krow = base + E + (long)kx * ldq;
+        float sdot = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 kv = *reinterpret_cast<const f16x8*>(krow + 16 * ks + 8 * hh);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sdot = fmaf((float)qf[ks][j], (float)kv[j], sdot);
+        }
+        sdot += __shfl_xor(sdot, 32, 64);
+        const float mn = fmaxf(m, sdot);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        const float pr = __builtin_amdgcn_exp2f(sdot - mn);
+        m = mn;
+        lsum = lsum * alpha + (hh == 0 ? pr : 0.f);          // the pair's partial sums are added once below
+        const float p16 = (float)(_Float16)pr;                 // P is an fp16 MFMA operand in the tiled path
+        const __half* vrow = base + 2 * E + (long)kx * ldq;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f16x4 vv = *reinterpret_cast<const f16x4*>(vrow + d * 32 + 8 * g + 4 * hh);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[d][g * 4 + k] = fmaf(p16, (float)vv[k], o[d][g * 4 + k] * alpha);
+            }
     }
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / ltot;
@@ -504,19 +539,28 @@ extern "C" int wc_attn_fwd(const void* qkv, void* out, float* out32, float* lse,
     WC_CHECK_ARG(E % 8 == 0 && B <= 65535 && H <= 65535 && (long)wc_cdiv(L, 128) * H * (B + 7) < (1L << 30),
                  "wc_attn_fwd: bad shape");
     const size_t lds = DH == 64 ? 2 * (64 * (64 * 2 + 16) + 64 * 128) : 2 * (64 * (32 * 2 + 16) + 64 * 64);
+    static const int nw_env = getenv("WECLIP_ATTN_NW") ? atoi(getenv("WECLIP_ATTN_NW")) : 0;
+    // 8 waves (256 queries per workgroup) when that still fills the chip; the small decoder / tiny cases keep 4
+    const int NWv = nw_env ? nw_env : ((DH == 64 && (long)wc_cdiv(L, 256) * H * B >= 512) ? 8 : 4);
+    const int nthr = NWv * 64;
     int r = attn_origin(L);
-    if (r && ((size_t)L + 4 + 16 + (256 / (DH / 8)) * DH) * 4 > lds) r = 0;     // row path needs its scores in LDS
-    const int nqb = wc_cdiv(L - r, 128);
+    if (r && ((size_t)L + 4 + 16 + (nthr / (DH / 8)) * DH) * 4 > lds) r = 0;     // row path needs its scores in LDS
+    const int kr = (L >= 64 && L % 64 > 0 && L % 64 <= ATT_EDGE_MAX) ? L % 64 : 0;   // keys handled outside the K/V tiles
+    const int nqb = wc_cdiv(L - r, NWv * 32);
     dim3 grid((unsigned)(nqb * H * ((B + 7) / 8 * 8) + r * H * B));
     hipStream_t st = (hipStream_t)stream;
     const int pr = wc_prof_begin(stream);
-    if (DH == 64)
-        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), lds, st, (const __half*)qkv, (__half*)out, out32, lse, L, H,
-                           E, r, nqb, B);
+    if (DH == 64 && NWv == 8)
+        hipLaunchKernelGGL((attn_fwd_kernel<64, 8>), grid, dim3(512), lds, st, (const __half*)qkv, (__half*)out, out32, lse, L, H,
+                           E, r, nqb, B, kr);
+    else if (DH == 64)
+        hipLaunchKernelGGL((attn_fwd_kernel<64, 4>), grid, dim3(256), lds, st, (const __half*)qkv, (__half*)out, out32, lse, L, H,
+                           E, r, nqb, B, kr);
     else
-        hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), lds, st, (const __half*)qkv, (__half*)out, out32, lse, L, H,
-                           E, r, nqb, B);
-    wc_prof_end(pr, DH == 64 ? "attn_fwd_kernel<64>" : "attn_fwd_kernel<32>", 4.0 * B * H * (double)L * L * DH, stream);
+        hipLaunchKernelGGL((attn_fwd_kernel<32, 4>), grid, dim3(256), lds, st, (const __half*)qkv, (__half*)out, out32, lse, L, H,
+                           E, r, nqb, B, kr);
+    wc_prof_end(pr, DH == 64 ? (NWv == 8 ? "attn_fwd_kernel<64, 8>" : "attn_fwd_kernel<64, 4>") : "attn_fwd_kernel<32, 4>",
+                4.0 * B * H * (double)L * L * DH, stream);
     WC_LAUNCH_CHECK("attn_fwd_kernel");
     return WC_OK;
 }
