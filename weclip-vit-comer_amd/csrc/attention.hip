@@ -184,14 +184,14 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(const __half* __re
         const int t__ = (t_); \
         _Pragma("unroll") \
         for (int i = 0; i < NKC; ++i) { \
-            const int c = (tid + NT * i) % TCH;     /* (threads beyond the tile re-fetch a chunk they do not store) */ \
+            const int c = (NKC * NT == TCH) ? tid + NT * i : (tid + NT * i) % TCH;   /* (threads beyond the tile re-fetch a chunk they do not store) */ \
             int key = k_origin + t__ * 64 + c / KCH; \
             if (key > L - 1) key = L - 1; \
             rk[i] = *reinterpret_cast<const u32x4*>(base + E + (long)key * ldq + (c % KCH) * 8); \
         } \
         _Pragma("unroll") \
         for (int i = 0; i < NVC; ++i) { \
-            const int c = (tid + NT * i) % TCH; \
+            const int c = (NKC * NT == TCH) ? tid + NT * i : (tid + NT * i) % TCH; \
             int key = k_origin + t__ * 64 + c / KCH; \
             if (key > L - 1) key = L - 1; \
             rv[i] = *reinterpret_cast<const u32x4*>(base + 2 * E + (long)key * ldq + (c % KCH) * 8); \
@@ -305,6 +305,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(const __half* __re
     // The first k_origin keys (L % 64 <= ATT_EDGE_MAX: the CLS token of a 1 + 32*32 sequence must not cost a 17th K/V tile
     // that holds one key): one online-softmax step per key on the VALU.  The lane pair (hh = 0, 1) of a query holds the
     // two halves of every 16-wide k-step of q; o[d][r] is dh row d*32 + (r&3) + 8*(r>>2) + 4*hh of this lane's query.
+    // (8-wave form only: in the 4-wave form, which stages twice as many K/V chunks per thread, the extra code spills)
+    if constexpr (NW == 8)
     for (int kx = 0; kx < k_origin; ++kx) {
         const __half* krow = base + E + (long)kx * ldq;
         float sdot = 0.f;
@@ -545,7 +547,7 @@ extern "C" int wc_attn_fwd(const void* qkv, void* out, float* out32, float* lse,
     const int nthr = NWv * 64;
     int r = attn_origin(L);
     if (r && ((size_t)L + 4 + 16 + (nthr / (DH / 8)) * DH) * 4 > lds) r = 0;     // row path needs its scores in LDS
-    const int kr = (L >= 64 && L % 64 > 0 && L % 64 <= ATT_EDGE_MAX) ? L % 64 : 0;   // keys handled outside the K/V tiles
+    const int kr = (NWv == 8 && L >= 64 && L % 64 > 0 && L % 64 <= ATT_EDGE_MAX) ? L % 64 : 0;   // keys handled outside the K/V tiles
     const int nqb = wc_cdiv(L - r, NWv * 32);
     dim3 grid((unsigned)(nqb * H * ((B + 7) / 8 * 8) + r * H * B));
     hipStream_t st = (hipStream_t)stream;
