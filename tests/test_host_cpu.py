@@ -98,3 +98,20 @@ def test_gradient_bucket_allreduce_gloo_world2():
     [p.join(120) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert ret.get(0) and ret.get(1)
+
+
+def test_pair_plan_update_refills_in_place():
+    """TrainStep's graph mode keeps ONE PairPlan per batch signature and refills its device tensors in place."""
+    from weclip_vit_comer_amd.clip.clip_tool import PairPlan
+    plan = PairPlan([[3, 7], [5, 9]], n_fg=20, n_bg=25, device="cpu")
+    ptrs = (plan.pair_img.data_ptr(), plan.text_idx.data_ptr(), plan.valid_key.data_ptr())
+    assert PairPlan.signature([[3, 7], [5, 9]]) == (2, 4, 2)
+    plan.update([[0, 1], [2, 19]])
+    assert (plan.pair_img.data_ptr(), plan.text_idx.data_ptr(), plan.valid_key.data_ptr()) == ptrs
+    assert plan.text_idx[2, :2].tolist() == [2, 19] and plan.valid_key.tolist() == [[0, 1, 2], [0, 3, 20]]
+    ref = PairPlan([[0, 1], [2, 19]], 20, 25, "cpu")
+    for a, b in ((plan.pair_img, ref.pair_img), (plan.pair_cls, ref.pair_cls), (plan.text_idx, ref.text_idx),
+                 (plan.n_text, ref.n_text), (plan.nk, ref.nk), (plan.nch, ref.nch), (plan.valid_key, ref.valid_key)):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        plan.update([[0], [2, 19, 4]])            # another signature (same pair count, other K) needs its own plan
