@@ -327,14 +327,15 @@ int wc_colscale_split(const float* x, const float* cs, float* out32, void* hi, v
  * value (N,S,M,D) f32, S = sum_l H_l*W_l (h_shapes: HOST array of n_levels (H,W) pairs);
  * loc (N,Lq,M,nL,P,2) f32 in [0,1] as (x,y); attn (N,Lq,M,nL,P) f32; out (N,Lq,M*D) f32:
  * out = sum_l sum_p attn * bilinear_zero_pad(value_l, loc*size - 0.5).
- * wc_msda_bwd: gvalue (every element written once: no initialisation needed), gloc, gattn.  grad_value is scattered
- *              in LDS as fixed point (scale 2^30 / max|gout|) with integer adds: no global float atomics, the
- *              result is independent of the execution order.  gmax: workspace of one uint32. */
+ * wc_msda_bwd: gvalue (every element written once: no initialisation needed), gloc, gattn.  grad_value is a bucketed
+ *              gather (count / scan / fill per pixel, then a per-pixel sum in 64-bit fixed point, scale 2^40 / max|gout|):
+ *              no float atomics anywhere, the result is independent of the execution order.  gmax: workspace of one
+ *              uint32; ws: workspace of N*M*S*2 + N*M*n_levels*Lq*P*4 int32; a level may have at most 16384 pixels. */
 int wc_msda_fwd(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
                 float* out, int N, int Lq, int M, int D, int P, void* stream);
 int wc_msda_bwd(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
-                const float* gout, float* gvalue, float* gloc, float* gattn, void* gmax, int N, int Lq, int M, int D,
-                int P, void* stream);
+                const float* gout, float* gvalue, float* gloc, float* gattn, void* gmax, void* ws, int N, int Lq, int M,
+                int D, int P, void* stream);
 
 /* Depth-wise conv2d (stride 1, zero "same" padding k/2, odd k <= 7) of the MRFP block of the ViT-CoMer inserts
  * (nn.Conv2d(C, C, k, padding=k//2, groups=C); no reference code).  x, y, dy, dx: (N, C, H, W) f32;

@@ -11,12 +11,9 @@
 // Layout: value (N, S, M, D) with S = sum_l H_l*W_l; one 64*k-thread block per query, thread = (head m,
 // channel d): the D channels of a sampled corner are D consecutive floats, so every gather is a
 // coalesced D*4-byte read.  Backward: the location / weight gradients are reduced across the D lanes of a head
-// (msda_bwd_kernel); grad_value is a scatter (many samples land on one pixel), done WITHOUT global float atomics:
-// msda_bwd_value_kernel gives every (image, head, block of <= 16384/D consecutive pixels of one level) to one
-// workgroup that keeps the block's gradient in LDS as fixed point (scale 2^30 / max|grad_out|, two 32-bit halves), scans the
-// image's samples and adds the corners that fall into its block with LDS integer adds -- integer addition is
-// associative, so the result does not depend on the order the waves run in (bit-reproducible gradients) -- and
-// finally writes its pixels once (no zero-initialisation, no read-modify-write of HBM).
+// (msda_bwd_kernel); grad_value is a scatter (many samples land on one pixel), done WITHOUT float atomics as a bucketed
+// gather (msda_bwd_value_kernel: count -> scan -> fill -> per-pixel gather in 64-bit fixed point), bit-reproducible and
+// with every element of grad_value written exactly once.
 #include "common.h"
 
 #define MSDA_MAX_LEVELS 8
@@ -126,80 +123,138 @@ __global__ __launch_bounds__(256) void msda_absmax_kernel(const float* __restric
     if (threadIdx.x == 0) atomicMax(gmax, __float_as_uint(m));
 }
 
-// grid (pixel blocks over all levels, M, N); 1024 threads = (1024 / D) sample slots x D channels (16 waves per CU:
-// the block owns the CU's LDS, so its own waves have to hide the latency of the sample loads).
-// LDS: RB x D accumulators of 2 x 32 bit, RB = pixels per block.
+// grad_value as a BUCKETED GATHER, two kernels:
+//   msda_bucket_kernel (one workgroup per (level, head, image)):
+//     pass 1  counts, per pixel of the level, the (sample, corner) pairs that land on it   (one LDS integer add per pair --
+//             not one per pair AND channel, which made the first LDS-scatter version LDS-atomic bound: 774 us per launch);
+//     scan    turns the counts into bucket offsets;
+//     pass 2  writes every pair's id into its pixel's bucket (the order inside a bucket depends on the wave scheduling);
+//   msda_gather_kernel (one group of D lanes per pixel, all pixels of all levels / heads / images in parallel):
+//     walks the pixel's bucket, recomputes the bilinear weight of each pair and accumulates
+//     attn * weight * grad_out[q, m, d] in 64-bit FIXED POINT (2^40 / max|grad_out|): integer sums do not depend on the
+//     order of the bucket, so the result is bit-reproducible, and every element of grad_value is written exactly once
+//     (no atomics on HBM at all).
+// LDS of the bucket kernel: 2 * H_l*W_l ints -> levels up to 16384 pixels.
+// ws (ints): [N*M*S] bucket starts | [N*M*S] bucket sizes | per (image, head, level) Lq*P*4 pair ids.
 #define MSDA_VT 1024
-__global__ __launch_bounds__(MSDA_VT) void msda_bwd_value_kernel(const float* __restrict__ loc, const float* __restrict__ attn,
-                                                              const float* __restrict__ gout, const unsigned int* __restrict__ gmax,
-                                                              float* __restrict__ gvalue, MsdaShapes sh, int S, int Lq, int M,
-                                                              int D, int P, int RB) {
-    // Fixed point v = round(g * 2^30 / max|gout|) (|v| <= 2^30), accumulated as two 32-bit halves v = hi * 4096 + lo with
-    // lo in [0, 4096): 32-bit LDS adds (the 64-bit LDS add measured ~20x slower); lo cannot overflow below 2^20 terms,
-    // hi (|hi| <= 2^18) below 2^13 terms per element -- far above the number of samples that can land on one pixel.
-    extern __shared__ unsigned int acc32[];          // [RB*D] lo | [RB*D] hi
-    const int m = blockIdx.y, n = blockIdx.z;
-    // which level / pixel range this block owns
-    int l = 0, blk = blockIdx.x;
-    for (; l < sh.n_levels; ++l) {
-        const int nb = (sh.H[l] * sh.W[l] + RB - 1) / RB;
-        if (blk < nb) break;
-        blk -= nb;
-    }
-    const int H = sh.H[l], W = sh.W[l];
-    const int p0 = blk * RB, p1 = min(p0 + RB, H * W);
-    unsigned int* acc_lo = acc32;
-    int* acc_hi = reinterpret_cast<int*>(acc32 + RB * D);
-    for (int i = threadIdx.x; i < (p1 - p0) * D; i += MSDA_VT) { acc_lo[i] = 0u; acc_hi[i] = 0; }
-    __syncthreads();
-    const float gm = __uint_as_float(*gmax);
-    const float scale = gm > 0.f ? 1073741824.0f / gm : 0.f;          // 2^30 / max|gout|
-    const int slots = MSDA_VT / D, slot = threadIdx.x / D, d = threadIdx.x - slot * D;
+__global__ __launch_bounds__(MSDA_VT) void msda_bucket_kernel(const float* __restrict__ loc, int* __restrict__ ws, MsdaShapes sh,
+                                                           int S, int Lq, int M, int P, int N) {
+    extern __shared__ int sm[];
+    const int l = blockIdx.x, m = blockIdx.y, n = blockIdx.z;
+    const int H = sh.H[l], W = sh.W[l], HW = H * W;
+    int* cnt = sm;                 // [HW] counts, then exclusive offsets
+    int* cur = sm + HW;            // [HW] fill cursors
+    __shared__ int wsum[MSDA_VT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long nsamp = (long)Lq * P;
-    // rows of the block's pixel range: a sample can only contribute if its 2x2 footprint touches them
-    const int ylo = p0 / W - 1, yhi = (p1 - 1) / W;
-    for (long e0 = slot; e0 < nsamp; e0 += 2L * slots) {
-        float sx[2], sy[2], sg[2];
-        bool live[2];
+    const long NMS = (long)N * M * S;
+    int* gstart = ws + ((long)n * M + m) * S + sh.start[l];
+    int* gsize = gstart + NMS;
+    int* list = ws + 2 * NMS + (((long)n * M + m) * sh.n_levels + l) * nsamp * 4;
+    for (int i = tid; i < HW; i += MSDA_VT) { cnt[i] = 0; cur[i] = 0; }
+    __syncthreads();
+    for (long e = tid; e < nsamp; e += MSDA_VT) {
+        const int q = (int)(e / P), p = (int)(e - (long)q * P);
+        const float* lb = loc + ((((long)n * Lq + q) * M + m) * sh.n_levels + l) * P * 2 + p * 2;
+        const float x = lb[0] * W - 0.5f, y = lb[1] * H - 0.5f;
+        if (!(y > -1.f && x > -1.f && y < H && x < W)) continue;
+        const int y0 = (int)floorf(y), x0 = (int)floorf(x);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {                  // both samples' loads are in flight before either is used
-            const long e = e0 + (long)u * slots;
-            live[u] = e < nsamp;
-            const long ee = live[u] ? e : e0;
-            const int q = (int)(ee / P), p = (int)(ee - (long)q * P);
-            const long qm = ((long)n * Lq + q) * M + m;
-            const float* lb = loc + (qm * sh.n_levels + l) * P * 2 + p * 2;
-            sx[u] = lb[0] * W - 0.5f;
-            sy[u] = lb[1] * H - 0.5f;
-            const int yy = (int)floorf(sy[u]);
-            live[u] = live[u] && sy[u] > -1.f && sx[u] > -1.f && sy[u] < H && sx[u] < W && yy >= ylo && yy <= yhi;
-            sg[u] = live[u] ? gout[qm * D + d] * attn[(qm * sh.n_levels + l) * P + p] * scale : 0.f;
+        for (int c = 0; c < 4; ++c) {
+            const int px = x0 + (c & 1), py = y0 + (c >> 1);
+            if (px >= 0 && px < W && py >= 0 && py < H) atomicAdd(&cnt[py * W + px], 1);
         }
+    }
+    __syncthreads();
+    // exclusive scan of cnt[0..HW): each thread a contiguous chunk, wave scan of the chunk sums, then the wave sums
+    const int chunk = (HW + MSDA_VT - 1) / MSDA_VT;
+    const int c0 = min(tid * chunk, HW), c1 = min(c0 + chunk, HW);
+    int tsum = 0;
+    for (int i = c0; i < c1; ++i) tsum += cnt[i];
+    int incl = tsum;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (!live[u]) continue;
-            const int y0 = (int)floorf(sy[u]), x0 = (int)floorf(sx[u]);
-            const float ly = sy[u] - y0, lx = sx[u] - x0, hy = 1.f - ly, hx = 1.f - lx;
-            const int px[4] = {x0, x0 + 1, x0, x0 + 1}, py[4] = {y0, y0, y0 + 1, y0 + 1};
-            const float cw[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w2 = 0; w2 < wv; ++w2) base += wsum[w2];
+    int run = base + incl - tsum;
+    for (int i = c0; i < c1; ++i) { const int v = cnt[i]; cnt[i] = run; gstart[i] = run; gsize[i] = v; run += v; }
+    __syncthreads();
+    for (long e = tid; e < nsamp; e += MSDA_VT) {
+        const int q = (int)(e / P), p = (int)(e - (long)q * P);
+        const float* lb = loc + ((((long)n * Lq + q) * M + m) * sh.n_levels + l) * P * 2 + p * 2;
+        const float x = lb[0] * W - 0.5f, y = lb[1] * H - 0.5f;
+        if (!(y > -1.f && x > -1.f && y < H && x < W)) continue;
+        const int y0 = (int)floorf(y), x0 = (int)floorf(x);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (px[c] < 0 || px[c] >= W || py[c] < 0 || py[c] >= H) continue;
-                const int pix = py[c] * W + px[c];
-                if (pix < p0 || pix >= p1) continue;
-                const int v = (int)rintf(sg[u] * cw[c]);
-                atomicAdd(&acc_lo[(pix - p0) * D + d], (unsigned int)(v & 4095));
-                atomicAdd(&acc_hi[(pix - p0) * D + d], v >> 12);           // arithmetic shift: v = (v >> 12) * 4096 + (v & 4095)
+        for (int c = 0; c < 4; ++c) {
+            const int px = x0 + (c & 1), py = y0 + (c >> 1);
+            if (px >= 0 && px < W && py >= 0 && py < H) {
+                const int pix = py * W + px;
+                list[cnt[pix] + atomicAdd(&cur[pix], 1)] = (int)(e * 4 + c);
             }
         }
     }
-    __syncthreads();
-    const float inv = gm > 0.f ? gm / 1073741824.0f : 0.f;
-    for (int i = threadIdx.x; i < (p1 - p0) * D; i += MSDA_VT) {
-        const int pix = p0 + i / D, dd = i - (i / D) * D;
-        const long long tot = (long long)acc_hi[i] * 4096 + (long long)acc_lo[i];
-        gvalue[(((long)n * S + sh.start[l] + pix) * M + m) * D + dd] = (float)tot * inv;
+}
+
+// grid: ceil(S / (256 / D)) x M x N workgroups of 256 threads = 256 / D pixels x D channels
+__global__ __launch_bounds__(256) void msda_gather_kernel(const float* __restrict__ loc, const float* __restrict__ attn,
+                                                           const float* __restrict__ gout, const unsigned int* __restrict__ gmax,
+                                                           const int* __restrict__ ws, float* __restrict__ gvalue, MsdaShapes sh,
+                                                           int S, int Lq, int M, int D, int P, int N) {
+    const int m = blockIdx.y, n = blockIdx.z;
+    const int grp = threadIdx.x / D, d = threadIdx.x - grp * D;
+    const int s = blockIdx.x * (256 / D) + grp;              // pixel index over all levels
+    if (s >= S) return;
+    int l = 0;
+    while (l + 1 < sh.n_levels && s >= sh.start[l + 1]) ++l;
+    const int H = sh.H[l], W = sh.W[l];
+    const long nsamp = (long)Lq * P;
+    const long NMS = (long)N * M * S;
+    const long pm = ((long)n * M + m) * S + s;
+    const int b0 = ws[pm], nb = ws[NMS + pm];
+    const int* list = ws + 2 * NMS + (((long)n * M + m) * sh.n_levels + l) * nsamp * 4 + b0;
+    const float gm = __uint_as_float(*gmax);
+    const float scale = gm > 0.f ? 1099511627776.0f / gm : 0.f;       // 2^40 / max|gout|
+    // The D lanes of the pixel's group work in two roles: lane j first prepares pair j of the next D pairs of the bucket
+    // (id, bilinear weight * attention weight, row of grad_out -- three dependent loads done ONCE, D pairs in parallel),
+    // then every lane, as channel d, adds the D pairs' contributions with the rows' addresses broadcast by shuffles: the
+    // D loads of grad_out are independent of one another and stay in flight together.
+    long long acc = 0;
+    for (int k0 = 0; k0 < nb; k0 += D) {
+        float wj = 0.f;
+        long rowj = 0;
+        if (k0 + d < nb) {
+            const int id = list[k0 + d];
+            const int c = id & 3;
+            const long e = id >> 2;
+            const int q = (int)(e / P), p = (int)(e - (long)q * P);
+            const long qm = ((long)n * Lq + q) * M + m;
+            const float* lb = loc + (qm * sh.n_levels + l) * P * 2 + p * 2;
+            const float x = lb[0] * W - 0.5f, y = lb[1] * H - 0.5f;
+            const float lx = x - floorf(x), ly = y - floorf(y);
+            wj = ((c & 1) ? lx : 1.f - lx) * ((c >> 1) ? ly : 1.f - ly) * attn[(qm * sh.n_levels + l) * P + p] * scale;
+            rowj = qm * D;
+        }
+        const int cntk = min(D, nb - k0);
+        for (int k = 0; k < cntk; k += 4) {
+            float gk[4], wk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = k + u < cntk ? k + u : k;                    // (clamped: the weight of a padded slot is zeroed below)
+                const long row = __shfl(rowj, kk, D);
+                wk[u] = k + u < cntk ? __shfl(wj, kk, D) : 0.f;
+                gk[u] = gout[row + d];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += (long long)rintf(gk[u] * wk[u]);
+        }
     }
+    gvalue[(((long)n * S + s) * M + m) * D + d] = gm > 0.f ? (float)acc * (gm / 1099511627776.0f) : 0.f;
 }
 
 static int fill_shapes(MsdaShapes* sh, const int* h_shapes, int n_levels, int* S) {
@@ -231,10 +286,11 @@ extern "C" int wc_msda_fwd(const float* value, const int* h_shapes, int n_levels
     return WC_OK;
 }
 
-// gvalue needs no initialisation (every element is written exactly once); gmax: 1 x u32 workspace.
+// gvalue needs no initialisation (every element is written exactly once); gmax: 1 x u32 workspace;
+// ws: N*M*S*2 + N*M*n_levels*Lq*P*4 ints (bucket starts, sizes, and the per-pixel buckets of (sample, corner) ids).
 extern "C" int wc_msda_bwd(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
-                           const float* gout, float* gvalue, float* gloc, float* gattn, void* gmax, int N, int Lq, int M,
-                           int D, int P, void* stream) {
+                           const float* gout, float* gvalue, float* gloc, float* gattn, void* gmax, void* ws, int N, int Lq,
+                           int M, int D, int P, void* stream) {
     MsdaShapes sh;
     int S = 0;
     WC_CHECK_ARG(value && h_shapes && loc && attn && gout && gvalue && gloc && gattn && gmax && N > 0 && Lq > 0 && M > 0 && P > 0,
@@ -251,17 +307,20 @@ extern "C" int wc_msda_bwd(const float* value, const int* h_shapes, int n_levels
     hipLaunchKernelGGL(msda_absmax_kernel, dim3((unsigned)(ng / 256 / 8 + 1 > 512 ? 512 : ng / 256 / 8 + 1)), dim3(256), 0, st, gout,
                        (unsigned int*)gmax, ng);
     WC_LAUNCH_CHECK("msda_absmax_kernel");
-    const int RB = 16384 / D;                       // 128 KiB of 64-bit accumulators per workgroup
-    int nblk = 0;
-    for (int l = 0; l < n_levels; ++l) nblk += wc_cdiv(sh.H[l] * sh.W[l], RB);
+    int maxhw = 0;
+    for (int l = 0; l < n_levels; ++l) maxhw = sh.H[l] * sh.W[l] > maxhw ? sh.H[l] * sh.W[l] : maxhw;
+    WC_CHECK_ARG(maxhw <= 16384 && ws, "wc_msda_bwd: a level may have at most 16384 pixels; ws workspace missing");
     static bool attr_set = false;
     if (!attr_set) {
-        WC_CHECK_ARG(hipFuncSetAttribute((const void*)msda_bwd_value_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess,
+        WC_CHECK_ARG(hipFuncSetAttribute((const void*)msda_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess,
                      "wc_msda_bwd: cannot reserve 128 KiB of LDS");
         attr_set = true;
     }
-    hipLaunchKernelGGL(msda_bwd_value_kernel, dim3(nblk, M, N), dim3(MSDA_VT), (size_t)RB * D * 8, st, loc, attn, gout,
-                       (const unsigned int*)gmax, gvalue, sh, S, Lq, M, D, P, RB);
-    WC_LAUNCH_CHECK("msda_bwd_value_kernel");
+    hipLaunchKernelGGL(msda_bucket_kernel, dim3(n_levels, M, N), dim3(MSDA_VT), (size_t)maxhw * 2 * sizeof(int), st, loc, (int*)ws, sh,
+                       S, Lq, M, P, N);
+    WC_LAUNCH_CHECK("msda_bucket_kernel");
+    hipLaunchKernelGGL(msda_gather_kernel, dim3(wc_cdiv(S, 256 / D), M, N), dim3(256), 0, st, loc, attn, gout,
+                       (const unsigned int*)gmax, (const int*)ws, gvalue, sh, S, Lq, M, D, P, N);
+    WC_LAUNCH_CHECK("msda_gather_kernel");
     return WC_OK;
 }
