@@ -214,6 +214,23 @@ def roofline_leg(args, step, loader, dev):
             traffic = {k: round(v["hbm_bytes_per_launch"]) for k, v in json.load(open(tpath)).items()}
             tsrc = "profiles/" + fn + " (committed rocprofv3 --pmc passes of this command, not this run)"
             break
+    # north-star group "ViT attention": in-projection + attention forward + head-mean maps + out-projection of the 12 ViT
+    # blocks (tagged at their call sites, clip/vit_engine.py) -- flops over time of the group as a whole
+    grp = [(n, r) for n, r in summ.items() if n.endswith("@vit_attn")]
+    group = None
+    if grp and sum(r["ms"] for _, r in grp) > 0:
+        gw, gms = sum(r["work"] for _, r in grp), sum(r["ms"] for _, r in grp)
+        group = {"kernels": sorted(n[:-len("@vit_attn")] for n, _ in grp), "achieved": round(gw / (gms * 1e-3) / 1e12, 1),
+                 "peak": 2500.0, "unit": "TFLOP/s", "frac": round(gw / (gms * 1e-3) / 2.5e15, 4),
+                 "frac_of_practical_mfma_ceiling_1733": round(gw / (gms * 1e-3) / 1.733e15, 4),
+                 "ms_per_step": round(gms * stride / n, 3)}
+    merged = {}
+    for name, r in summ.items():          # fold the tagged records back into their kernels for the per-kernel rows
+        base = name.split("@")[0]
+        m = merged.setdefault(base, {"ms": 0.0, "launches": 0, "work": 0.0})
+        for k in m:
+            m[k] += r[k]
+    summ = merged
     roofs = []
     for name, r in summ.items():
         bound, peak, unit = peak_of(name)
@@ -229,7 +246,8 @@ def roofline_leg(args, step, loader, dev):
     roofs.sort(key=lambda x: -x["share_of_eager_step"])
     # the north-star group "ViT attention" = in-projection + QK^T/softmax/PV + head-mean maps + out-projection is
     # reported by the library under its own tag when the launch sites carry it (csrc/core.hip wc_prof groups)
-    return roofs, {"eager_instrumented_ms_per_step": round(dt / n * 1e3, 3), "traffic_source": tsrc}
+    return roofs, {"eager_instrumented_ms_per_step": round(dt / n * 1e3, 3), "traffic_source": tsrc, "vit_attention_group": group,
+                   "practical_mfma_ceiling": "1733 TFLOP/s at 1.71 GHz in-kernel clock (tools/probes/mfma_clock.hip, profiles/r02_probes.txt)"}
 
 
 def encoder_leg(args, dev):

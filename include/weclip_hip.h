@@ -33,6 +33,9 @@ int wc_device_arch(int dev, char* buf, int buflen);
  * fences its launch, ~6 us), (0) stops.  wc_prof_report synchronises the device and
  * writes one "kernel name \t launches \t total ms \t algorithmic work (flop or bytes)" line per kernel. */
 void wc_prof_enable(int stride);
+/* Group tag appended to the kernel names of the launches that follow ("@vit_attn": in-projection, attention, head-mean
+ * maps and out-projection of an encoder block, the north star's "ViT attention" group); NULL / "" clears it. */
+void wc_prof_tag(const char* tag);
 int wc_prof_report(char* buf, int cap);
 
 /* ---- PAR: pixel-adaptive refinement -------------------------------------------------- */

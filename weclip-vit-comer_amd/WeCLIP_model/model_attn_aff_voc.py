@@ -100,7 +100,8 @@ class WeCLIP(nn.Module):
         need = self._maps_needed(seg_trans) if want_maps else [False] * 11
         xs, maps = [], []
         for i in range(vis.transformer.layers - 1):
-            rows, m = VE.run_block(vis.transformer.resblocks[i].pack(), rows, B, Lq, want_mean=need[i], x16_out=x16)
+            rows, m = VE.run_block(vis.transformer.resblocks[i].pack(), rows, B, Lq, want_mean=need[i], x16_out=x16,
+                                   tag=b"@vit_attn")
             xs.append(rows)
             maps.append(m)
         return xs, maps, B, Lq

@@ -58,13 +58,16 @@ class X16Stack(list):
         return Split(self.big[i], self.big_lo[i] if self.big_lo is not None else None)
 
 
-def run_block(pk, x, B, L, want_mean=True, keep=None, x16_out=None):
+def run_block(pk, x, B, L, want_mean=True, keep=None, x16_out=None, tag=None):
     """x (B*L, E) fp32 -> (x_out fp32, head-mean map (B,L,L) or None).
-    `keep`, if a dict, receives intermediates needed by the analytic backward."""
+    `keep`, if a dict, receives intermediates needed by the analytic backward.
+    `tag`: bench.py's roofline group of the attention half (in-projection, attention, head-mean, out-projection)."""
     M, E, H, DH = B * L, pk.E, pk.H, pk.DH
     dev = x.device
     ex = pk.exact
     a32, a = ops.layernorm(x, pk.ln1_w, pk.ln1_b, want32=keep is not None, with_lo=ex)
+    if tag:
+        ops.KernelTimer.tag(tag)
     qkv = torch.empty(M, 3 * E, device=dev, dtype=F16)
     ops.gemm(a, pk.in_w, M, 3 * E, E, bias=pk.in_b, out16=qkv, scale=ops.q_scale(DH), scale_cols=E)
     o32 = None
@@ -74,6 +77,8 @@ def run_block(pk, x, B, L, want_mean=True, keep=None, x16_out=None):
         o16, lse, mean = ops.attention(qkv, B, L, H, DH, want_mean=want_mean)
     x1 = torch.empty(M, E, device=dev, dtype=F32)
     ops.gemm(o16, pk.out_w, M, E, E, bias=pk.out_b, resid=x, out32=x1, round16=True)
+    if tag:
+        ops.KernelTimer.tag(None)
     _, a2 = ops.layernorm(x1, pk.ln2_w, pk.ln2_b, with_lo=ex)
     z = Split(torch.empty(M, 4 * E, device=dev, dtype=F16),
               torch.empty(M, 4 * E, device=dev, dtype=F16) if ex else None)

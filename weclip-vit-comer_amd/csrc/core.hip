@@ -48,8 +48,9 @@ extern "C" int wc_device_arch(int dev, char* buf, int buflen) {
 // the dominant kernels bracket themselves with wc_prof_begin / wc_prof_end.  Off by default (one branch per launch).
 // An event pair around a launch costs ~6 us of GPU time (it fences the neighbouring kernels), so bench.py records a
 // regular 1-in-n sample of the instrumented launches rather than all ~290 per step (which costs 10 % throughput).
-struct ProfRec { const char* name; hipEvent_t e0, e1; double work; };
+struct ProfRec { const char* name; const char* tag; hipEvent_t e0, e1; double work; };
 static int g_prof_stride = 0;          // 0 = off; n = record one of every n instrumented launches
+static const char* g_prof_tag = "";    // group tag of the call site (e.g. "@vit_attn"), appended to the kernel name in the report
 static unsigned long g_prof_ctr = 0;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_pool;
@@ -68,10 +69,24 @@ extern "C" void wc_prof_enable(int stride) {
     g_prof_ctr = 0;
 }
 
+// Group tag for the launches that follow (bench.py: "@vit_attn" around in-projection, attention, head-mean and
+// out-projection of an encoder block).  tag must be a string that outlives the report (the Python host passes interned
+// constants); NULL or "" clears it.
+extern "C" void wc_prof_tag(const char* tag) {
+    static std::vector<std::string> keep;
+    if (!tag || !*tag) { g_prof_tag = ""; return; }
+    for (auto& k : keep)
+        if (k == tag) { g_prof_tag = k.c_str(); return; }
+    keep.reserve(64);
+    keep.push_back(tag);
+    g_prof_tag = keep.back().c_str();
+}
+
 int wc_prof_begin(void* stream) {
     if (!g_prof_stride || (g_prof_ctr++ % g_prof_stride) != 0) return -1;
     ProfRec r;
     r.name = "";
+    r.tag = g_prof_tag;
     r.e0 = prof_event();
     r.e1 = prof_event();
     r.work = 0.0;
@@ -95,7 +110,7 @@ extern "C" int wc_prof_report(char* buf, int cap) {
     for (auto& r : g_prof) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
-        auto& a = agg[r.name];
+        auto& a = agg[std::string(r.name) + r.tag];
         a.first += ms;
         a.second.first += r.work;
         a.second.second += 1;

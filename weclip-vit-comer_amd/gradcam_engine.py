@@ -136,5 +136,5 @@ def last_layer_forward(clip_model, rows, B, Lq, want_mean=True):
     analytic backward needs."""
     blk = clip_model.visual.transformer.resblocks[-1]
     keep = {}
-    x2, mean = VE.run_block(blk.pack(), rows, B, Lq, want_mean=want_mean, keep=keep)
+    x2, mean = VE.run_block(blk.pack(), rows, B, Lq, want_mean=want_mean, keep=keep, tag=b"@vit_attn")
     return LastLayerState(clip_model, x2, mean, keep, B, Lq)

@@ -17,10 +17,21 @@ class KernelTimer:
     the C library at its own launch sites (csrc/core.hip wc_prof_*), one pair per kernel launch on the launch
     stream, under the kernel names rocprofv3 reports; `work` is the algorithmic work (flops or bytes) of a launch."""
 
+    active = False
+
     @staticmethod
     def enable(stride=1):
         """Record one of every `stride` instrumented launches (clearing earlier records); 0 / False stops."""
         L.lib().cdll.wc_prof_enable(int(stride))
+        KernelTimer.active = bool(stride)
+        if not stride:
+            L.lib().cdll.wc_prof_tag(None)
+
+    @staticmethod
+    def tag(name):
+        """Group tag for the launches that follow (only while the timers run: one ctypes call otherwise saved)."""
+        if KernelTimer.active:
+            L.lib().cdll.wc_prof_tag(name)
 
     @staticmethod
     def summary():
