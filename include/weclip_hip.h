@@ -91,6 +91,12 @@ int wc_seg_loss_fwd(const float* seg, const int64_t* label, float* part, float* 
                     int H, int W, int ignore, void* stream);
 int wc_seg_loss_bwd(const float* seg, const int64_t* label, const float* wts, float* ghr, int B, int nc, int h,
                     int w, int H, int W, int ignore, void* stream);
+/* The same backward without the (B,nc,H,W) high-resolution gradient: the soft-max gradient is formed per pixel inside the
+ * Y pass of the separable bilinear backward (fixed summation order), then the X pass.  tmp: workspace B*nc*h*W f32;
+ * out: (B,nc,h,w).  Same summation order as wc_seg_loss_bwd + wc_bilinear_resize_bwd (bit-identical for nc > 24; for
+ * nc <= 24 the per-pixel log-sum-exp is formed max-first: equal to rounding). */
+int wc_seg_loss_bwd_fused(const float* seg, const int64_t* label, const float* wts, float* tmp, float* out, int B, int nc,
+                          int h, int w, int H, int W, int ignore, void* stream);
 
 /* Affinity loss fused with the affinity-label construction (reference utils/camutils.py:226-247 +
  * scripts/dist_clip_voc.py:116-133 radius mask + utils/losses.py:11-22): attn_pred (B,hw,hw) f32, cam_label (B,H,W)

@@ -61,3 +61,30 @@ def test_fused_affinity_loss_forward_backward(B, h, w, radius):
     (0.1 * out).backward()
     assert abs(out.item() - ref.item()) < 1e-5
     np.testing.assert_allclose(x.grad.cpu().numpy(), 0.1 * ref_in.grad.numpy(), rtol=1e-4, atol=1e-10)
+
+
+@pytest.mark.parametrize("B,nc,h,w,scale", [(2, 21, 4, 6, 16), (1, 81, 5, 3, 16), (2, 21, 32, 32, 16)])
+def test_fused_seg_loss_backward_matches_the_two_kernel_path(B, nc, h, w, scale):
+    """wc_seg_loss_bwd_fused (soft-max gradient formed inside the Y pass, no (B, nc, H, W) tensor) vs wc_seg_loss_bwd +
+    wc_bilinear_resize_bwd: same per-pixel arithmetic, same summation order -> the same bits."""
+    from weclip_vit_comer_amd import _lib as L
+    H, W = h * scale, w * scale
+    g = torch.Generator().manual_seed(B * nc + h)
+    seg = torch.randn(B, nc, h, w, generator=g).cuda()
+    lab = torch.randint(0, nc, (B, H, W), generator=g)
+    lab[:, :3] = 255
+    lab = lab.cuda()
+    wts = torch.tensor([0.37e-4, 0.81e-4], device="cuda")
+    F32 = torch.float32
+    ghr = torch.empty(B, nc, H, W, device="cuda")
+    L.lib().wc_seg_loss_bwd(L.ptr(seg, F32), L.ptr(lab, torch.int64), L.ptr(wts, F32), L.ptr(ghr), B, nc, h, w, H, W, 255, L.stream())
+    ref, tmp = torch.empty_like(seg), torch.empty(B * nc * h * W, device="cuda")
+    L.lib().wc_bilinear_resize_bwd(L.ptr(ghr), L.ptr(ref), L.ptr(tmp), B * nc, h, w, H, W, 0, L.stream())
+    out, tmp2 = torch.empty_like(seg), torch.empty(B * nc * h * W, device="cuda")
+    L.lib().wc_seg_loss_bwd_fused(L.ptr(seg, F32), L.ptr(lab, torch.int64), L.ptr(wts, F32), L.ptr(tmp2), L.ptr(out), B, nc, h, w, H, W,
+                                  255, L.stream())
+    assert ref.abs().max().item() > 0
+    if nc > 24:
+        assert torch.equal(out, ref)
+    else:       # the small-class-count form takes the per-pixel maximum first instead of the online log-sum-exp: equal to rounding
+        assert (out - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()

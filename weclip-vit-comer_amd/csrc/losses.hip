@@ -132,6 +132,150 @@ extern "C" int wc_seg_loss_bwd(const float* seg, const int64_t* label, const flo
 }
 
 
+// Backward of the fused up-sampling + cross-entropy WITHOUT the (B, nc, H, W) high-resolution gradient (352 MB written and
+// read back at 16 x 21 x 512 x 512): bilinear interpolation is separable, so the low-resolution gradient is
+//   tmp[b,c,ys,X] = sum_Y wy(Y -> ys) * g[b,c,Y,X]      (this kernel: g is formed on the fly, per pixel, from the logits)
+//   out[b,c,ys,xs] = sum_X wx(X -> xs) * tmp[b,c,ys,X]  (seg_bwd_x_kernel)
+// A thread owns one high-resolution column X of one low-resolution row ys and walks the ~2/sy rows Y that touch ys in
+// ascending order (fixed summation order: deterministic; for nc > 24 bit-identical to the two-kernel path it replaces, for
+// nc <= 24 the log-sum-exp is formed max-first instead of online: same value to rounding); every pixel's soft-max is
+// evaluated for both low-resolution rows it feeds (2 x the exponentials, none of the HBM traffic).
+template <int NCT>
+__global__ __launch_bounds__(256) void seg_loss_bwd_y_kernel(const float* __restrict__ seg, const long* __restrict__ label,
+                                                              const float* __restrict__ wts, float* __restrict__ tmp, int nc,
+                                                              int h, int w, int H, int W, float sy, float sx, int ignore) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), ys = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (x >= W || ys >= h) return;
+    int x0, x1;
+    float lx;
+    bil_index(x, w, sx, x0, x1, lx);
+    const float iy = 1.0f / sy;
+    int y_lo = (int)floorf((ys - 1.5f) * iy) - 1, y_hi = (int)ceilf((ys + 1.5f) * iy) + 1;
+    if (y_lo < 0) y_lo = 0;
+    if (y_hi > H - 1) y_hi = H - 1;
+    float acc[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) acc[c] = 0.f;
+    const float* S = seg + (long)b * nc * h * w;
+    const float wbg = wts[0], wfg = wts[1];
+    // CACHE (small class counts): the four low-resolution neighbours of this column for every class live in registers and
+    // are re-read only when the source row pair (y0, y1) changes (every ~1/sy rows): a row then costs FMAs and
+    // exponentials, not 2 x 4 x nc loads
+    constexpr bool CACHE = NCT <= 24;
+    float s00[CACHE ? NCT : 1], s01[CACHE ? NCT : 1], s10[CACHE ? NCT : 1], s11[CACHE ? NCT : 1];
+    int cy0 = -1, cy1 = -1;
+    long labs[8];
+    for (int y = y_lo; y <= y_hi; ++y) {
+        if (((y - y_lo) & 7) == 0) {               // the labels of the next 8 rows in one go: 8 independent loads in flight
+#pragma unroll
+            for (int u = 0; u < 8; ++u) labs[u] = label[((long)b * H + min(y + u, H - 1)) * W + x];
+        }
+        int y0, y1;
+        float ly;
+        bil_index(y, h, sy, y0, y1, ly);
+        const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);       // wave-uniform
+        long lab = labs[0];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) lab = ((y - y_lo) & 7) == u ? labs[u] : lab;
+        if (wy == 0.f) continue;
+        const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+        const long o00 = (long)y0 * w + x0, o01 = (long)y0 * w + x1, o10 = (long)y1 * w + x0, o11 = (long)y1 * w + x1;
+        if constexpr (CACHE) {
+            if (y0 != cy0 || y1 != cy1) {          // wave-uniform
+                cy0 = y0; cy1 = y1;
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) {
+                    if (c < nc) {
+                        const float* Sc = S + (long)c * h * w;
+                        s00[c] = Sc[o00]; s01[c] = Sc[o01]; s10[c] = Sc[o10]; s11[c] = Sc[o11];
+                    }
+                }
+            }
+        }
+        float mx = -INFINITY, sum = 0.f;
+        float zc[CACHE ? NCT : 1];
+        if constexpr (CACHE) {
+            // maximum first, then independent exponentials (the online form's max -> rescale -> add chain is serial over
+            // the classes); the interpolated logits stay in registers for the gradient pass
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                zc[c] = c < nc ? w00 * s00[c] + w01 * s01[c] + w10 * s10[c] + w11 * s11[c] : -INFINITY;
+                mx = fmaxf(mx, zc[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) sum += c < nc ? __expf(zc[c] - mx) : 0.f;
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                if (c < nc) {
+                    const float* Sc = S + (long)c * h * w;
+                    const float z = w00 * Sc[o00] + w01 * Sc[o01] + w10 * Sc[o10] + w11 * Sc[o11];
+                    const float nm = fmaxf(mx, z);
+                    sum = sum * __expf(mx - nm) + __expf(z - nm);
+                    mx = nm;
+                }
+            }
+        }
+        const bool valid = lab != ignore && lab >= 0 && lab < nc;
+        const float wp = valid ? (lab == 0 ? wbg : wfg) : 0.f;
+        const float lse = mx + __logf(sum);
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            if (c < nc) {
+                float z;
+                if constexpr (CACHE) z = zc[c];
+                else { const float* Sc = S + (long)c * h * w; z = w00 * Sc[o00] + w01 * Sc[o01] + w10 * Sc[o10] + w11 * Sc[o11]; }
+                const float gval = wp * (__expf(z - lse) - (c == lab ? 1.f : 0.f));
+                acc[c] = fmaf(wy, gval, acc[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+        if (c < nc) tmp[(((long)b * nc + c) * h + ys) * W + x] = acc[c];
+}
+
+__global__ __launch_bounds__(256) void seg_bwd_x_kernel(const float* __restrict__ tmp, float* __restrict__ gsrc, int Hs, int Ws,
+                                                         int Wd, float sx) {
+    const int xs = blockIdx.x * 64 + (threadIdx.x & 63), ys = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xs >= Ws || ys >= Hs) return;
+    const float* T = tmp + ((long)blockIdx.z * Hs + ys) * Wd;
+    const float ix = 1.0f / sx;
+    int x_lo = (int)floorf((xs - 1.5f) * ix) - 1, x_hi = (int)ceilf((xs + 1.5f) * ix) + 1;
+    if (x_lo < 0) x_lo = 0;
+    if (x_hi > Wd - 1) x_hi = Wd - 1;
+    float acc = 0.f;
+    for (int x = x_lo; x <= x_hi; ++x) {
+        int x0, x1;
+        float lx;
+        bil_index(x, Ws, sx, x0, x1, lx);
+        const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
+        acc = fmaf(wx, T[x], acc);
+    }
+    gsrc[((long)blockIdx.z * Hs + ys) * Ws + xs] = acc;
+}
+
+// d loss / d seg (B, nc, h, w) of get_seg_loss(F.interpolate(seg, (H, W)), label) in two launches.
+// wts (2) device floats: gradient weight of a background / foreground pixel.  tmp: workspace B*nc*h*W floats.
+extern "C" int wc_seg_loss_bwd_fused(const float* seg, const int64_t* label, const float* wts, float* tmp, float* out, int B,
+                                     int nc, int h, int w, int H, int W, int ignore, void* stream) {
+    WC_CHECK_ARG(seg && label && wts && tmp && out && B > 0 && B <= 65535 && nc > 0 && nc <= SEG_MAX_C && (long)B * nc <= 65535 &&
+                 h > 0 && w > 0 && H >= h && W >= w, "wc_seg_loss_bwd_fused: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(wc_cdiv(W, 64), wc_cdiv(h, 4), B);
+    if (nc <= 24)
+        hipLaunchKernelGGL(seg_loss_bwd_y_kernel<24>, grid, dim3(256), 0, st, seg, (const long*)label, wts, tmp, nc, h, w, H, W,
+                           (float)h / H, (float)w / W, ignore);
+    else
+        hipLaunchKernelGGL(seg_loss_bwd_y_kernel<SEG_MAX_C>, grid, dim3(256), 0, st, seg, (const long*)label, wts, tmp, nc, h, w, H,
+                           W, (float)h / H, (float)w / W, ignore);
+    WC_LAUNCH_CHECK("seg_loss_bwd_y_kernel");
+    hipLaunchKernelGGL(seg_bwd_x_kernel, dim3(wc_cdiv(w, 64), wc_cdiv(h, 4), B * nc), dim3(256), 0, st, tmp, out, h, w, W,
+                       (float)w / W);
+    WC_LAUNCH_CHECK("seg_bwd_x_kernel");
+    return WC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Affinity loss of the training step, fused with the label -> affinity-label construction.
 // reference utils/camutils.py:226-247 (cams_to_affinity_label: nearest down-sampling of the pseudo labels by 16,

@@ -52,11 +52,11 @@ class _SegLossFn(torch.autograd.Function):
         H, W = label.shape[1:]
         wts = sums[5:7] * g            # (0.5 / n_bg, 0.5 / n_fg) from the forward reduce kernel: no host sync
         out = torch.empty_like(seg)
-        ghr = torch.empty(B, nc, H, W, device=seg.device, dtype=torch.float32)
-        L.lib().wc_seg_loss_bwd(L.ptr(seg), L.ptr(label), L.ptr(wts, torch.float32, "wts"), L.ptr(ghr), B, nc, h, w, H, W,
-                                ctx.ignore, L.stream())
+        # soft-max gradient formed inside the Y pass of the separable bilinear backward: the (B, nc, H, W) gradient
+        # (352 MB at 16 x 21 x 512 x 512) is never written (csrc/losses.hip seg_loss_bwd_y_kernel)
         tmp = torch.empty(B * nc * h * W, device=seg.device, dtype=torch.float32)
-        L.lib().wc_bilinear_resize_bwd(L.ptr(ghr), L.ptr(out), L.ptr(tmp), B * nc, h, w, H, W, 0, L.stream())
+        L.lib().wc_seg_loss_bwd_fused(L.ptr(seg), L.ptr(label), L.ptr(wts, torch.float32, "wts"), L.ptr(tmp), L.ptr(out), B, nc,
+                                      h, w, H, W, ctx.ignore, L.stream())
         return out, None, None
 
 
