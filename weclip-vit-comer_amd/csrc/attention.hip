@@ -390,7 +390,7 @@ __device__ __forceinline__ void attn_mean_edge_body(const __half* __restrict__ q
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int DH>
+template <int DH, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void attn_mean_kernel(const __half* __restrict__ qkv,
                                                          const float* __restrict__ lse,
                                                          float* __restrict__ mean, int L, int H, int E, int origin,
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void attn_mean_kernel(const __half* __restr
     __syncthreads();
     for (int h = 0; h < H; ++h) {
         const int buf = h & 1;
-        if (h + 1 < H) GLOAD(h + 1);
+        if (h + 1 < H && ABL != 3) GLOAD(h + 1);
         const char* qb = smem + buf * BUF;
         const float* ls = reinterpret_cast<const float*>(qb + 2 * TB);
         f32x16 s[2][2];
@@ -492,6 +492,7 @@ __global__ __launch_bounds__(256, 2) void attn_mean_kernel(const __half* __restr
             const f16x8 a1 = *reinterpret_cast<const f16x8*>(As + 32 * ROW + ks * 32);
             const f16x8 b0 = *reinterpret_cast<const f16x8*>(Bs + ks * 32);
             const f16x8 b1 = *reinterpret_cast<const f16x8*>(Bs + 32 * ROW + ks * 32);
+            if (ABL == 2) { s[0][0][ks] += a0[0]; s[0][1][ks] += b0[0]; s[1][0][ks] += a1[0]; s[1][1][ks] += b1[0]; continue; }
             s[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, s[0][0], 0, 0, 0);
             s[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, s[0][1], 0, 0, 0);
             s[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, s[1][0], 0, 0, 0);
@@ -503,10 +504,10 @@ __global__ __launch_bounds__(256, 2) void attn_mean_kernel(const __half* __restr
             for (int ni = 0; ni < 2; ++ni) {
                 f32x16 pv;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[mi][ni][r]);
+                for (int r = 0; r < 16; ++r) pv[r] = ABL == 1 ? s[mi][ni][r] : __builtin_amdgcn_exp2f(s[mi][ni][r]);
                 acc[mi][ni] += pv;       // vector add: v_pk_add_f32
             }
-        if (h + 1 < H) LSTORE(buf ^ 1);
+        if (h + 1 < H && ABL != 3) LSTORE(buf ^ 1);
         __syncthreads();
     }
     const float invh = 1.0f / H;
@@ -579,7 +580,16 @@ extern "C" int wc_attn_mean(const void* qkv, const float* lse, float* mean, int 
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = DH == 64 ? 2 * (2 * 128 * (64 * 2 + 16) + 512) : 2 * (2 * 128 * (32 * 2 + 16) + 512);
     const int pr = wc_prof_begin(stream);
-    if (DH == 64)
+    static const int abl = getenv("WECLIP_MEAN_ABL") ? atoi(getenv("WECLIP_MEAN_ABL")) : 0;
+    if (DH == 64 && abl == 1)
+        hipLaunchKernelGGL((attn_mean_kernel<64, 1>), grid, dim3(256), lds, st, (const __half*)qkv, lse, mean, L, H, E, r, nt, B);
+    else if (DH == 64 && abl == 2)
+        hipLaunchKernelGGL((attn_mean_kernel<64, 2>), grid, dim3(256), lds, st, (const __half*)qkv, lse, mean, L, H, E, r, nt, B);
+    else if (DH == 64 && abl == 3)
+        hipLaunchKernelGGL((attn_mean_kernel<64, 3>), grid, dim3(256), lds, st, (const __half*)qkv, lse, mean, L, H, E, r, nt, B);
+    else if (DH == 64 && abl == 4)
+        hipLaunchKernelGGL((attn_mean_kernel<64, 0>), dim3(nt * nt * ((B + 7) / 8 * 8)), dim3(256), lds, st, (const __half*)qkv, lse, mean, L, H, E, r, nt, B);
+    else if (DH == 64)
         hipLaunchKernelGGL(attn_mean_kernel<64>, grid, dim3(256), lds, st, (const __half*)qkv, lse, mean, L, H, E, r, nt, B);
     else
         hipLaunchKernelGGL(attn_mean_kernel<32>, grid, dim3(256), lds, st, (const __half*)qkv, lse, mean, L, H, E, r, nt, B);
