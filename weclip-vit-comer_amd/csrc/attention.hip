@@ -10,9 +10,10 @@
 //   attn_mean_kernel : mean_h P_h = (1/H) sum_h exp2(Q_h K_h^T - LSE_h) for a 128x128 tile,
 //                      the H-head sum held in MFMA accumulators, written once, coalesced
 //                      (the returned `attn_output_weights.sum(dim=1) / num_heads`).
-//   attn_row_body / attn_mean_edge_body (extra workgroups of the two kernels above): the first L % 128 query rows (and key columns) when that
-//                      remainder is tiny (the CLS token of a 1 + 32*32 sequence): a 129th row must not cost
-//                      a whole 128-row tile, so the tiled kernels start at row L % 128 and these finish the rest.
+//   attn_row_body (extra workgroups of attn_fwd_kernel) / the edge part of attn_mean_kernel: the first L % 128 query
+//                      rows (and key columns) when that remainder is tiny (the CLS token of a 1 + 32*32 sequence): a
+//                      129th row must not cost a whole 128-row tile, so the tiled work starts at row L % 128; the mean
+//                      kernel's first tile row / column take the edge entries from the tiles they hold in LDS.
 // V stays row-major [key][dh] (as the in-projection wrote it); the O^T = V^T P^T fragments (8 consecutive keys
 // of one dh column) come from gfx950's transposing LDS read ds_read_b64_tr_b16 -- no V^T copy in HBM.
 //
@@ -28,6 +29,7 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define NEG_BIG (-1.0e30f)
@@ -115,6 +117,7 @@ __device__ __forceinline__ void attn_row_body(const __half* __restrict__ qkv, __
 // NW waves per workgroup = NW * 32 queries per workgroup sharing one K/V stream: every K/V tile is staged once per
 // NW * 32 queries, so 8 waves (256 queries) halve the L2 -> LDS traffic of the 4-wave form (a (b, h) streams its
 // 2 x L x dh K/V bytes once per query block: 403 -> 202 MB per launch at B = 16, L = 1025), at the same waves per SIMD.
+#define ATT_EDGE_MAX 8      // largest L % 128 (mean map) / L % 64 (forward keys) remainder handled off the tiles
 template <int DH, int NW>
 __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(const __half* __restrict__ qkv,
                                                         __half* __restrict__ out,
@@ -353,44 +356,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(const __half* __re
     }
 }
 
-// mean_h P_h for the entries the origin-shifted tiles leave out: rows q < r (all keys) and columns k < r (q >= r).
-// Runs as extra workgroups of attn_mean_kernel: `blk` = edge-block index inside image b (16 entries per block).
-template <int DH>
-__device__ __forceinline__ void attn_mean_edge_body(const __half* __restrict__ qkv, const float* __restrict__ lse,
-                                                    float* __restrict__ mean, int L, int H, int E, int r, int blk, int b) {
-    // 16 lanes per entry, one head each (heads 16, 32, .. loop); the 16-lane group sums the heads
-    const int hl = threadIdx.x & 15;
-    const long e = (long)blk * 16 + (threadIdx.x >> 4);
-    const long nrow = (long)r * L;                    // entries of the first r rows
-    const long ncol = (long)r * (L - r);              // remaining entries of the first r columns
-    const bool live = e < nrow + ncol;
-    int q = 0, k = 0;
-    if (live) {
-        if (e < nrow) { q = (int)(e / L); k = (int)(e - (long)q * L); }
-        else { const long f = e - nrow; k = (int)(f / (L - r)); q = r + (int)(f - (long)k * (L - r)); }
-    }
-    const long ldq = 3L * E;
-    const __half* qr = qkv + ((long)b * L + q) * ldq;
-    const __half* kr = qkv + ((long)b * L + k) * ldq + E;
-    float acc = 0.f;
-    for (int h = hl; h < H; h += 16) {
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < DH / 8; ++c) {
-            const f16x8 a = *reinterpret_cast<const f16x8*>(qr + h * DH + c * 8);
-            const f16x8 w = *reinterpret_cast<const f16x8*>(kr + h * DH + c * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s = fmaf((float)a[j], (float)w[j], s);
-        }
-        acc += __builtin_amdgcn_exp2f(s - lse[((long)b * H + h) * L + q]);
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (live && hl == 0) mean[(long)b * L * L + (long)q * L + k] = acc / H;
-}
-
 // ------------------------------------------------------------------------------------------------
-template <int DH, int ABL = 0>
+template <int DH, int R>
 __global__ __launch_bounds__(256, 2) void attn_mean_kernel(const __half* __restrict__ qkv,
                                                          const float* __restrict__ lse,
                                                          float* __restrict__ mean, int L, int H, int E, int origin,
@@ -400,22 +367,16 @@ __global__ __launch_bounds__(256, 2) void attn_mean_kernel(const __half* __restr
     constexpr int TB = 128 * ROW;        // bytes of one 128-row operand tile
     constexpr int CH = DH / 8;           // 16-B chunks per row
     constexpr int NC = 128 * CH / 256;   // chunks per thread per operand (4 for DH=64, 2 for 32)
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][Q tile | K tile | lse 128 f32]
-    constexpr int BUF = 2 * TB + 512;
+    // [2][Q tile | K tile | lse 128 f32 | edge: q_e (R rows of DH halves) | k_e (R rows) | lse_e (R f32, padded to 32 B)]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int EDGE = 2 * TB + 512;                  // byte offset of the edge area inside a buffer
+    constexpr int BUF = EDGE + (R > 0 ? 2 * R * DH * 2 + 32 : 0);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, l31 = lane & 31;
     const int wr = wave >> 1, wc = wave & 1;
     // XCD-aware order (see attn_fwd_kernel): one XCD walks all tiles of an image, so that image's Q and K
     // (2 x L x E halves, ~3 MB) stay in its L2 across the nt x nt tiles
-    const int main_blocks = nt * nt * ((Bn + 7) / 8 * 8);
-    if ((int)blockIdx.x >= main_blocks) {        // edge entries (rows / columns < origin), 16 per workgroup
-        const long nedge = (long)origin * L + (long)origin * (L - origin);
-        const int per_img = (int)((nedge + 15) / 16);
-        const int e = blockIdx.x - main_blocks;
-        attn_mean_edge_body<DH>(qkv, lse, mean, L, H, E, origin, e % per_img, e / per_img);
-        return;
-    }
     const int slot = blockIdx.x >> 3;
     const int b = (slot / (nt * nt)) * 8 + (blockIdx.x & 7);
     if (b >= Bn) return;
@@ -424,7 +385,19 @@ __global__ __launch_bounds__(256, 2) void attn_mean_kernel(const __half* __restr
     const long ldq = 3L * E;
     const __half* base = qkv + (long)b * L * ldq;
 
-    u32x4 rq[NC], rk[NC];
+    // Edge entries (rows / columns < origin, the CLS token of 1 + 32*32): the workgroups of the first tile row / column
+    // take them from the K / Q tile they already hold in LDS -- threads 0..127 one key each (all edge rows), threads
+    // 128..255 one query each (all edge columns); the edge rows' own q / k / LSE of the current head travel with the
+    // tiles (one 16-B chunk per thread of the first 2 * origin * CH threads).  R = compiled edge capacity: 0 (origin
+    // == 0), 1 (the CLS-token case) or ATT_EDGE_MAX; the origin x origin corner is finished after the loop.
+    const bool edge_wg = R > 0 && (q0 == origin || k0 == origin);
+    const bool edge_row = R > 0 && q0 == origin && tid < 128;
+    const bool edge_col = R > 0 && k0 == origin && tid >= 128;
+    const int e_which = tid / (origin * CH > 0 ? origin * CH : 1);         // 0: q_e chunk, 1: k_e chunk, >= 2: none
+    const int e_rem = tid - e_which * origin * CH;
+    const __half* e_src = base + (long)(e_rem / CH) * ldq + (e_which ? E : 0) + (e_rem % CH) * 8;
+    const int e_dst = EDGE + (e_which * R * CH + e_rem) * 16;
+    u32x4 rq[NC], rk[NC], re = {0u, 0u, 0u, 0u};
     float rl = 0.f;
 #undef GLOAD
 #define GLOAD(h_) \
@@ -444,6 +417,11 @@ __global__ __launch_bounds__(256, 2) void attn_mean_kernel(const __half* __restr
             if (qr > L - 1) qr = L - 1; \
             rl = lse[((long)b * H + h__) * L + qr]; \
         } \
+        if constexpr (R > 0) \
+            if (edge_wg) { \
+                if (e_which < 2) re = *reinterpret_cast<const u32x4*>(e_src + h__ * DH); \
+                if (tid >= 128 && tid < 128 + origin) rl = lse[((long)b * H + h__) * L + tid - 128]; \
+            } \
     }
 #undef LSTORE
 #define LSTORE(buf_) \
@@ -457,6 +435,11 @@ __global__ __launch_bounds__(256, 2) void attn_mean_kernel(const __half* __restr
             *reinterpret_cast<u32x4*>(qb + TB + (c / CH) * ROW + (c % CH) * 16) = rk[i]; \
         } \
         if (tid < 128) reinterpret_cast<float*>(qb + 2 * TB)[tid] = rl; \
+        if constexpr (R > 0) \
+            if (edge_wg) { \
+                if (e_which < 2) *reinterpret_cast<u32x4*>(qb + e_dst) = re; \
+                if (tid >= 128 && tid < 128 + origin) reinterpret_cast<float*>(qb + EDGE + 2 * R * DH * 2)[tid - 128] = rl; \
+            } \
     }
 
     f32x16 acc[2][2];
@@ -466,24 +449,43 @@ __global__ __launch_bounds__(256, 2) void attn_mean_kernel(const __half* __restr
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // -LSE enters the scores through one more MFMA k-step instead of 64 accumulator moves per head: the Q side carries
+    // (-lse_hi, -lse_lo, 0, ...) (two fp16 that sum to -LSE to 2^-22 relative), the K side (1, 1, 0, ...).
+    f16x8 b_aug;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b_aug[j] = (_Float16)((hh == 0 && j < 2) ? 1.0f : 0.0f);
+    float eacc[R > 0 ? R : 1];
+#pragma unroll
+    for (int e = 0; e < (R > 0 ? R : 1); ++e) eacc[e] = 0.f;
 
     GLOAD(0);
     LSTORE(0);
     __syncthreads();
     for (int h = 0; h < H; ++h) {
         const int buf = h & 1;
-        if (h + 1 < H && ABL != 3) GLOAD(h + 1);
+        if (h + 1 < H) GLOAD(h + 1);
         const char* qb = smem + buf * BUF;
         const float* ls = reinterpret_cast<const float*>(qb + 2 * TB);
+        f16x8 a_aug[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const float nl = -ls[wr * 64 + mi * 32 + l31];
+            const _Float16 hi = (_Float16)nl;
+            const _Float16 lo = (_Float16)(nl - (float)hi);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a_aug[mi][j] = (_Float16)0.0f;
+            if (hh == 0) { a_aug[mi][0] = hi; a_aug[mi][1] = lo; }
+        }
         f32x16 s[2][2];
+        {
+            f32x16 zero;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float nl = -ls[wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh];
-                s[mi][0][r] = nl;
-                s[mi][1][r] = nl;
-            }
+            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+            s[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_aug[0], b_aug, zero, 0, 0, 0);
+            s[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_aug[0], b_aug, zero, 0, 0, 0);
+            s[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_aug[1], b_aug, zero, 0, 0, 0);
+            s[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_aug[1], b_aug, zero, 0, 0, 0);
+        }
         const char* As = qb + (wr * 64 + l31) * ROW + hh * 16;
         const char* Bs = qb + TB + (wc * 64 + l31) * ROW + hh * 16;
 #pragma unroll
@@ -492,7 +494,6 @@ __global__ __launch_bounds__(256, 2) void attn_mean_kernel(const __half* __restr
             const f16x8 a1 = *reinterpret_cast<const f16x8*>(As + 32 * ROW + ks * 32);
             const f16x8 b0 = *reinterpret_cast<const f16x8*>(Bs + ks * 32);
             const f16x8 b1 = *reinterpret_cast<const f16x8*>(Bs + 32 * ROW + ks * 32);
-            if (ABL == 2) { s[0][0][ks] += a0[0]; s[0][1][ks] += b0[0]; s[1][0][ks] += a1[0]; s[1][1][ks] += b1[0]; continue; }
             s[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, s[0][0], 0, 0, 0);
             s[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, s[0][1], 0, 0, 0);
             s[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, s[1][0], 0, 0, 0);
@@ -501,13 +502,38 @@ __global__ __launch_bounds__(256, 2) void attn_mean_kernel(const __half* __restr
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                f32x16 pv;
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) pv[r] = ABL == 1 ? s[mi][ni][r] : __builtin_amdgcn_exp2f(s[mi][ni][r]);
-                acc[mi][ni] += pv;       // vector add: v_pk_add_f32
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] += __builtin_amdgcn_exp2f(s[mi][ni][r]);
+        if constexpr (R > 0)
+        if (edge_row || edge_col) {            // wave-uniform
+            // own operand row (a key for the row edge, a query for the column edge) against the edge rows' q / k of
+            // this head: both from LDS (the latter broadcast reads)
+            const int t = tid & 127;
+            const char* own = qb + (edge_row ? TB : 0) + t * ROW;
+            const char* oth = qb + EDGE + (edge_row ? 0 : R * DH * 2);
+            float sd[R];
+#pragma unroll
+            for (int e = 0; e < R; ++e) sd[e] = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const f16x8 ov = *reinterpret_cast<const f16x8*>(own + c * 16);
+#pragma unroll
+                for (int e = 0; e < R; ++e)
+                    if (R == 1 || e < origin) {
+                        const f16x8 xv = *reinterpret_cast<const f16x8*>(oth + e * DH * 2 + c * 16);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            sd[e] = __builtin_amdgcn_fdot2(f16x2{xv[2 * j], xv[2 * j + 1]}, f16x2{ov[2 * j], ov[2 * j + 1]}, sd[e], false);
+                    }
             }
-        if (h + 1 < H && ABL != 3) LSTORE(buf ^ 1);
+            const float own_lse = ls[t];      // the query's LSE (column edge)
+            const float* els = reinterpret_cast<const float*>(qb + EDGE + 2 * R * DH * 2);
+#pragma unroll
+            for (int e = 0; e < R; ++e)
+                if (R == 1 || e < origin) eacc[e] += __builtin_amdgcn_exp2f(sd[e] - (edge_row ? els[e] : own_lse));
+        }
+        if (h + 1 < H) LSTORE(buf ^ 1);
         __syncthreads();
     }
     const float invh = 1.0f / H;
@@ -524,11 +550,38 @@ __global__ __launch_bounds__(256, 2) void attn_mean_kernel(const __half* __restr
                 if (q < L) mb[(long)q * L + key] = acc[mi][ni][r] * invh;
             }
         }
+    if constexpr (R > 0)
+    if (edge_row || edge_col) {
+        const int t = tid & 127;
+#pragma unroll
+        for (int e = 0; e < R; ++e)
+            if (R == 1 || e < origin) {
+                if (edge_row) { if (k0 + t < L) mb[(long)e * L + k0 + t] = eacc[e] * invh; }
+                else if (q0 + t < L) mb[(long)(q0 + t) * L + e] = eacc[e] * invh;
+            }
+    }
+    if (R > 0 && q0 == origin && k0 == origin && tid < origin * origin) {      // the origin x origin corner
+        const int qe = tid / origin, ke = tid - qe * origin;
+        float a = 0.f;
+        for (int h = 0; h < H; ++h) {
+            const __half* qr = base + (long)qe * ldq + h * DH;
+            const __half* kr = base + (long)ke * ldq + E + h * DH;
+            float sd = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const f16x8 xv = *reinterpret_cast<const f16x8*>(qr + c * 8);
+                const f16x8 kv = *reinterpret_cast<const f16x8*>(kr + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sd = fmaf((float)xv[j], (float)kv[j], sd);
+            }
+            a += __builtin_amdgcn_exp2f(sd - lse[((long)b * H + h) * L + qe]);
+        }
+        mb[(long)qe * L + ke] = a * invh;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// A remainder of at most ATT_EDGE_MAX rows (L % 128) is finished by the row kernels; the tiles then start at it.
-#define ATT_EDGE_MAX 8
+// A remainder of at most ATT_EDGE_MAX rows (L % 128) is finished by the row / edge paths; the tiles then start at it.
 static int attn_origin(int L) {
     const int r = L % 128;
     return (L >= 128 && r > 0 && r <= ATT_EDGE_MAX) ? r : 0;
@@ -575,24 +628,28 @@ extern "C" int wc_attn_mean(const void* qkv, const float* lse, float* mean, int 
     WC_CHECK_ARG(DH == 64 || DH == 32, "wc_attn_mean: head dim must be 32 or 64 (got %d)", DH);
     const int r = attn_origin(L);
     const int nt = wc_cdiv(L - r, 128);
-    const long nedge = (long)r * L + (long)r * (L - r);
-    dim3 grid((unsigned)(nt * nt * ((B + 7) / 8 * 8) + wc_cdiv(nedge, 16) * B));
+    dim3 grid((unsigned)(nt * nt * ((B + 7) / 8 * 8)));
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = DH == 64 ? 2 * (2 * 128 * (64 * 2 + 16) + 512) : 2 * (2 * 128 * (32 * 2 + 16) + 512);
+    const int rcap = r == 0 ? 0 : (r == 1 ? 1 : ATT_EDGE_MAX);
+    const size_t lds = 2 * ((size_t)2 * 128 * (DH * 2 + 16) + 512 + (rcap ? 2 * rcap * DH * 2 + 32 : 0));   // 2 x BUF of the kernel
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {         // more than 64 KiB of dynamic LDS
+#define WC_MEAN_ATTR(DH_, R_) \
+    (hipFuncSetAttribute((const void*)attn_mean_kernel<DH_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess)
+        WC_CHECK_ARG(WC_MEAN_ATTR(64, 0) && WC_MEAN_ATTR(64, 1) && WC_MEAN_ATTR(64, ATT_EDGE_MAX) && WC_MEAN_ATTR(32, 0) &&
+                     WC_MEAN_ATTR(32, 1) && WC_MEAN_ATTR(32, ATT_EDGE_MAX), "wc_attn_mean: cannot reserve 80 KiB of LDS");
+#undef WC_MEAN_ATTR
+        lds_attr_set = true;
+    }
     const int pr = wc_prof_begin(stream);
-    static const int abl = getenv("WECLIP_MEAN_ABL") ? atoi(getenv("WECLIP_MEAN_ABL")) : 0;
-    if (DH == 64 && abl == 1)
-        hipLaunchKernelGGL((attn_mean_kernel<64, 1>), grid, dim3(256), lds, st, (const __half*)qkv, lse, mean, L, H, E, r, nt, B);
-    else if (DH == 64 && abl == 2)
-        hipLaunchKernelGGL((attn_mean_kernel<64, 2>), grid, dim3(256), lds, st, (const __half*)qkv, lse, mean, L, H, E, r, nt, B);
-    else if (DH == 64 && abl == 3)
-        hipLaunchKernelGGL((attn_mean_kernel<64, 3>), grid, dim3(256), lds, st, (const __half*)qkv, lse, mean, L, H, E, r, nt, B);
-    else if (DH == 64 && abl == 4)
-        hipLaunchKernelGGL((attn_mean_kernel<64, 0>), dim3(nt * nt * ((B + 7) / 8 * 8)), dim3(256), lds, st, (const __half*)qkv, lse, mean, L, H, E, r, nt, B);
-    else if (DH == 64)
-        hipLaunchKernelGGL(attn_mean_kernel<64>, grid, dim3(256), lds, st, (const __half*)qkv, lse, mean, L, H, E, r, nt, B);
-    else
-        hipLaunchKernelGGL(attn_mean_kernel<32>, grid, dim3(256), lds, st, (const __half*)qkv, lse, mean, L, H, E, r, nt, B);
+#define WC_MEAN_LAUNCH(DH_, R_) \
+    hipLaunchKernelGGL((attn_mean_kernel<DH_, R_>), grid, dim3(256), lds, st, (const __half*)qkv, lse, mean, L, H, E, r, nt, B)
+    if (DH == 64) {
+        if (r == 0) WC_MEAN_LAUNCH(64, 0); else if (r == 1) WC_MEAN_LAUNCH(64, 1); else WC_MEAN_LAUNCH(64, ATT_EDGE_MAX);
+    } else {
+        if (r == 0) WC_MEAN_LAUNCH(32, 0); else if (r == 1) WC_MEAN_LAUNCH(32, 1); else WC_MEAN_LAUNCH(32, ATT_EDGE_MAX);
+    }
+#undef WC_MEAN_LAUNCH
     wc_prof_end(pr, DH == 64 ? "attn_mean_kernel<64>" : "attn_mean_kernel<32>", 2.0 * B * H * (double)L * L * DH, stream);
     WC_LAUNCH_CHECK("attn_mean_kernel");
     return WC_OK;
