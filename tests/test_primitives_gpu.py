@@ -137,6 +137,33 @@ def test_gemm_ragged_rows_split(ops):
     assert _rel(out.cpu().double(), ref4) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(16, 3072, 768), (32, 768, 3072), (5, 300, 192)])
+def test_gemm_few_rows(ops, M, N, K):
+    """M <= 32 rows against N >= 256 weight rows take the K-split kernel without LDS staging (the ragged rows of the tall
+    encoder GEMMs): plain, QuickGELU + residual + hi/lo outputs, three K-segments (split precision), ragged N."""
+    g = torch.Generator().manual_seed(M * N)
+    a = torch.randn(M, K, generator=g).half()
+    w = (torch.randn(N, K, generator=g) * 0.05).half()
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ref = a.double() @ w.double().t() + bias.double()
+    out = torch.zeros(M, N, device="cuda")
+    ops.gemm(a.cuda(), w.cuda(), M, N, K, bias=bias.cuda(), out32=out)
+    assert _rel(out.cpu().double(), ref) < 2e-6
+    hi = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+    lo = torch.zeros_like(hi)
+    ops.gemm(a.cuda(), w.cuda(), M, N, K, bias=bias.cuda(), resid=res.cuda(), out32=out, out16=hi, out16lo=lo, act=1)
+    ref2 = ref * torch.sigmoid(1.702 * ref) + res.double()
+    assert _rel(out.cpu().double(), ref2) < 2e-6
+    assert _rel((hi.float() + lo.float()).cpu().double(), ref2) < 2e-6
+    ops.gemm(a.cuda(), w.cuda(), M, N, K, bias=bias.cuda(), out16=hi)           # fp16-only output: the wide epilogue
+    assert _rel(hi.float().cpu().double(), ref) < 1e-3
+    x = torch.randn(M, K, generator=g)
+    w32 = torch.randn(N, K, generator=g) * 0.04
+    ops.gemm(ops.split_f16(x.cuda(), True), ops.split_f16(w32.cuda(), True), M, N, K, out32=out)
+    assert _rel(out.cpu().double(), x.double() @ w32.double().t()) < 5e-6
+
+
 def test_gemm_grouped_two_level_batch(ops):
     """wc_gemm_f16_grouped: batch index z = group * zdiv + member.  (a) groups x members with per-group weights / biases
     and outputs written side by side (the adapters' first Linear: blocks x images); (b) groups only, A taken as column

@@ -341,9 +341,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
 // rows), so bank conflicts are avoided by an XOR swizzle carried on the per-lane GLOBAL source address:
 // physical 16-B chunk pc of row r holds logical chunk pc ^ ((r >> 1) & 7); fragment reads apply the same
 // XOR (16 consecutive rows then cover all 64 banks exactly once per ds_read_b128 lane group).
-template <bool AUX>
+// NST = 2: two stages, one in flight, two workgroups per CU hide each other's load latency (grids of many tiles).
+// NST = 4: a ring of four stages, three in flight behind counted vmcnt waits and raw s_barriers, 128 KiB: for grids of
+// at most one workgroup per CU, where the 2-stage loop runs at one global-memory latency per 64-deep K-tile.
+template <bool AUX, int NST>
 __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A tile 16 KiB | W tile 16 KiB]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [NST stages][A tile 16 KiB | W tile 16 KiB]
     constexpr int TILE = BM * BK * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -415,16 +418,9 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
 
     float bv[2], sc[2];
     gemm_colvals(g, n0, wc, lane, zb, bv, sc, z2 * g.sB2);
-    GLDS(0, 0);
-    __syncthreads();     // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) GLDS(t + 1, buf ^ 1);
-        const char* As = smem + buf * (2 * TILE);
-        const char* Ws = As + TILE;
-        // software-pipelined fragment reads: the ds_reads of k-step ks+1 are issued before the MFMAs of
-        // ks (the compiler otherwise parks the wave on lgkmcnt(0) in front of every MFMA group)
-        f16x8 fa0, fa1, fb0, fb1, na0, na1, nb0, nb1;
+    // software-pipelined fragment reads: the ds_reads of k-step ks+1 are issued before the MFMAs of
+    // ks (the compiler otherwise parks the wave on lgkmcnt(0) in front of every MFMA group);
+    // sched_barrier(0) pins the issue order (hipcc otherwise sinks the reads back in front of their use)
 #define FRAG_LOAD(ks_, a0_, a1_, b0_, b1_)                                                           \
         {                                                                                            \
             const int ch_ = 2 * (ks_) + hh;                                                          \
@@ -440,27 +436,128 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_, b0_, acc[1][0], 0, 0, 0);        \
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_, b1_, acc[1][1], 0, 0, 0);        \
         }
-        // sched_barrier(0) pins the issue order (hipcc otherwise sinks the reads back in front of their use)
-        FRAG_LOAD(0, fa0, fa1, fb0, fb1);
-        FRAG_LOAD(1, na0, na1, nb0, nb1);
-        __builtin_amdgcn_sched_barrier(0);
-        FRAG_MMA(fa0, fa1, fb0, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        FRAG_LOAD(2, fa0, fa1, fb0, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        FRAG_MMA(na0, na1, nb0, nb1);
-        __builtin_amdgcn_sched_barrier(0);
-        FRAG_LOAD(3, na0, na1, nb0, nb1);
-        __builtin_amdgcn_sched_barrier(0);
-        FRAG_MMA(fa0, fa1, fb0, fb1);
-        FRAG_MMA(na0, na1, nb0, nb1);
-        __builtin_amdgcn_sched_barrier(0);
+#define STAGE_MMA(buf_)                                                                              \
+    {                                                                                                \
+        const char* As = smem + (buf_) * (2 * TILE);                                                 \
+        const char* Ws = As + TILE;                                                                  \
+        f16x8 fa0, fa1, fb0, fb1, na0, na1, nb0, nb1;                                                \
+        FRAG_LOAD(0, fa0, fa1, fb0, fb1);                                                            \
+        FRAG_LOAD(1, na0, na1, nb0, nb1);                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        FRAG_MMA(fa0, fa1, fb0, fb1);                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        FRAG_LOAD(2, fa0, fa1, fb0, fb1);                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        FRAG_MMA(na0, na1, nb0, nb1);                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        FRAG_LOAD(3, na0, na1, nb0, nb1);                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        FRAG_MMA(fa0, fa1, fb0, fb1);                                                                \
+        FRAG_MMA(na0, na1, nb0, nb1);                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+    }
+    if constexpr (NST == 2) {
+        GLDS(0, 0);
+        __syncthreads();     // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < nt) GLDS(t + 1, buf ^ 1);
+            STAGE_MMA(buf);
+            __syncthreads();
+        }
+    } else {
+#pragma unroll
+        for (int s_ = 0; s_ < NST - 1; ++s_)
+            if (s_ < nt) GLDS(s_, s_);
+        int buf = 0, nbuf = NST - 1;
+        for (int t = 0; t < nt; ++t) {
+            // stage t has landed once at most the NST - 2 later requests (8 DMA instructions each) are outstanding
+            const int ahead = nt - 1 - t;
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();     // all parts of stage t are in LDS; stage t-1's buffer is free
+            if (t + NST - 1 < nt) GLDS(t + NST - 1, nbuf);
+            STAGE_MMA(buf);
+            buf = buf + 1 == NST ? 0 : buf + 1;
+            nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+        }
+        __syncthreads();                      // the epilogue reuses the ring as scratch
+    }
+#undef STAGE_MMA
 #undef FRAG_LOAD
 #undef FRAG_MMA
-        __syncthreads();
-    }
 #undef GLDS
     gemm_epilogue<AUX>(g, acc, m0, n0, wr, wc, lane, zb, smem + wave * 8192, bv, sc, z1 * g.sC + z2 * g.sC2, z2 * g.sX2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// M <= 32 rows (the ragged last rows of a tall GEMM: 16 images x 1025 tokens leave 16 rows past the last 256-row tile;
+// the 128x128 kernel ran them as N/128 workgroups, each pulling its 128 weight rows through ONE CU's ~35 GB/s miss path:
+// 17.8 us for 16 x 3072 x 768).  Here a workgroup owns 64 output columns, its four waves split K, operands go straight
+// from global memory to MFMA fragments (no LDS: nothing is shared between waves), all loads of a chunk of 12 k-steps in
+// flight at once; the four partial tiles meet in LDS and wave 0 runs the shared epilogue.
+template <bool AUX>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float red[3 * 32 * 64];      // partial tiles of waves 1..3: [wave-1][reg][lane]
+    __shared__ __attribute__((aligned(16))) char scr[8192];              // epilogue scratch of wave 0
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hh = lane >> 5, l31 = lane & 31;
+    const int n0 = blockIdx.x * 64;
+    const int arow = l31 < g.M ? l31 : g.M - 1;
+    int wrow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        wrow[j] = n0 + j * 32 + l31;
+        if (wrow[j] > g.N - 1) wrow[j] = g.N - 1;
+    }
+    const int per = g.K / 64;                    // k-steps (of 16) per wave; K % 64 == 0
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bv[2], sc[2];
+    if (wave == 0) gemm_colvals(g, n0, 0, lane, 0, bv, sc, 0);
+    for (int seg = 0; seg < g.nseg; ++seg) {
+        const __half* Ap = (seg == 0 ? g.A[0] : (seg == 1 ? g.A[1] : g.A[2])) + (long)arow * g.lda + (long)wave * per * 16 + hh * 8;
+        const __half* Wb = seg == 0 ? g.W[0] : (seg == 1 ? g.W[1] : g.W[2]);
+        const __half* Wp0 = Wb + (long)wrow[0] * g.ldw + (long)wave * per * 16 + hh * 8;
+        const __half* Wp1 = Wb + (long)wrow[1] * g.ldw + (long)wave * per * 16 + hh * 8;
+        for (int ks0 = 0; ks0 < per; ks0 += 12) {
+            f16x8 fa[12], fb0[12], fb1[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (ks0 + i < per) {
+                    fa[i] = *reinterpret_cast<const f16x8*>(Ap + (ks0 + i) * 16);
+                    fb0[i] = *reinterpret_cast<const f16x8*>(Wp0 + (ks0 + i) * 16);
+                    fb1[i] = *reinterpret_cast<const f16x8*>(Wp1 + (ks0 + i) * 16);
+                }
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (ks0 + i < per) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb0[i], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb1[i], acc[0][1], 0, 0, 0);
+                }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave - 1) * 32 + j * 16 + r) * 64 + lane] = acc[0][j][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][j][r] += red[(w * 32 + j * 16 + r) * 64 + lane];
+    gemm_epilogue<AUX>(g, acc, 0, n0, 0, 0, lane, 0, scr, bv, sc, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -705,7 +802,9 @@ struct KmArgs {
     int mslice;           // tokens per slice (multiple of 64)
     int bias;
     int gx;
-    long gA, gX, gP;      // group (blockIdx.y) strides of dY, X and the partials, in elements
+    int tiles, ns, units; // output tiles per (group, slice) unit, slices per group, units = groups * ns
+    int xcd;              // XCD-aware workgroup order (units % 8 == 0)
+    long gA, gX, gP;      // group strides of dY, X and the partials, in elements
     GemmArgs e;           // epilogue: M = N, N = K + bias, C32 = partials, ldc, sC
 };
 
@@ -713,24 +812,43 @@ typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
 
 __global__ __launch_bounds__(256, 2) void gemm_km_kernel(KmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A tile 16 KiB | X tile 16 KiB]
-    constexpr int TILE = 64 * 256;
+    // ring of 4 stages x [32 tokens]: [A tile 8 KiB | X tile 8 KiB]; three stages in flight while one is consumed,
+    // counted vmcnt waits + raw s_barrier (a __syncthreads() drains every outstanding LDS-DMA: with 2 stages of 64
+    // tokens the loop ran at one global-memory latency per stage)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = 32 * 256;
+    constexpr int ST = 32;                // tokens per stage
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int ty = blockIdx.x / g.gx, tx = blockIdx.x - ty * g.gx;
+    // XCD-aware order: workgroup ids go round-robin over the 8 XCDs, so unit u (= one token slice of one group, whose
+    // `tiles` workgroups all read the same dY / X rows) takes the ids congruent to u mod 8 of its block of 8 units:
+    // the slice's operands (~2-3 MB) are fetched into ONE 4-MiB L2 instead of all eight (33 -> 36 us at N 256, K 1024,
+    // 16 slices).  Only when the units divide evenly over the XCDs: 33 units of 14 long tiles (the grouped adapters)
+    // would put 70 workgroups on the first XCD's 64 slots and run two rounds there (173 -> 265 us).
+    int unit, tile;
+    if (g.xcd) {
+        const int chunk = blockIdx.x / (8 * g.tiles), within = blockIdx.x - chunk * (8 * g.tiles);
+        unit = chunk * 8 + (within & 7);
+        tile = within >> 3;
+    } else {
+        unit = blockIdx.x / g.tiles;
+        tile = blockIdx.x - unit * g.tiles;
+    }
+    const int grp = unit / g.ns;
+    const int z = unit - grp * g.ns;
+    const int ty = tile / g.gx, tx = tile - ty * g.gx;
     const int n0 = ty * 128, k0 = tx * 128;
-    const int z = blockIdx.z;
-    const __half* Ag = g.A + (long)blockIdx.y * g.gA;      // group (e.g. adapter) of a grouped launch
-    const __half* Xg = g.X + (long)blockIdx.y * g.gX;
+    const __half* Ag = g.A + (long)grp * g.gA;      // group (e.g. adapter) of a grouped launch
+    const __half* Xg = g.X + (long)grp * g.gX;
     const int mbeg = z * g.mslice;
     const int mend = (mbeg + g.mslice < g.M) ? mbeg + g.mslice : g.M;
-    const int nt = (mend - mbeg + 63) / 64;
+    const int nt = (mend - mbeg + ST - 1) / ST;
 
     // DMA bookkeeping: chunk q = i*256 + tid -> tile row q>>4 (token), physical chunk q&15
-    int rowi[4], acol[4], xcol[4], xg[4], xr[4];
-    bool aok[4], xok[4];
+    int rowi[2], acol[2], xcol[2], xg[2], xr[2];
+    bool aok[2], xok[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2; ++i) {
         const int q = i * 256 + tid;
         const int row = q >> 4, pc = q & 15;
         const int lc = pc ^ (((row & 3) << 2) | ((row >> 2) & 3));
@@ -748,14 +866,14 @@ __global__ __launch_bounds__(256, 2) void gemm_km_kernel(KmArgs g) {
 #define KM_LOAD(t_, buf_)                                                                                       \
     {                                                                                                            \
         char* dst_ = smem + (buf_) * (2 * TILE) + wave * 1024;                                                   \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
-            const int m_ = mbeg + (t_) * 64 + rowi[i];                                                           \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
+            const int m_ = mbeg + (t_) * ST + rowi[i];                                                           \
             const bool in_ = m_ < mend;                                                                          \
             const __half* pa_ = (in_ && aok[i]) ? Ag + (long)m_ * g.lda + acol[i] : g.zeros;                     \
             const __half* px_ = (in_ && xok[i]) ? Xg + ((long)xg[i] * g.x_gs + xr[i] + g.x_off) * g.ldx + xcol[i] : g.zeros; \
             __builtin_amdgcn_global_load_lds((gbl_ptr)pa_, (lds_ptr)(dst_ + i * 4096), 16, 0, 0);                \
             __builtin_amdgcn_global_load_lds((gbl_ptr)px_, (lds_ptr)(dst_ + TILE + i * 4096), 16, 0, 0);         \
-            xr[i] += 64;                                                                                         \
+            xr[i] += ST;                                                                                         \
             while (xr[i] >= g.x_rpg) { xr[i] -= g.x_rpg; xg[i] += 1; }                                           \
         }                                                                                                        \
     }
@@ -774,11 +892,9 @@ __global__ __launch_bounds__(256, 2) void gemm_km_kernel(KmArgs g) {
             baddr[t][r] = 256 * row + 16 * (chb ^ f) + 8 * (p & 1);
         }
     }
-    typedef __attribute__((address_space(3))) s16x4* tr_ptr;
-#define KM_FRAG(base_, off_)                                                                                     \
-    __builtin_bit_cast(f16x8, __builtin_shufflevector(                                                           \
-        __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)((base_) + (off_)[0])),                                  \
-        __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)((base_) + (off_)[1])), 0, 1, 2, 3, 4, 5, 6, 7))
+    const unsigned lbase = (unsigned)(size_t)(lds_ptr)smem;        // LDS byte address of the ring
+#define KM_TR(dst_, addr_) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst_) : "v"(addr_))
+#define KM_JOIN(lo_, hi_) __builtin_bit_cast(f16x8, __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7))
 
     f32x16 acc[2][2], bacc[2];
 #pragma unroll
@@ -797,20 +913,43 @@ __global__ __launch_bounds__(256, 2) void gemm_km_kernel(KmArgs g) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
 
+    // KM_LOAD advances the token -> X row map, so the stages must be requested in order: 0, 1, 2, then t + 3 in the loop
     if (nt > 0) KM_LOAD(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (nt > 1) KM_LOAD(1, 1);
+    if (nt > 2) KM_LOAD(2, 2);
     for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) KM_LOAD(t + 1, buf ^ 1);
-        const char* As = smem + buf * (2 * TILE);
-        const char* Xs = As + TILE;
+        const int buf = t & 3;
+        // stage t has landed once at most the requests of stages t+1, t+2 (4 DMA instructions each) are outstanding
+        if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();     // every wave's part of stage t is in LDS; stage t-1's buffer is free
+        if (t + 3 < nt) KM_LOAD(t + 3, (t + 3) & 3);
+        // Fragment reads as inline asm: hipcc puts a full `s_waitcnt vmcnt(0)` in front of the ds_read_tr builtin
+        // whenever LDS-DMA is outstanding (it cannot tell which LDS bytes the DMA writes), which would drain the ring.
+        // Both k-steps' 16 transposing reads are issued, then one lgkmcnt(0) that carries the registers.
+        const unsigned sa = lbase + buf * (2 * TILE), sx = sa + TILE;
+        s16x4 ra[2][2][2], rb[2][2][2];           // [ks][mi / ni][half]
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const f16x8 a0 = KM_FRAG(As + ks * 4096, aaddr[0]);
-            const f16x8 a1 = KM_FRAG(As + ks * 4096, aaddr[1]);
-            const f16x8 b0 = KM_FRAG(Xs + ks * 4096, baddr[0]);
-            const f16x8 b1 = KM_FRAG(Xs + ks * 4096, baddr[1]);
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    KM_TR(ra[ks][t2][r], sa + ks * 4096 + aaddr[t2][r]);
+                    KM_TR(rb[ks][t2][r], sx + ks * 4096 + baddr[t2][r]);
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ra[0][0][0]), "+v"(ra[0][0][1]), "+v"(ra[0][1][0]), "+v"(ra[0][1][1]), "+v"(ra[1][0][0]),
+                       "+v"(ra[1][0][1]), "+v"(ra[1][1][0]), "+v"(ra[1][1][1]), "+v"(rb[0][0][0]), "+v"(rb[0][0][1]),
+                       "+v"(rb[0][1][0]), "+v"(rb[0][1][1]), "+v"(rb[1][0][0]), "+v"(rb[1][0][1]), "+v"(rb[1][1][0]),
+                       "+v"(rb[1][1][1]));
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f16x8 a0 = KM_JOIN(ra[ks][0][0], ra[ks][0][1]);
+            const f16x8 a1 = KM_JOIN(ra[ks][1][0], ra[ks][1][1]);
+            const f16x8 b0 = KM_JOIN(rb[ks][0][0], rb[ks][0][1]);
+            const f16x8 b1 = KM_JOIN(rb[ks][1][0], rb[ks][1][1]);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
@@ -820,10 +959,10 @@ __global__ __launch_bounds__(256, 2) void gemm_km_kernel(KmArgs g) {
                 bacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, ones, bacc[1], 0, 0, 0);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
-#undef KM_FRAG
+    __syncthreads();                      // the epilogue reuses the ring as scratch
+#undef KM_TR
+#undef KM_JOIN
 #undef KM_LOAD
     if (own_bias) {      // every column of bacc holds the row sums: drop them into output column K
         const int ni = kb >> 5, cl = kb & 31;
@@ -838,7 +977,7 @@ __global__ __launch_bounds__(256, 2) void gemm_km_kernel(KmArgs g) {
         }
     }
     const float bv[2] = {0.f, 0.f}, sc[2] = {1.f, 1.f};
-    gemm_epilogue<false>(g.e, acc, n0, k0, wr, wc, lane, z, smem + wave * 8192, bv, sc, (long)z * g.e.sC + (long)blockIdx.y * g.gP);
+    gemm_epilogue<false>(g.e, acc, n0, k0, wr, wc, lane, z, smem + wave * 8192, bv, sc, (long)z * g.e.sC + (long)grp * g.gP);
 }
 
 // part: (nslices, N, K + bias) fp32 with nslices = ceil(M / mslice); zeros: device buffer of >= 16 zero bytes.
@@ -879,7 +1018,10 @@ extern "C" int wc_gemm_km_f16_grouped(const void* dY, long lda, const void* X, l
     e.sCS = 0; e.gx = g.gx; e.gy = wc_cdiv(N, 128); e.vec = 0; e.auxvec = 0;
     e.zdiv = 1; e.sA2 = e.sW2 = e.sC2 = e.sB2 = e.sX2 = 0;
     g.gA = gA; g.gX = gX; g.gP = (long)ns * N * K1;
-    dim3 grid((unsigned)(g.gx * wc_cdiv(N, 128)), groups, ns);
+    g.tiles = g.gx * wc_cdiv(N, 128); g.ns = ns; g.units = groups * ns;
+    g.xcd = g.units % 8 == 0 ? 1 : 0;
+    WC_CHECK_ARG((long)g.tiles * g.units < (1L << 31), "wc_gemm_km_f16: grid too large");
+    dim3 grid((unsigned)(g.tiles * g.units));
     const int pr = wc_prof_begin(stream);
     hipLaunchKernelGGL(gemm_km_kernel, grid, dim3(256), 4 * 64 * 256, (hipStream_t)stream, g);
     wc_prof_end(pr, "gemm_km_kernel", 2.0 * M * N * K1 * groups, stream);
@@ -1071,15 +1213,43 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
         g.M = M = m_rem;
         g.gx = wc_cdiv(N, BN);
     }
+    static const int skinny_env = getenv("WECLIP_GEMM_SKINNY") ? atoi(getenv("WECLIP_GEMM_SKINNY")) : 1;
+    if (skinny_env && M <= 32 && batch == 1 && N >= 256) {      // a few rows against many weight rows
+        const int prs = wc_prof_begin(stream);
+        if (act >= 4)
+            hipLaunchKernelGGL(gemm_skinny_kernel<true>, dim3(wc_cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, g);
+        else
+            hipLaunchKernelGGL(gemm_skinny_kernel<false>, dim3(wc_cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, g);
+        wc_prof_end(prs, act >= 4 ? "gemm_skinny_kernel<true>" : "gemm_skinny_kernel<false>", 2.0 * M * N * K, stream);
+        WC_LAUNCH_CHECK("gemm_skinny_kernel");
+        return WC_OK;
+    }
     g.gy = wc_cdiv(M, BM);
     dim3 grid((unsigned)(g.gx * ((g.gy + 7) / 8 * 8)), 1, batch);
-    const size_t lds = 2 * 2 * BM * BK * 2;
+    // at most one workgroup per CU: the 4-stage ring (128 KiB); else two 2-stage workgroups per CU
+    static int n_cu128 = 0;
+    if (!n_cu128) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n_cu128, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu128 <= 0)
+            n_cu128 = 256;
+        WC_CHECK_ARG(hipFuncSetAttribute((const void*)gemm_f16_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * BM * BK * 2) == hipSuccess &&
+                     hipFuncSetAttribute((const void*)gemm_f16_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * BM * BK * 2) == hipSuccess,
+                     "wc_gemm_f16: cannot reserve 128 KiB of LDS");
+    }
+    static const int ring_env = getenv("WECLIP_GEMM_RING") ? atoi(getenv("WECLIP_GEMM_RING")) : 1;
+    const bool ring = ring_env && (long)g.gx * g.gy * batch <= n_cu128 && K / BK * nseg >= 3;
+    const size_t lds = (ring ? 4 : 2) * 2 * BM * BK * 2;
     const int pr = wc_prof_begin(stream);
-    if (act >= 4)
-        hipLaunchKernelGGL(gemm_f16_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, g);
-    else
-        hipLaunchKernelGGL(gemm_f16_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, g);
-    wc_prof_end(pr, act >= 4 ? "gemm_f16_kernel<true>" : "gemm_f16_kernel<false>", 2.0 * g.M * N * K * batch, stream);
+    if (act >= 4) {
+        if (ring) hipLaunchKernelGGL((gemm_f16_kernel<true, 4>), grid, dim3(256), lds, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((gemm_f16_kernel<true, 2>), grid, dim3(256), lds, (hipStream_t)stream, g);
+    } else {
+        if (ring) hipLaunchKernelGGL((gemm_f16_kernel<false, 4>), grid, dim3(256), lds, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((gemm_f16_kernel<false, 2>), grid, dim3(256), lds, (hipStream_t)stream, g);
+    }
+    wc_prof_end(pr, act >= 4 ? (ring ? "gemm_f16_kernel<true, 4>" : "gemm_f16_kernel<true, 2>")
+                             : (ring ? "gemm_f16_kernel<false, 4>" : "gemm_f16_kernel<false, 2>"), 2.0 * g.M * N * K * batch, stream);
     WC_LAUNCH_CHECK("gemm_f16_kernel");
     return WC_OK;
 }
