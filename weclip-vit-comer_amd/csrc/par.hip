@@ -237,11 +237,17 @@ __global__ __launch_bounds__(64 * ROWS) void par_iter_kernel(const float* __rest
         }
         if constexpr (H16) {
             if (cb) __syncthreads();          // the previous channel group is done with the tile
-            for (int i = threadIdx.x; i < TH * TW; i += 64 * ROWS) {
-                const int ty = i / TW, tx = i - ty * TW;
-                const long o = (long)clampi(blockIdx.y * ROWS + ty - PAR_HALO, H - 1) * W + clampi(blockIdx.x * 64 + tx - PAR_HALO, W - 1);
+            // thread (lx, ly) fills columns lx, lx + 64 of rows ly, ly + ROWS, ..: no division, one row multiply per row
+            for (int ty = ly; ty < TH; ty += ROWS) {
+                const int ro = clampi(blockIdx.y * ROWS + ty - PAR_HALO, H - 1) * W;
+                for (int tx = lx; tx < TW; tx += 64) {
+                    // uniform plane pointer + unsigned 32-bit byte offset: the scalar-base addressing form, no 64-bit
+                    // vector address arithmetic per load
+                    const unsigned ob = (unsigned)(ro + clampi(blockIdx.x * 64 + tx - PAR_HALO, W - 1)) * 4u;
 #pragma unroll
-                for (int k = 0; k < CG; ++k) tile[(k * TH + ty) * TW + tx] = Mc[k][o];
+                    for (int k = 0; k < CG; ++k)
+                        tile[(k * TH + ty) * TW + tx] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Mc[k]) + ob);
+                }
             }
             __syncthreads();
         }
@@ -259,16 +265,32 @@ __global__ __launch_bounds__(64 * ROWS) void par_iter_kernel(const float* __rest
             bool near = false;                 // one batch = the 8 taps of one dilation (get_kernel order)
             if constexpr (H16) near = (taps.dy[t] < 0 ? -taps.dy[t] : taps.dy[t]) <= PAR_HALO && (taps.dx[t] < 0 ? -taps.dx[t] : taps.dx[t]) <= PAR_HALO;
             if (near) {
+                // tile index = the thread's own + a wave-uniform tap offset (scalar arithmetic): one vector add per tap
+                const int tb = (ly + PAR_HALO) * TW + lx + PAR_HALO;
 #pragma unroll
                 for (int u = 0; u < TB_; ++u) {
-                    const int o = (ly + taps.dy[t + u] + PAR_HALO) * TW + lx + taps.dx[t + u] + PAR_HALO;
+                    const int o = tb + (taps.dy[t + u] * TW + taps.dx[t + u]);
 #pragma unroll
                     for (int k = 0; k < CG; ++k) m[u][k] = tile[k * TH * TW + o];
+                }
+            } else if constexpr (H16) {
+                // the 8 neighbours of one dilation d (build_taps: rows y-d, y, y+d x columns x-d, x, x+d without the
+                // centre): three clamped row offsets and three clamped columns instead of 8 x (2 clamps + multiply)
+                const int d = taps.dx[t + 2];
+                const int rw[3] = {clampi(y - d, H - 1) * W, y * W, clampi(y + d, H - 1) * W};
+                const int cl[3] = {clampi(x - d, W - 1), x, clampi(x + d, W - 1)};
+                constexpr int RY[8] = {0, 0, 0, 1, 1, 2, 2, 2}, CX[8] = {0, 1, 2, 0, 2, 0, 1, 2};
+                static_assert(TB_ == 8, "one batch = one dilation");
+#pragma unroll
+                for (int u = 0; u < TB_; ++u) {
+                    const unsigned ob = (unsigned)(rw[RY[u]] + cl[CX[u]]) * 4u;
+#pragma unroll
+                    for (int k = 0; k < CG; ++k) m[u][k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Mc[k]) + ob);
                 }
             } else {
 #pragma unroll
                 for (int u = 0; u < TB_; ++u) {
-                    if constexpr (!H16) a[u] = A[(t + u) * ts];
+                    a[u] = A[(t + u) * ts];
                     const int o = clampi(y + taps.dy[t + u], H - 1) * W + clampi(x + taps.dx[t + u], W - 1);
 #pragma unroll
                     for (int k = 0; k < CG; ++k) m[u][k] = Mc[k][o];
