@@ -650,7 +650,9 @@ extern "C" int wc_attn_mean(const void* qkv, const float* lse, float* mean, int 
         if (r == 0) WC_MEAN_LAUNCH(32, 0); else if (r == 1) WC_MEAN_LAUNCH(32, 1); else WC_MEAN_LAUNCH(32, ATT_EDGE_MAX);
     }
 #undef WC_MEAN_LAUNCH
-    wc_prof_end(pr, DH == 64 ? "attn_mean_kernel<64>" : "attn_mean_kernel<32>", 2.0 * B * H * (double)L * L * DH, stream);
+    static const char* const mean_names[2][3] = {{"attn_mean_kernel<64, 0>", "attn_mean_kernel<64, 1>", "attn_mean_kernel<64, 8>"},
+                                                 {"attn_mean_kernel<32, 0>", "attn_mean_kernel<32, 1>", "attn_mean_kernel<32, 8>"}};
+    wc_prof_end(pr, mean_names[DH == 64 ? 0 : 1][r == 0 ? 0 : (r == 1 ? 1 : 2)], 2.0 * B * H * (double)L * L * DH, stream);
     WC_LAUNCH_CHECK("attn_mean_kernel");
     return WC_OK;
 }
