@@ -147,7 +147,7 @@ def run_leg(args, dev, rank, world, *, comer=False, seg_trans=False, steps=None,
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     model = make_model(dev, comer=comer, seg_trans=seg_trans)
-    use_graph = graph and not comer          # the CoMer inserts run stock torch modules (cuDNN-style lazy workspaces): eager
+    use_graph = graph and (not comer or os.environ.get("WECLIP_COMER_GRAPH", "1") != "0")
     step = TrainStep(model, graph=use_graph)
     loader = SyntheticVOCLoader(args.batch, args.size, args.classes_per_image, rank=rank, world=world, device=dev,
                                 source="uint8")      # device-side rescale / flip / crop / normalise inside every step

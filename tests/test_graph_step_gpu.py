@@ -10,13 +10,13 @@ pytestmark = pytest.mark.gpu
 H, W = synth.TINY_HW
 
 
-def _model(train):
+def _model(train, comer=False):
     from weclip_vit_comer_amd.WeCLIP_model.model_attn_aff_voc import WeCLIP
     sd = synth.make_clip_state_dict(**synth.TINY)
     bg, fg = synth.make_text_features(20, 25, synth.TINY["embed_dim"])
     fuse, dec = synth.make_head_state_dicts(width=synth.TINY["width"])
     m = WeCLIP(num_classes=21, clip_model=sd, embedding_dim=256, in_channels=[synth.TINY["width"]] * 4,
-               dataset_root_path=None, device="cuda", text_features=(bg.cuda(), fg.cuda()))
+               dataset_root_path=None, device="cuda", text_features=(bg.cuda(), fg.cuda()), comer=comer)
     m.decoder_fts_fuse.load_state_dict(fuse)
     m.decoder.load_state_dict(dec)
     return m.train() if train else m.eval()
@@ -26,10 +26,10 @@ BATCHES = [(11, [[3, 7], [0, 14]]), (12, [[1, 2], [5, 19]]), (13, [[4, 6], [8, 9
            (15, [[0, 1], [2, 3]])]
 
 
-def _run(graph, seg_trans=False):
+def _run(graph, seg_trans=False, comer=False):
     from weclip_vit_comer_amd.train_step import TrainStep
     torch.manual_seed(0)
-    m = _model(train=False)                  # eval: no Dropout2d, so eager and replayed steps see the same arithmetic
+    m = _model(train=False, comer=comer)     # eval: no Dropout2d, so eager and replayed steps see the same arithmetic
     if seg_trans:
         m.iter_num = 20000
     step = TrainStep(m, graph=graph)
@@ -54,6 +54,18 @@ def test_graph_replay_is_bit_identical_to_eager(seg_trans):
         assert torch.equal(a, b)
     assert torch.equal(pe, pg)
     assert len({tuple(l) for l in lg}) == len(lg)          # the batches really differ from step to step
+
+
+def test_graph_replay_with_comer_inserts_is_bit_identical_to_eager():
+    """The ViT-CoMer inserts (conv stem, MRFP, CTI with deformable attention: hip_functional autograd Functions + torch
+    glue) are captured and replayed like the rest of the step."""
+    le, ge, pe, _, _ = _run(False, comer=True)
+    lg, gg, pg, step, _ = _run(True, comer=True)
+    assert len(step._graphs) == 1 and next(iter(step._graphs.values()))["graph"] is not None
+    assert le == lg, (le, lg)
+    for a, b in zip(ge, gg):
+        assert torch.equal(a, b)
+    assert torch.equal(pe, pg)
 
 
 def test_graph_mode_new_signature_gets_its_own_graph_and_dropout_varies():

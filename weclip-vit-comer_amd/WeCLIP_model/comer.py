@@ -86,15 +86,29 @@ class MSDeformAttn(nn.Module):
         value = _lin(self.value_proj, feat).view(N, feat.shape[1], M, C // M)
         off = _lin(self.sampling_offsets, query).view(N, Lq, M, nL, P, 2)
         aw = F.softmax(_lin(self.attention_weights, query).view(N, Lq, M, nL * P), -1).view(N, Lq, M, nL, P)
-        norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32, device=query.device)
+        norm = _level_sizes(tuple(tuple(hw) for hw in shapes), query.device)
         loc = reference_points[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
         return _lin(self.output_proj, ms_deform_attn_core(value, shapes, loc, aw))
 
 
+_CONST = {}      # per (kind, shape, device) constants: built once, so a step neither copies from the host nor re-launches
+                 # their arithmetic (and the step can be captured in a HIP graph)
+
+
+def _level_sizes(shapes, device):
+    key = ("sizes", shapes, str(device))
+    if key not in _CONST:
+        _CONST[key] = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32, device=device)
+    return _CONST[key]
+
+
 def _ref_points(h, w, device):
-    ys, xs = torch.meshgrid((torch.arange(h, device=device) + 0.5) / h, (torch.arange(w, device=device) + 0.5) / w,
-                            indexing="ij")
-    return torch.stack([xs.reshape(-1), ys.reshape(-1)], -1)        # (h*w, 2) as (x, y)
+    key = ("ref", h, w, str(device))
+    if key not in _CONST:
+        ys, xs = torch.meshgrid((torch.arange(h, device=device) + 0.5) / h, (torch.arange(w, device=device) + 0.5) / w,
+                                indexing="ij")
+        _CONST[key] = torch.stack([xs.reshape(-1), ys.reshape(-1)], -1)        # (h*w, 2) as (x, y)
+    return _CONST[key]
 
 
 class _DWConvFunction(torch.autograd.Function):
