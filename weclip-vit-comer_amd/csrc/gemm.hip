@@ -528,13 +528,22 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
         const __half* Wp1 = Wb + (long)wrow[1] * g.ldw + (long)wave * per * 16 + hh * 8;
         for (int ks0 = 0; ks0 < per; ks0 += 12) {
             f16x8 fa[12], fb0[12], fb1[12];
+            // a lane pair reads 32 contiguous bytes of its row per k-step, so a 128-B line serves four consecutive k-steps:
+            // the four loads of a line are issued back to back per operand (with A, B0, B1 interleaved per k-step the four
+            // waves' streams pushed each line out of the 32-KiB L1 before its next use: 4x over-fetch from L2)
 #pragma unroll
-            for (int i = 0; i < 12; ++i)
-                if (ks0 + i < per) {
-                    fa[i] = *reinterpret_cast<const f16x8*>(Ap + (ks0 + i) * 16);
-                    fb0[i] = *reinterpret_cast<const f16x8*>(Wp0 + (ks0 + i) * 16);
-                    fb1[i] = *reinterpret_cast<const f16x8*>(Wp1 + (ks0 + i) * 16);
-                }
+            for (int i4 = 0; i4 < 12; i4 += 4) {
+#pragma unroll
+                for (int i = i4; i < i4 + 4; ++i)
+                    if (ks0 + i < per) fb0[i] = *reinterpret_cast<const f16x8*>(Wp0 + (ks0 + i) * 16);
+#pragma unroll
+                for (int i = i4; i < i4 + 4; ++i)
+                    if (ks0 + i < per) fb1[i] = *reinterpret_cast<const f16x8*>(Wp1 + (ks0 + i) * 16);
+#pragma unroll
+                for (int i = i4; i < i4 + 4; ++i)
+                    if (ks0 + i < per) fa[i] = *reinterpret_cast<const f16x8*>(Ap + (ks0 + i) * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 12; ++i)
                 if (ks0 + i < per) {
