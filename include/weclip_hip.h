@@ -98,6 +98,12 @@ int wc_seg_loss_bwd(const float* seg, const int64_t* label, const float* wts, fl
 int wc_seg_loss_bwd_fused(const float* seg, const int64_t* label, const float* wts, float* tmp, float* out, int B, int nc,
                           int h, int w, int H, int W, int ignore, void* stream);
 
+/* Training form of the two above: loss sums (as wc_seg_loss_fwd) AND d loss / d seg for an upstream gradient of 1 in ONE
+ * pass over the pixels (a label count first gives the class weights).  cnt: 2048 floats, part: 4 floats per 64 x 4 block
+ * of (W, h) per image, tmp: 2*B*nc*h*W floats, grad: (B,nc,h,w).  nc <= 24.  (scripts/dist_clip_voc.py:105-113,250) */
+int wc_seg_loss_fwd_bwd(const float* seg, const int64_t* label, float* cnt, float* part, float* sums, float* tmp, float* grad,
+                        int B, int nc, int h, int w, int H, int W, int ignore, void* stream);
+
 /* Affinity loss fused with the affinity-label construction (reference utils/camutils.py:226-247 +
  * scripts/dist_clip_voc.py:116-133 radius mask + utils/losses.py:11-22): attn_pred (B,hw,hw) f32, cam_label (B,H,W)
  * int64 pseudo labels (nearest down-sampled to h x w inside), Chebyshev `radius`.

@@ -27,6 +27,10 @@ def test_fused_seg_loss_forward_backward(B, nc, h, w, scale):
     (3.0 * out).backward()
     assert abs(out.item() - ref.item()) < 2e-5 * max(1.0, abs(ref.item()))
     np.testing.assert_allclose(x.grad.cpu().numpy(), 3.0 * ref_in.grad.numpy(), rtol=2e-3, atol=2e-7)
+    # without a gradient request the forward-only kernel runs (nc <= 24 with one: loss + gradient in one pixel pass)
+    with torch.no_grad():
+        out_ng = get_seg_loss_fused(seg.cuda(), lab.cuda())
+    assert abs(out_ng.item() - out.item()) < 2e-6 * max(1.0, abs(out.item()))
 
 
 @pytest.mark.parametrize("align", [False, True])

@@ -4,9 +4,11 @@
 // each CE a mean over its non-ignored pixels.  The reference materialises the (B, nc, H, W) up-sampled
 // logits (352 MB at 16x21x512x512) for log_softmax forward and backward; here every high-res pixel
 // interpolates its nc logits from the low-res map on the fly.
-//   seg_loss_fwd_kernel : per pixel nll; block sums of (nll_bg, n_bg, nll_fg, n_fg) -> partials
-//   seg_loss_bwd_kernel : per pixel g[c] = w_pix * (softmax_c - [c == label]) written as (B, nc, H, W);
-//                         the low-res gradient is then the separable bilinear backward (resize.hip).
+//   seg_loss_kernel<false>  : per pixel nll; block sums of (nll_bg, n_bg, nll_fg, n_fg) -> partials (forward only)
+//   seg_loss_kernel<true>   : per pixel g[c] = w_pix * (softmax_c - [c == label]) written as (B, nc, H, W);
+//                             the low-res gradient is then the separable bilinear backward (resize.hip).
+//   seg_loss_bwd_y_kernel   : the same gradient formed inside the Y pass (no (B, nc, H, W) tensor), + seg_bwd_x_kernel
+//   seg_loss_fused_kernel   : TRAINING: loss and gradient in one pixel pass (nc <= 24), + seg_count / seg_bwd_x2 kernels
 #include "common.h"
 
 #define SEG_MAX_C 96
@@ -273,6 +275,181 @@ extern "C" int wc_seg_loss_bwd_fused(const float* seg, const int64_t* label, con
     hipLaunchKernelGGL(seg_bwd_x_kernel, dim3(wc_cdiv(w, 64), wc_cdiv(h, 4), B * nc), dim3(256), 0, st, tmp, out, h, w, W,
                        (float)w / W);
     WC_LAUNCH_CHECK("seg_bwd_x_kernel");
+    return WC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Training form: loss AND its gradient in one pass over the pixels (the soft-max of a pixel is formed once; the
+// separate forward + gradient passes formed it three times: once for the loss and once for each of the two low-resolution
+// rows a pixel contributes to).  The gradient needs the class weights 0.5 / n_bg, 0.5 / n_fg before the pass: a label
+// count runs first (SEG_CNT_BLOCKS block partials, summed in a fixed order by every workgroup of the main pass).
+// Thread (x, ys): the pixels of column x whose upper source row is ys.  Their logits are a_c + ly * (b_c - a_c) with
+// a_c, b_c = the x-interpolated logits of rows ys, ys + 1 (registers); their gradient goes to row ys with weight 1 - ly
+// (tmpA) and to row ys + 1 with ly (tmpB); the X pass adds the two in a fixed order.
+#define SEG_CNT_BLOCKS 1024
+__global__ __launch_bounds__(256) void seg_count_kernel(const long* __restrict__ label, float* __restrict__ cnt, long n, int nc,
+                                                         int ignore) {
+    __shared__ float red[16];
+    float nb = 0.f, nf = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long lab = label[i];
+        const bool valid = lab != ignore && lab >= 0 && lab < nc;
+        nb += (valid && lab == 0) ? 1.f : 0.f;
+        nf += (valid && lab != 0) ? 1.f : 0.f;
+    }
+    const float a = block_sum(nb, red), b = block_sum(nf, red);      // integers < 2^24: exact
+    if (threadIdx.x == 0) { cnt[2 * blockIdx.x] = a; cnt[2 * blockIdx.x + 1] = b; }
+}
+
+template <int NCT>
+__global__ __launch_bounds__(256) void seg_loss_fused_kernel(const float* __restrict__ seg, const long* __restrict__ label,
+                                                              const float* __restrict__ cnt, float* __restrict__ part,
+                                                              float* __restrict__ tmpA, float* __restrict__ tmpB, int nc, int h,
+                                                              int w, int H, int W, float sy, float sx, int ignore) {
+    __shared__ float red[16];
+    float pb = 0.f, pf = 0.f;
+    for (int i = threadIdx.x; i < SEG_CNT_BLOCKS; i += 256) { pb += cnt[2 * i]; pf += cnt[2 * i + 1]; }
+    const float nbg = block_sum(pb, red), nfg = block_sum(pf, red);
+    const float wbg = nbg > 0.f ? 0.5f / nbg : 0.f, wfg = nfg > 0.f ? 0.5f / nfg : 0.f;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), ys = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    float l_bg = 0.f, c_bg = 0.f, l_fg = 0.f, c_fg = 0.f;
+    if (x < W && ys < h) {
+        int x0, x1;
+        float lx;
+        bil_index(x, w, sx, x0, x1, lx);
+        const int y1s = ys + (ys < h - 1 ? 1 : 0);
+        const float* S = seg + (long)b * nc * h * w;
+        float av[NCT], dv[NCT], accT[NCT], accB[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            accT[c] = accB[c] = 0.f;
+            av[c] = dv[c] = 0.f;
+            if (c < nc) {
+                const float* Sc = S + (long)c * h * w;
+                const float a = (1.f - lx) * Sc[ys * w + x0] + lx * Sc[ys * w + x1];
+                const float bb = (1.f - lx) * Sc[y1s * w + x0] + lx * Sc[y1s * w + x1];
+                av[c] = a;
+                dv[c] = bb - a;
+            }
+        }
+        const float iy = 1.0f / sy;
+        int y_lo = ys == 0 ? 0 : (int)floorf((ys + 0.5f) * iy - 0.5f) - 1;
+        int y_hi = ys == h - 1 ? H - 1 : (int)ceilf((ys + 1.5f) * iy - 0.5f) + 1;
+        if (y_lo < 0) y_lo = 0;
+        if (y_hi > H - 1) y_hi = H - 1;
+        long labs[8];
+        for (int y = y_lo; y <= y_hi; ++y) {
+            if (((y - y_lo) & 7) == 0) {               // the labels of the next 8 rows: 8 independent loads in flight
+#pragma unroll
+                for (int u = 0; u < 8; ++u) labs[u] = label[((long)b * H + min(y + u, H - 1)) * W + x];
+            }
+            int y0, y1;
+            float ly;
+            bil_index(y, h, sy, y0, y1, ly);
+            long lab = labs[0];
+#pragma unroll
+            for (int u = 1; u < 8; ++u) lab = ((y - y_lo) & 7) == u ? labs[u] : lab;
+            if (y0 != ys) continue;                      // wave-uniform
+            float zc[NCT];
+            float mx = -INFINITY, zl = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                zc[c] = c < nc ? fmaf(ly, dv[c], av[c]) : -INFINITY;
+                mx = fmaxf(mx, zc[c]);
+                zl = c == lab ? zc[c] : zl;
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                zc[c] = c < nc ? __expf(zc[c] - mx) : 0.f;
+                sum += zc[c];
+            }
+            const bool valid = lab != ignore && lab >= 0 && lab < nc;
+            const float nll = mx + __logf(sum) - zl;
+            if (valid && lab == 0) { l_bg += nll; c_bg += 1.f; }
+            if (valid && lab != 0) { l_fg += nll; c_fg += 1.f; }
+            const float wp = valid ? (lab == 0 ? wbg : wfg) : 0.f;
+            const float u = wp / sum;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const float gval = fmaf(u, zc[c], c == lab ? -wp : 0.f);       // wp * (softmax_c - [c == label])
+                accT[c] += gval;
+                accB[c] = fmaf(ly, gval, accB[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+            if (c < nc) {
+                const long o = (((long)b * nc + c) * h) * W + x;
+                if (y1s == ys) tmpA[o + (long)ys * W] = accT[c];               // last row: both weights land on it
+                else {
+                    tmpA[o + (long)ys * W] = accT[c] - accB[c];
+                    tmpB[o + (long)y1s * W] = accB[c];
+                }
+            }
+    }
+    const float a0 = block_sum(l_bg, red), a1 = block_sum(c_bg, red), a2 = block_sum(l_fg, red), a3 = block_sum(c_fg, red);
+    if (threadIdx.x == 0) {
+        const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        part[blk * 4] = a0; part[blk * 4 + 1] = a1; part[blk * 4 + 2] = a2; part[blk * 4 + 3] = a3;
+    }
+}
+
+// X pass over tmpA (+ tmpB for rows > 0: row 0 receives nothing from above).  One wave per (image, class, row): the Wd
+// values are read coalesced and parked in LDS (index x + x/16: the 32 output lanes then read their windows, 16 apart, from
+// different banks); each output lane sums its window in ascending x, the order of the per-thread form (which read global
+// memory at a 64-byte lane stride: 51 us for 22 MB).
+__global__ __launch_bounds__(256) void seg_bwd_x2_kernel(const float* __restrict__ tmpA, const float* __restrict__ tmpB,
+                                                          float* __restrict__ gsrc, long rows, int Hs, int Ws, int Wd, float sx) {
+    extern __shared__ float xrow[];                       // 4 waves x (Wd + Wd/16 + 1)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;         // (image * nc + class) * Hs + ys
+    if (row >= rows) return;                              // wave-uniform; no block-wide barrier below
+    const int ys = (int)(row % Hs);
+    float* v = xrow + wave * (Wd + (Wd >> 4) + 1);
+    const float* TA = tmpA + row * Wd;
+    const float* TB = tmpB + row * Wd;
+    for (int x = lane; x < Wd; x += 64) v[x + (x >> 4)] = ys > 0 ? TA[x] + TB[x] : TA[x];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS writes of this wave are done before its lanes read them
+    __builtin_amdgcn_wave_barrier();
+    const float ix = 1.0f / sx;
+    for (int xs = lane; xs < Ws; xs += 64) {
+        int x_lo = (int)floorf((xs - 1.5f) * ix) - 1, x_hi = (int)ceilf((xs + 1.5f) * ix) + 1;
+        if (x_lo < 0) x_lo = 0;
+        if (x_hi > Wd - 1) x_hi = Wd - 1;
+        float acc = 0.f;
+        for (int x = x_lo; x <= x_hi; ++x) {
+            int x0, x1;
+            float lx;
+            bil_index(x, Ws, sx, x0, x1, lx);
+            const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
+            acc = fmaf(wx, v[x + (x >> 4)], acc);
+        }
+        gsrc[row * Ws + xs] = acc;
+    }
+}
+
+// Loss (sums, as wc_seg_loss_fwd) and d loss / d seg for an upstream gradient of 1 (grad, (B,nc,h,w)) in one pixel pass.
+// cnt: 2 * 1024 floats, part: 4 floats per 64 x 4 block of (W, h) per image, tmp: 2 * B*nc*h*W floats.  nc <= 24.
+extern "C" int wc_seg_loss_fwd_bwd(const float* seg, const int64_t* label, float* cnt, float* part, float* sums, float* tmp,
+                                   float* grad, int B, int nc, int h, int w, int H, int W, int ignore, void* stream) {
+    WC_CHECK_ARG(seg && label && cnt && part && sums && tmp && grad && B > 0 && B <= 65535 && nc > 0 && nc <= 24 &&
+                 (long)B * nc <= 65535 && h > 0 && w > 0 && H >= h && W >= w, "wc_seg_loss_fwd_bwd: bad argument (nc <= 24)");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(seg_count_kernel, dim3(SEG_CNT_BLOCKS), dim3(256), 0, st, (const long*)label, cnt, (long)B * H * W, nc, ignore);
+    WC_LAUNCH_CHECK("seg_count_kernel");
+    dim3 grid(wc_cdiv(W, 64), wc_cdiv(h, 4), B);
+    float* tmpB = tmp + (long)B * nc * h * W;
+    hipLaunchKernelGGL(seg_loss_fused_kernel<24>, grid, dim3(256), 0, st, seg, (const long*)label, cnt, part, tmp, tmpB, nc, h, w, H,
+                       W, (float)h / H, (float)w / W, ignore);
+    WC_LAUNCH_CHECK("seg_loss_fused_kernel");
+    hipLaunchKernelGGL(seg_loss_reduce_kernel, dim3(1), dim3(1024), 0, st, part, sums, (long)grid.x * grid.y * grid.z, 0);
+    WC_LAUNCH_CHECK("seg_loss_reduce_kernel");
+    const long rows = (long)B * nc * h;
+    WC_CHECK_ARG(W <= 8192, "wc_seg_loss_fwd_bwd: W too large for the row buffer");
+    hipLaunchKernelGGL(seg_bwd_x2_kernel, dim3((unsigned)wc_cdiv(rows, 4)), dim3(256), 4 * (W + (W >> 4) + 1) * sizeof(float), st,
+                       tmp, tmpB, grad, rows, h, w, W, (float)w / W);
+    WC_LAUNCH_CHECK("seg_bwd_x2_kernel");
     return WC_OK;
 }
 

@@ -34,19 +34,36 @@ class _SegLossFn(torch.autograd.Function):
         label = label.long().contiguous()
         B, nc, h, w = seg.shape
         H, W = label.shape[1:]
+        sums = torch.empty(8, device=seg.device, dtype=torch.float32)
+        ctx.ignore = int(ignore_index)
+        ctx.one_pass = bool(ctx.needs_input_grad[0]) and nc <= 24
+        if ctx.one_pass:
+            # training: loss and gradient (for an upstream gradient of 1) in one pass over the pixels -- the soft-max of a
+            # pixel is formed once instead of three times (csrc/losses.hip seg_loss_fused_kernel)
+            nblk = ((W + 63) // 64) * ((h + 3) // 4) * B
+            part = torch.empty(nblk * 4, device=seg.device, dtype=torch.float32)
+            cnt = torch.empty(2048, device=seg.device, dtype=torch.float32)
+            tmp = torch.empty(2 * B * nc * h * W, device=seg.device, dtype=torch.float32)
+            grad = torch.empty_like(seg)
+            L.lib().wc_seg_loss_fwd_bwd(L.ptr(seg, torch.float32, "seg"), L.ptr(label, torch.int64, "label"), L.ptr(cnt),
+                                        L.ptr(part), L.ptr(sums), L.ptr(tmp), L.ptr(grad), B, nc, h, w, H, W, ctx.ignore,
+                                        L.stream())
+            ctx.save_for_backward(grad)
+            return sums[4].clone()
         nblk = ((W + 63) // 64) * ((H + 3) // 4) * B
         part = torch.empty(nblk * 4, device=seg.device, dtype=torch.float32)
-        sums = torch.empty(8, device=seg.device, dtype=torch.float32)
         L.lib().wc_seg_loss_fwd(L.ptr(seg, torch.float32, "seg"), L.ptr(label, torch.int64, "label"), L.ptr(part),
-                                L.ptr(sums), B, nc, h, w, H, W, int(ignore_index), L.stream())
+                                L.ptr(sums), B, nc, h, w, H, W, ctx.ignore, L.stream())
         ctx.save_for_backward(seg, label, sums)
-        ctx.ignore = int(ignore_index)
         # mean over an empty set is NaN in F.cross_entropy too (0/0); the scalar tail is computed by the reduce kernel
         return sums[4].clone()
 
     @staticmethod
     def backward(ctx, g):
         from .. import _lib as L
+        if ctx.one_pass:
+            (grad,) = ctx.saved_tensors
+            return grad * g, None, None
         seg, label, sums = ctx.saved_tensors
         B, nc, h, w = seg.shape
         H, W = label.shape[1:]
