@@ -19,20 +19,40 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define NEG_BIG (-1.0e30f)
 
 // dst[b,h,d,l] = src[(b*L + l)*ld + col_off + h*DH + d], zero for l in [L, Lp)
-__global__ __launch_bounds__(256) void head_transpose_kernel(const __half* __restrict__ src, long ld, int col_off,
-                                                              __half* __restrict__ dst, int L, int Lp, int H, int DH) {
+// One launch for the three operands of a layer (blockIdx.y = operand * E/64 + column tile): q and k out of the packed
+// in-projection output, dO; 16-byte global loads and stores (the element-wise form moved 2 bytes per lane: 9 launches of
+// 15 us per step).
+__global__ __launch_bounds__(256) void head_transpose_kernel(const __half* __restrict__ qkv, const __half* __restrict__ dO,
+                                                              __half* __restrict__ qt, __half* __restrict__ kt,
+                                                              __half* __restrict__ dot, int L, int Lp, int H, int DH) {
     __shared__ __half tile[64][66];
-    const int l0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
+    const int E = H * DH, ct = E >> 6;
+    const int which = blockIdx.y / ct, c0 = (blockIdx.y - which * ct) * 64;
+    const __half* src = which == 2 ? dO : qkv;
+    const long ld = which == 2 ? E : 3L * E;
+    const int col_off = which == 1 ? E : 0;
+    __half* dst = which == 0 ? qt : (which == 1 ? kt : dot);
+    const int l0 = blockIdx.x * 64, b = blockIdx.z;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int i = threadIdx.x + 256 * p;
+        const int r = i >> 3, cv = (i & 7) * 8;
         const int l = l0 + r;
-        tile[r][c] = (l < L) ? src[((long)b * L + l) * ld + col_off + c0 + c] : __float2half(0.f);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (l < L) v = *reinterpret_cast<const u32x4*>(src + ((long)b * L + l) * ld + col_off + c0 + cv);
+        unsigned* t32 = reinterpret_cast<unsigned*>(&tile[r][cv]);          // (r * 66 + cv) halves: 4-byte aligned
+        t32[0] = v[0]; t32[1] = v[1]; t32[2] = v[2]; t32[3] = v[3];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int c = i >> 6, r = i & 63;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int i = threadIdx.x + 256 * p;
+        const int c = i >> 3, rv = (i & 7) * 8;
+        __half o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = tile[rv + j][c];
         const int e = c0 + c, h = e / DH, d = e - h * DH;
-        dst[(((long)b * H + h) * DH + d) * Lp + l0 + r] = tile[r][c];
+        *reinterpret_cast<u32x4*>(dst + (((long)b * H + h) * DH + d) * Lp + l0 + rv) = *reinterpret_cast<const u32x4*>(o);
     }
 }
 
@@ -368,10 +388,11 @@ extern "C" int wc_attn_bwd(const void* qkv, const void* dO, const float* o32, co
                  "wc_attn_bwd: bad argument (Lp %% 64 == 0, (H*DH) %% 64 == 0)");
     WC_CHECK_ARG(DH == 64 || DH == 32, "wc_attn_bwd: head dim must be 32 or 64");
     hipStream_t st = (hipStream_t)stream;
-    dim3 tg(Lp / 64, E / 64, B);
-    hipLaunchKernelGGL(head_transpose_kernel, tg, dim3(256), 0, st, (const __half*)qkv, 3L * E, 0, (__half*)qt, L, Lp, H, DH);
-    hipLaunchKernelGGL(head_transpose_kernel, tg, dim3(256), 0, st, (const __half*)qkv, 3L * E, E, (__half*)kt, L, Lp, H, DH);
-    hipLaunchKernelGGL(head_transpose_kernel, tg, dim3(256), 0, st, (const __half*)dO, (long)E, 0, (__half*)dot, L, Lp, H, DH);
+    WC_CHECK_ARG(((uintptr_t)qkv | (uintptr_t)dO | (uintptr_t)qt | (uintptr_t)kt | (uintptr_t)dot) % 16 == 0,
+                 "wc_attn_bwd: operands must be 16-byte aligned");
+    dim3 tg(Lp / 64, 3 * (E / 64), B);
+    hipLaunchKernelGGL(head_transpose_kernel, tg, dim3(256), 0, st, (const __half*)qkv, (const __half*)dO, (__half*)qt, (__half*)kt,
+                       (__half*)dot, L, Lp, H, DH);
     WC_LAUNCH_CHECK("head_transpose_kernel");
     const long total = (long)B * L;
     hipLaunchKernelGGL(attn_delta_rows_kernel, dim3(wc_cdiv(total, 4)), dim3(256), 0, st, (const __half*)dO, o32, delta,

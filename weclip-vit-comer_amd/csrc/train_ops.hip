@@ -43,27 +43,31 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     for (long r = r0; r < r1; ++r) s += (float)src[r * ld + c];
     part[(long)blockIdx.y * C + c] = s;
 }
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                            int nblk, int C, float alpha, int round16) {
-    // 64 columns per block, the partial rows dealt over 4 waves (256-B coalesced reads, 4 loads in flight each)
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                             int nblk, int C, float alpha, int round16) {
+    // 64 columns per block, the partial rows dealt over 16 waves (256-B coalesced reads, 4 loads in flight each): the grid
+    // is only C/64 blocks, so the block is as wide as it gets (4 waves: 22 us for 1024 partial rows of 512 columns)
+    __shared__ float red[16][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < C) {
         int b = rg;
-        for (; b + 12 < nblk; b += 16) {
+        for (; b + 48 < nblk; b += 64) {
             s0 += part[(long)b * C + c];
-            s1 += part[(long)(b + 4) * C + c];
-            s2 += part[(long)(b + 8) * C + c];
-            s3 += part[(long)(b + 12) * C + c];
+            s1 += part[(long)(b + 16) * C + c];
+            s2 += part[(long)(b + 32) * C + c];
+            s3 += part[(long)(b + 48) * C + c];
         }
-        for (; b < nblk; b += 4) s0 += part[(long)b * C + c];
+        for (; b < nblk; b += 16) s0 += part[(long)b * C + c];
     }
     red[rg][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rg == 0 && c < C) {
-        float s = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) * alpha;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][cl];
+        s *= alpha;
         out[c] = round16 ? __half2float(__float2half(s)) : s;
     }
 }
@@ -245,7 +249,7 @@ extern "C" int wc_colsum(const void* src, int src_f32, long ld, float* part, flo
     else
         hipLaunchKernelGGL(colsum_partial_kernel<__half>, grid, dim3(256), 0, st, (const __half*)src, ld, part, R, C, rpb);
     WC_LAUNCH_CHECK("colsum_partial_kernel");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(wc_cdiv(C, 64)), dim3(256), 0, st, part, out, nblk, C, alpha, round16);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(wc_cdiv(C, 64)), dim3(1024), 0, st, part, out, nblk, C, alpha, round16);
     WC_LAUNCH_CHECK("colsum_final_kernel");
     return WC_OK;
 }
@@ -266,7 +270,7 @@ extern "C" int wc_layernorm_bwd(const float* dy, const float* x, const float* w,
         hipLaunchKernelGGL(ln_bwd_kernel<16>, dim3(nblk), dim3(256), sm, st, dy, x, w, add, eps, dx32, (__half*)dx16,
                            out_scale, part, rows, D);
     WC_LAUNCH_CHECK("ln_bwd_kernel");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(wc_cdiv(2 * D, 64)), dim3(256), 0, st, part, dgb, nblk, 2 * D, alpha, 0);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(wc_cdiv(2 * D, 64)), dim3(1024), 0, st, part, dgb, nblk, 2 * D, alpha, 0);
     WC_LAUNCH_CHECK("colsum_final_kernel");
     return WC_OK;
 }
