@@ -362,8 +362,18 @@ __global__ __launch_bounds__(256) void aff_colreduce_kernel(const float* __restr
                                                              int K, int nblk, int mode) {
     const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;       // e = j*K + k
     if (e >= hw * K) return;
+    // 8 partial rows in flight (the grid is small: hw * K / 256 x B workgroups), summed in a fixed order
+    const float* cp = colpart + (long)b * nblk * hw * K + e;
+    const long st = (long)hw * K;
     float s = 0.f;
-    for (int blk = 0; blk < nblk; ++blk) s += colpart[((long)b * nblk + blk) * hw * K + e];
+    int blk = 0;
+    for (; blk + 8 <= nblk; blk += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = cp[(blk + u) * st];
+        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; blk < nblk; ++blk) s += cp[blk * st];
     if (mode == 0) out[(long)b * hw + e] = 1.0f / s;
     else out[(long)b * hw * K + e] = 0.5f * (y1[(long)b * hw * K + e] + c[(long)b * hw + e / K] * s);
 }
