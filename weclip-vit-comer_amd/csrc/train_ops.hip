@@ -91,6 +91,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     // chains interleaved (the row-after-row loop exposed one load latency and four shuffle chains per row: 29 us for
     // 16 384 x 256 at two waves per SIMD)
     const long r0 = ((long)blockIdx.x * 4 + wv) * LNB_ROWS;
+    // slot i of a lane = element ((i >> 2) * 64 + lane) * 4 + (i & 3): four consecutive elements per lane, 16-byte IO
+    // (D % 4 == 0, so a group of four slots is inside the row or outside it as a whole)
+#define LN_E(i_) ((((i_) >> 2) * 64 + lane) * 4 + ((i_) & 3))
     float xv[LNB_ROWS][NV], dv[LNB_ROWS][NV], s[LNB_ROWS];
     bool live[LNB_ROWS];
 #pragma unroll
@@ -101,11 +104,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         const float* dr = dy + row * D;
         s[r] = 0.f;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int e = lane + 64 * i;
-            xv[r][i] = e < D ? xr[e] : 0.f;
-            dv[r][i] = (e < D && live[r]) ? dr[e] : 0.f;
-            s[r] += xv[r][i];
+        for (int i = 0; i < NV; i += 4) {
+            const int e = LN_E(i);
+            float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), da = xa;
+            if (e < D) {
+                xa = *reinterpret_cast<const float4*>(xr + e);
+                if (live[r]) da = *reinterpret_cast<const float4*>(dr + e);
+            }
+            xv[r][i] = xa.x; xv[r][i + 1] = xa.y; xv[r][i + 2] = xa.z; xv[r][i + 3] = xa.w;
+            dv[r][i] = da.x; dv[r][i + 1] = da.y; dv[r][i + 2] = da.z; dv[r][i + 3] = da.w;
+            s[r] += (xa.x + xa.y) + (xa.z + xa.w);
         }
     }
     float mean[LNB_ROWS], rstd[LNB_ROWS], sg[LNB_ROWS], sgx[LNB_ROWS];
@@ -116,8 +124,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int e = lane + 64 * i;
-            const float d = e < D ? xv[r][i] - mean[r] : 0.f;
+            const float d = LN_E(i) < D ? xv[r][i] - mean[r] : 0.f;
             q += d * d;
         }
         s[r] = q;
@@ -126,14 +133,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int r = 0; r < LNB_ROWS; ++r) rstd[r] = rsqrtf(wave_sum(s[r]) / D + eps);
     float wv_[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) wv_[i] = lane + 64 * i < D ? w[lane + 64 * i] : 0.f;
+    for (int i = 0; i < NV; i += 4) {
+        const int e = LN_E(i);
+        const float4 wa = e < D ? *reinterpret_cast<const float4*>(w + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        wv_[i] = wa.x; wv_[i + 1] = wa.y; wv_[i + 2] = wa.z; wv_[i + 3] = wa.w;
+    }
 #pragma unroll
     for (int r = 0; r < LNB_ROWS; ++r) {
         float a = 0.f, bsum = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int e = lane + 64 * i;
-            if (e < D) {
+            if (LN_E(i) < D) {
                 const float xh = (xv[r][i] - mean[r]) * rstd[r];
                 const float g = dv[r][i] * wv_[i];
                 a += g;
@@ -155,25 +165,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         if (!live[r]) continue;
         const long row = r0 + r;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int e = lane + 64 * i;
+        for (int i = 0; i < NV; i += 4) {
+            const int e = LN_E(i);
             if (e < D) {
-                const float xh = (xv[r][i] - mean[r]) * rstd[r];
-                float v = rstd[r] * (dv[r][i] * wv_[i] - sg[r] - xh * sgx[r]);
-                if (add) v += add[row * D + e];
-                if (dx32) dx32[row * D + e] = v;
-                if (dx16) dx16[row * D + e] = __float2half(v * out_scale);
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float xh = (xv[r][i + k] - mean[r]) * rstd[r];
+                    v[k] = rstd[r] * (dv[r][i + k] * wv_[i + k] - sg[r] - xh * sgx[r]);
+                }
+                if (add) {
+                    const float4 aa = *reinterpret_cast<const float4*>(add + row * D + e);
+                    v[0] += aa.x; v[1] += aa.y; v[2] += aa.z; v[3] += aa.w;
+                }
+                if (dx32) *reinterpret_cast<float4*>(dx32 + row * D + e) = make_float4(v[0], v[1], v[2], v[3]);
+                if (dx16) {
+                    __half hv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) hv[k] = __float2half(v[k] * out_scale);
+                    *reinterpret_cast<uint2*>(dx16 + row * D + e) = *reinterpret_cast<const uint2*>(hv);
+                }
             }
         }
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int e = lane + 64 * i;
+        const int e = LN_E(i);
         if (e < D) {
             sm[(wv * 2 + 0) * D + e] = ag[i];
             sm[(wv * 2 + 1) * D + e] = ab[i];
         }
     }
+#undef LN_E
     __syncthreads();
     for (int e = threadIdx.x; e < 2 * D; e += 256) {
         const int which = e / D, k = e - which * D;
@@ -288,8 +311,10 @@ extern "C" int wc_colsum(const void* src, int src_f32, long ld, float* part, flo
 extern "C" int wc_layernorm_bwd(const float* dy, const float* x, const float* w, const float* add, float eps,
                                 float* dx32, void* dx16, float out_scale, float* part, float* dgb, float alpha,
                                 long rows, int D, void* stream) {
-    WC_CHECK_ARG(dy && x && w && part && dgb && rows > 0 && D > 0 && D <= 1024 && (dx32 || dx16),
-                 "wc_layernorm_bwd: bad argument (D <= 1024)");
+    WC_CHECK_ARG(dy && x && w && part && dgb && rows > 0 && D > 0 && D <= 1024 && D % 4 == 0 && (dx32 || dx16),
+                 "wc_layernorm_bwd: bad argument (D <= 1024, D %% 4 == 0)");
+    WC_CHECK_ARG(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)w | (uintptr_t)add | (uintptr_t)dx32) % 16 == 0 && (uintptr_t)dx16 % 8 == 0,
+                 "wc_layernorm_bwd: operands must be 16-byte aligned");
     const int nblk = wc_cdiv(rows, 4 * LNB_ROWS);
     hipStream_t st = (hipStream_t)stream;
     const size_t sm = 8 * (size_t)D * sizeof(float);
