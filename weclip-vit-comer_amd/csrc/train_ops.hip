@@ -365,30 +365,74 @@ __global__ __launch_bounds__(256) void convert_weights_kernel(const long* __rest
     const int R = (int)e[5], C = (int)e[6];
     const long ldT = e[7];
     const int tc = (C + 63) / 64, tr = (R + 63) / 64;
+    // 16-byte loads / 8-byte stores when the rows allow it (C % 4 == 0 for the row-major outputs, ldT % 4 == 0 for the
+    // transposed ones; every 2-D weight of the heads does), element-wise otherwise (bias vectors, odd shapes)
+    const bool vrow = (C & 3) == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)hi & 7) == 0 && (!lo || ((uintptr_t)lo & 7) == 0);
+    const bool vcol = hiT && (ldT & 3) == 0 && ((uintptr_t)hiT & 7) == 0 && (!loT || ((uintptr_t)loT & 7) == 0);
     for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
         const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
-        for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-            const int r = i >> 6, c = i & 63;
-            float v = 0.f;
-            if (r0 + r < R && c0 + c < C) {
-                v = src[(long)(r0 + r) * C + c0 + c];
-                const __half h = __float2half(v);
-                hi[(long)(r0 + r) * C + c0 + c] = h;
-                if (lo) lo[(long)(r0 + r) * C + c0 + c] = __float2half(v - __half2float(h));
+        if (vrow) {
+            for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+                const int r = i >> 4, c = (i & 15) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r0 + r < R && c0 + c < C) {
+                    const long o = (long)(r0 + r) * C + c0 + c;
+                    v = *reinterpret_cast<const float4*>(src + o);
+                    const float f[4] = {v.x, v.y, v.z, v.w};
+                    __half h[4], l[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        h[k] = __float2half(f[k]);
+                        l[k] = __float2half(f[k] - __half2float(h[k]));
+                    }
+                    *reinterpret_cast<uint2*>(hi + o) = *reinterpret_cast<const uint2*>(h);
+                    if (lo) *reinterpret_cast<uint2*>(lo + o) = *reinterpret_cast<const uint2*>(l);
+                }
+                tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
             }
-            tile[r][c] = v;
+        } else {
+            for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+                const int r = i >> 6, c = i & 63;
+                float v = 0.f;
+                if (r0 + r < R && c0 + c < C) {
+                    v = src[(long)(r0 + r) * C + c0 + c];
+                    const __half h = __float2half(v);
+                    hi[(long)(r0 + r) * C + c0 + c] = h;
+                    if (lo) lo[(long)(r0 + r) * C + c0 + c] = __float2half(v - __half2float(h));
+                }
+                tile[r][c] = v;
+            }
         }
         __syncthreads();
-        if (hiT)
-            for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-                const int c = i >> 6, r = i & 63;
-                if (c0 + c < C && r0 + r < R) {
-                    const float v = tile[r][c];
-                    const __half h = __float2half(v);
-                    hiT[(long)(c0 + c) * ldT + r0 + r] = h;
-                    if (loT) loT[(long)(c0 + c) * ldT + r0 + r] = __float2half(v - __half2float(h));
+        if (hiT) {
+            if (vcol && r0 + 64 <= R) {
+                for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+                    const int c = i >> 4, r = (i & 15) * 4;
+                    if (c0 + c < C) {
+                        __half h[4], l[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float v = tile[r + k][c];
+                            h[k] = __float2half(v);
+                            l[k] = __float2half(v - __half2float(h[k]));
+                        }
+                        const long o = (long)(c0 + c) * ldT + r0 + r;
+                        *reinterpret_cast<uint2*>(hiT + o) = *reinterpret_cast<const uint2*>(h);
+                        if (loT) *reinterpret_cast<uint2*>(loT + o) = *reinterpret_cast<const uint2*>(l);
+                    }
+                }
+            } else {
+                for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+                    const int c = i >> 6, r = i & 63;
+                    if (c0 + c < C && r0 + r < R) {
+                        const float v = tile[r][c];
+                        const __half h = __float2half(v);
+                        hiT[(long)(c0 + c) * ldT + r0 + r] = h;
+                        if (loT) loT[(long)(c0 + c) * ldT + r0 + r] = __float2half(v - __half2float(h));
+                    }
                 }
             }
+        }
         __syncthreads();
     }
 }
