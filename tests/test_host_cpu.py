@@ -85,7 +85,10 @@ def _dp_worker(rank, world, port, ret):
     dist.all_gather(gathered, local)
     ok = torch.allclose(bucket.flat, sum(gathered) / world) and all(
         p.grad.data_ptr() >= bucket.flat.data_ptr() for p in net.parameters())
-    ret[rank] = bool(ok) and bucket.flat.numel() == sum(p.numel() for p in net.parameters())
+    # every view starts on a 16-byte boundary: odd-sized tensors are followed by <= 3 zero padding elements
+    padded = sum((p.numel() + 3) // 4 * 4 for p in net.parameters())
+    ret[rank] = bool(ok) and bucket.flat.numel() == padded and all(
+        (p.grad.data_ptr() - bucket.flat.data_ptr()) % 16 == 0 for p in net.parameters())
     dist.destroy_process_group()
 
 

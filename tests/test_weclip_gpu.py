@@ -171,7 +171,10 @@ def test_grouped_adapter_launches_equal_per_adapter_launches(monkeypatch, precis
         torch.manual_seed(1)
         loss, _, _ = step(img, labels=[[1], [2, 5], [0, 3]])
         ad = {id(q) for q in m.decoder_fts_fuse.linears_modulelist.parameters()}
-        mask = torch.cat([torch.full((q.numel(),), id(q) in ad, dtype=torch.bool) for q in step.bucket.params]).cuda()
+        mask = torch.zeros(step.bucket.flat.numel(), dtype=torch.bool)       # views start on 16-byte boundaries (padding: False)
+        for q, o in zip(step.bucket.params, step.bucket.offsets):
+            mask[o:o + q.numel()] = id(q) in ad
+        mask = mask.cuda()
         return loss.item(), step.bucket.flat.clone(), mask
 
     real_wg = HE.ops.wgrad_partials

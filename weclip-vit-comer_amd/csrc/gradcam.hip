@@ -311,12 +311,22 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const __half* __restric
     const int E = H * DH;
     const __half* a = dO + row * E;
     const float* b = o32 + ((long)pair_img[p] * L + q) * E;
-    for (int e0 = 0; e0 < E; e0 += 64) {
-        float s = __half2float(a[e0 + lane]) * b[e0 + lane];
-        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-        s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
-        if (DH == 64) s += __shfl_xor(s, 32, 64);
-        if ((lane & (DH - 1)) == 0) delta[(p * H + (e0 + lane) / DH) * L + q] = s;
+    // 8 consecutive elements per lane (16-byte dO load, two 16-byte O loads): a head of DH elements lives in DH / 8
+    // adjacent lanes, summed by 2-3 shuffles (the element-per-lane form: 2- and 4-byte loads, 5-6 shuffles per 64 elements)
+    const int nch = E >> 3, lph = DH >> 3;             // 16-byte chunks per row, lanes per head
+    for (int c0 = 0; c0 < nch; c0 += 64) {
+        const int c = c0 + lane;
+        float s = 0.f;
+        if (c < nch) {
+            const u32x4 av = *reinterpret_cast<const u32x4*>(a + c * 8);
+            const float4 b0 = *reinterpret_cast<const float4*>(b + c * 8), b1 = *reinterpret_cast<const float4*>(b + c * 8 + 4);
+            const __half* ah = reinterpret_cast<const __half*>(&av);
+            s = __half2float(ah[0]) * b0.x + __half2float(ah[1]) * b0.y + __half2float(ah[2]) * b0.z + __half2float(ah[3]) * b0.w +
+                __half2float(ah[4]) * b1.x + __half2float(ah[5]) * b1.y + __half2float(ah[6]) * b1.z + __half2float(ah[7]) * b1.w;
+        }
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+        if (lph == 8) s += __shfl_xor(s, 4, 64);
+        if (c < nch && (c & (lph - 1)) == 0) delta[(p * H + c / lph) * L + q] = s;
     }
 }
 

@@ -219,6 +219,57 @@ __global__ __launch_bounds__(256) void sigmoid_gram_bwd_kernel(const float* __re
     const int tj = ti + rem, b = blockIdx.y;
     const long base = (long)b * n * n;
     const int i0 = ti * 64, j0 = tj * 64;
+    const bool vec = (n & 3) == 0 && (ldo & 3) == 0 && (((uintptr_t)dAP | (uintptr_t)AP) & 15) == 0 && ((uintptr_t)hi & 7) == 0 &&
+                     (!lo || ((uintptr_t)lo & 7) == 0);
+    if (vec) {            // 16-byte loads, 8-byte stores: four columns per thread
+        for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+            const int r = e >> 4, c = (e & 15) * 4;
+            float v[4] = {0.f, 0.f, 0.f, 0.f}, vt[4] = {0.f, 0.f, 0.f, 0.f};
+            if (i0 + r < n && j0 + c < n) {
+                const long o = base + (long)(i0 + r) * n + j0 + c;
+                const float4 a = *reinterpret_cast<const float4*>(AP + o), d = *reinterpret_cast<const float4*>(dAP + o);
+                v[0] = d.x * a.x * (1.f - a.x); v[1] = d.y * a.y * (1.f - a.y);
+                v[2] = d.z * a.z * (1.f - a.z); v[3] = d.w * a.w * (1.f - a.w);
+            }
+            if (ti != tj && j0 + r < n && i0 + c < n) {
+                const long o = base + (long)(j0 + r) * n + i0 + c;
+                const float4 a = *reinterpret_cast<const float4*>(AP + o), d = *reinterpret_cast<const float4*>(dAP + o);
+                vt[0] = d.x * a.x * (1.f - a.x); vt[1] = d.y * a.y * (1.f - a.y);
+                vt[2] = d.z * a.z * (1.f - a.z); vt[3] = d.w * a.w * (1.f - a.w);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { za[r][c + k] = v[k]; zb[r][c + k] = vt[k]; }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+            const int r = e >> 4, c = (e & 15) * 4;
+            if (i0 + r < n && j0 + c < n) {
+                __half h[4], l[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = scale * (za[r][c + k] + (ti == tj ? za[c + k][r] : zb[c + k][r]));
+                    h[k] = __float2half(v);
+                    l[k] = __float2half(v - __half2float(h[k]));
+                }
+                const long oo = (long)b * n * ldo + (long)(i0 + r) * ldo + j0 + c;
+                *reinterpret_cast<uint2*>(hi + oo) = *reinterpret_cast<const uint2*>(h);
+                if (lo) *reinterpret_cast<uint2*>(lo + oo) = *reinterpret_cast<const uint2*>(l);
+            }
+            if (ti != tj && j0 + r < n && i0 + c < n) {
+                __half h[4], l[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = scale * (zb[r][c + k] + za[c + k][r]);
+                    h[k] = __float2half(v);
+                    l[k] = __float2half(v - __half2float(h[k]));
+                }
+                const long oo = (long)b * n * ldo + (long)(j0 + r) * ldo + i0 + c;
+                *reinterpret_cast<uint2*>(hi + oo) = *reinterpret_cast<const uint2*>(h);
+                if (lo) *reinterpret_cast<uint2*>(lo + oo) = *reinterpret_cast<const uint2*>(l);
+            }
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < 64 * 64; e += 256) {
         const int r = e >> 6, c = e & 63;
         float v = 0.f, vt = 0.f;
@@ -458,6 +509,28 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const long* __restrict
     float* m = reinterpret_cast<float*>(e[2]);
     float* v = reinterpret_cast<float*>(e[3]);
     const long n = e[4];
+    if (((n & 3) | (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15)) == 0) {
+        // four elements per thread and access (16-byte IO); element-wise arithmetic unchanged
+        for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+            const float4 g4 = *reinterpret_cast<const float4*>(g + i), p4 = *reinterpret_cast<const float4*>(p + i);
+            const float4 m4 = *reinterpret_cast<const float4*>(m + i), v4 = *reinterpret_cast<const float4*>(v + i);
+            const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w};
+            const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+            float po[4], mo[4], vo[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float pi = pp[k] * decay;
+                mo[k] = mm[k] + w1 * (gg[k] - mm[k]);
+                vo[k] = vv[k] * b2 + (w2 * gg[k]) * gg[k];
+                const float denom = sqrtf(vo[k]) / bc2_sqrt + eps;
+                po[k] = pi - step_size * (mo[k] / denom);
+            }
+            *reinterpret_cast<float4*>(p + i) = make_float4(po[0], po[1], po[2], po[3]);
+            *reinterpret_cast<float4*>(m + i) = make_float4(mo[0], mo[1], mo[2], mo[3]);
+            *reinterpret_cast<float4*>(v + i) = make_float4(vo[0], vo[1], vo[2], vo[3]);
+        }
+        return;
+    }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float gi = g[i];
         float pi = p[i] * decay;

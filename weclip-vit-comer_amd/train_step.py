@@ -35,12 +35,16 @@ class GradBucket:
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(n, device=self.params[0].device, dtype=torch.float32)
-        off = 0
+        # every gradient starts on a 16-byte boundary (the fused AdamW and the split-K reductions use 16-byte accesses):
+        # an odd-sized tensor (the 21-class bias) is followed by <= 3 padding elements, which stay zero
+        offs, off = [], 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+            offs.append(off)
+            off = (off + p.numel() + 3) & ~3
+        self.flat = torch.zeros(off, device=self.params[0].device, dtype=torch.float32)
+        self.offsets = offs
+        for p, o in zip(self.params, offs):
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
 
     def zero(self):
         self.flat.zero_()
