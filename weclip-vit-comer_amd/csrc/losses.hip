@@ -470,28 +470,88 @@ __device__ __forceinline__ int aff_lowres_label(const long* __restrict__ cam, in
     return (int)cam[((long)b * H + sy) * W + sx];
 }
 
+#define AFF_ROWS 32      // rows of the (hw, hw) matrix per workgroup
 template <bool BWD>
 __global__ __launch_bounds__(256) void aff_loss_kernel(const float* __restrict__ ap, const long* __restrict__ cam,
                                                         float* __restrict__ part, const float* __restrict__ coef,
                                                         float* __restrict__ dap, int h, int w, int H, int W, int radius,
                                                         int ignore) {
-    extern __shared__ int lab[];          // [hw] low-res labels of image b
+    extern __shared__ int lab[];          // [hw] low-res labels of image b | [hw] (y << 16 | x) of every token
     __shared__ float red[16];
     const int hw = h * w, b = blockIdx.y;
-    for (int t = threadIdx.x; t < hw; t += 256) lab[t] = aff_lowres_label(cam, b, t, h, w, H, W);
+    int* yx = lab + hw;                   // token coordinates once per block: the sweep below has no integer division
+    for (int t = threadIdx.x; t < hw; t += 256) {
+        lab[t] = aff_lowres_label(cam, b, t, h, w, H, W);
+        const int ty = t / w;
+        yx[t] = (ty << 16) | (t - ty * w);
+    }
     __syncthreads();
-    // block = ROWS rows i of the (hw, hw) matrix, threads sweep j
-    constexpr int ROWS = 8;
+    // block = ROWS rows i of the (hw, hw) matrix, threads sweep j (four consecutive j per thread and 16-byte access when
+    // hw % 4 == 0; the low-resolution label table above is rebuilt per block, so the rows per block amortise it)
+    constexpr int ROWS = AFF_ROWS;
     float ps = 0.f, pc = 0.f, ns = 0.f, nc = 0.f;
     float cp = 0.f, cn = 0.f;
     if (BWD) { cp = coef[0]; cn = coef[1]; }
+    const bool vec = (hw & 3) == 0;
+    if (!BWD && vec && (blockIdx.x + 1) * ROWS <= hw) {
+        // forward, full block: the 16-byte loads of 8 rows are issued before any of them is consumed (the row loop
+        // below keeps one load per thread in flight: 32 dependent round trips per thread)
+        for (int r0 = 0; r0 < ROWS; r0 += 8) {
+            for (int j0 = threadIdx.x * 4; j0 < hw; j0 += 1024) {
+                float4 pv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    pv[u] = *reinterpret_cast<const float4*>(ap + ((long)b * hw + blockIdx.x * ROWS + r0 + u) * hw + j0);
+                int lj[4], yj[4], xj[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { lj[k] = lab[j0 + k]; yj[k] = yx[j0 + k] >> 16; xj[k] = yx[j0 + k] & 0xffff; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = blockIdx.x * ROWS + r0 + u;
+                    const int li = lab[i], yi = yx[i] >> 16, xi = yx[i] & 0xffff;
+                    const float p4[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int dy = yi - yj[k], dx = xi - xj[k];
+                        const bool ok = li != ignore && lj[k] != ignore && dy <= radius && -dy <= radius && dx <= radius && -dx <= radius;
+                        const bool pos = ok && li == lj[k], neg = ok && li != lj[k];
+                        if (pos) { ps += 1.f - p4[k]; pc += 1.f; }
+                        if (neg) { ns += p4[k]; nc += 1.f; }
+                    }
+                }
+            }
+        }
+    } else
     for (int r = 0; r < ROWS; ++r) {
         const int i = blockIdx.x * ROWS + r;
         if (i >= hw) break;
         const int li = lab[i], yi = i / w, xi = i - yi * w;
         const float* row = ap + ((long)b * hw + i) * hw;
+        if (vec) {
+            for (int j0 = threadIdx.x * 4; j0 < hw; j0 += 1024) {
+                float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!BWD) pv = *reinterpret_cast<const float4*>(row + j0);
+                const float p4[4] = {pv.x, pv.y, pv.z, pv.w};
+                float o4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int j = j0 + k;
+                    const int lj = lab[j], yj = yx[j] >> 16, xj = yx[j] & 0xffff;
+                    const int dy = yi - yj, dx = xi - xj;
+                    const bool ok = li != ignore && lj != ignore && dy <= radius && -dy <= radius && dx <= radius && -dx <= radius;
+                    const bool pos = ok && li == lj, neg = ok && li != lj;
+                    o4[k] = pos ? cp : (neg ? cn : 0.f);
+                    if (!BWD) {
+                        if (pos) { ps += 1.f - p4[k]; pc += 1.f; }
+                        if (neg) { ns += p4[k]; nc += 1.f; }
+                    }
+                }
+                if (BWD) *reinterpret_cast<float4*>(dap + ((long)b * hw + i) * hw + j0) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            }
+            continue;
+        }
         for (int j = threadIdx.x; j < hw; j += 256) {
-            const int lj = lab[j], yj = j / w, xj = j - yj * w;
+            const int lj = lab[j], yj = yx[j] >> 16, xj = yx[j] & 0xffff;
             const int dy = yi - yj, dx = xi - xj;
             const bool ok = li != ignore && lj != ignore && dy <= radius && -dy <= radius && dx <= radius && -dx <= radius;
             const bool pos = ok && li == lj, neg = ok && li != lj;
@@ -518,10 +578,10 @@ extern "C" int wc_aff_loss_fwd(const float* attn_pred, const int64_t* cam_label,
                                int w, int H, int W, int radius, int ignore, void* stream) {
     WC_CHECK_ARG(attn_pred && cam_label && part && sums && B > 0 && h > 0 && w > 0 && H >= h && W >= w && radius >= 0,
                  "wc_aff_loss_fwd: bad argument");
-    WC_CHECK_ARG((size_t)h * w * 4 <= 64 * 1024 && B <= 65535, "wc_aff_loss_fwd: h*w <= 16384");
-    dim3 grid(wc_cdiv(h * w, 8), B);
+    WC_CHECK_ARG((size_t)h * w * 8 <= 64 * 1024 && B <= 65535 && h < 32768 && w < 65536, "wc_aff_loss_fwd: h*w <= 8192");
+    dim3 grid(wc_cdiv(h * w, AFF_ROWS), B);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(aff_loss_kernel<false>, grid, dim3(256), (size_t)h * w * 4, st, attn_pred, (const long*)cam_label, part,
+    hipLaunchKernelGGL(aff_loss_kernel<false>, grid, dim3(256), (size_t)h * w * 8, st, attn_pred, (const long*)cam_label, part,
                        nullptr, nullptr, h, w, H, W, radius, ignore);
     WC_LAUNCH_CHECK("aff_loss_kernel<fwd>");
     hipLaunchKernelGGL(seg_loss_reduce_kernel, dim3(1), dim3(1024), 0, st, part, sums, (long)grid.x * grid.y, 1);
@@ -535,8 +595,8 @@ extern "C" int wc_aff_loss_bwd(const int64_t* cam_label, const float* coef, floa
                                int radius, int ignore, void* stream) {
     WC_CHECK_ARG(cam_label && coef && dap && B > 0 && h > 0 && w > 0 && H >= h && W >= w && radius >= 0,
                  "wc_aff_loss_bwd: bad argument");
-    WC_CHECK_ARG((size_t)h * w * 4 <= 64 * 1024 && B <= 65535, "wc_aff_loss_bwd: h*w <= 16384");
-    hipLaunchKernelGGL(aff_loss_kernel<true>, dim3(wc_cdiv(h * w, 8), B), dim3(256), (size_t)h * w * 4, (hipStream_t)stream,
+    WC_CHECK_ARG((size_t)h * w * 8 <= 64 * 1024 && B <= 65535 && h < 32768 && w < 65536, "wc_aff_loss_bwd: h*w <= 8192");
+    hipLaunchKernelGGL(aff_loss_kernel<true>, dim3(wc_cdiv(h * w, AFF_ROWS), B), dim3(256), (size_t)h * w * 8, (hipStream_t)stream,
                        nullptr, (const long*)cam_label, nullptr, coef, dap, h, w, H, W, radius, ignore);
     WC_LAUNCH_CHECK("aff_loss_kernel<bwd>");
     return WC_OK;
