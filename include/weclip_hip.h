@@ -171,6 +171,10 @@ int wc_sum_slices_wb(const float* part, float* out_w, float* out_b, int nslices,
  * out_w + i*gW and out_b + i*gB (elements) -- the per-adapter gradient views of a flat gradient bucket. */
 int wc_sum_slices_wb_grouped(const float* part, float* out_w, float* out_b, int nslices, int rows, int cols,
                              float alpha, int groups, long gW, long gB, void* stream);
+/* Many split-K reductions in one launch.  jobs: HOST array of count x 7 int64 {part, out_w, out_b (device pointers), nslices,
+ * rows, cols, alpha as IEEE float bits}; each job = one wc_sum_slices_wb (same summation order).  The jobs travel by value
+ * in the kernel arguments (graph-capturable, no device table). */
+int wc_sum_slices_wb_multi(const int64_t* jobs, int count, void* stream);
 
 /* Weight-gradient GEMM on row-major operands: part[z, n, k] = sum over the tokens m of slice z of dY[m, n] * X[m, k]
  * (and, with bias != 0, one more column k = K holding sum_m dY[m, n]); z = 0 .. ceil(M / mslice) - 1, mslice a multiple

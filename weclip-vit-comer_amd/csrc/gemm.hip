@@ -16,6 +16,7 @@
 // DMA of tile t+1 is issued before the MFMAs of tile t, one barrier per K-tile, 64 KiB LDS -> two
 // workgroups per CU.  blockIdx.x walks N tiles (they share the A tile through L2), blockIdx.y M tiles.
 #include "common.h"
+#include <cstring>
 #include <stdlib.h>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -1090,6 +1091,72 @@ extern "C" int wc_sum_slices_wb_grouped(const float* part, float* out_w, float* 
     hipLaunchKernelGGL(sum_slices_wb_kernel, dim3(wc_cdiv((long)rows * (cols + 1), 256), groups), dim3(256), 0,
                        (hipStream_t)stream, part, out_w, out_b, nslices, rows, cols, alpha, gW, gB);
     WC_LAUNCH_CHECK("sum_slices_wb_kernel");
+    return WC_OK;
+}
+
+// Many split-K reductions in ONE launch (a training step has 16 of them, 5-7 us each at the launch floor): the jobs
+// travel BY VALUE in the kernel arguments (no table in device memory: nothing to copy, nothing a captured graph could
+// find overwritten on replay).  blockIdx.y = job, blockIdx.x strides over its elements; same summation order as
+// sum_slices_wb_kernel.
+#define SUMJ_MAX 64
+struct SumJobs {
+    const float* part[SUMJ_MAX];
+    float* out_w[SUMJ_MAX];
+    float* out_b[SUMJ_MAX];
+    int nslices[SUMJ_MAX], rows[SUMJ_MAX], cols[SUMJ_MAX];
+    float alpha[SUMJ_MAX];
+};
+__global__ __launch_bounds__(256) void sum_slices_wb_multi_kernel(SumJobs j) {
+    const int q = blockIdx.y;
+    const float* __restrict__ part = j.part[q];
+    float* __restrict__ out_w = j.out_w[q];
+    float* __restrict__ out_b = j.out_b[q];
+    const int nslices = j.nslices[q], cols = j.cols[q];
+    const float alpha = j.alpha[q];
+    const long n = (long)j.rows[q] * (cols + 1);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // 4 slice loads in flight
+        int k = 0;
+        for (; k + 4 <= nslices; k += 4) {
+            s0 += part[(long)k * n + i];
+            s1 += part[(long)(k + 1) * n + i];
+            s2 += part[(long)(k + 2) * n + i];
+            s3 += part[(long)(k + 3) * n + i];
+        }
+        for (; k < nslices; ++k) s0 += part[(long)k * n + i];
+        const float s = (s0 + s1) + (s2 + s3);
+        const int r = (int)(i / (cols + 1)), c = (int)(i - (long)r * (cols + 1));
+        if (c < cols) out_w[(long)r * cols + c] = s * alpha;
+        else out_b[r] = s * alpha;
+    }
+}
+
+// jobs: count x 7 host int64 {part, out_w, out_b (device pointers), nslices, rows, cols, alpha as float bits}
+extern "C" int wc_sum_slices_wb_multi(const int64_t* jobs, int count, void* stream) {
+    WC_CHECK_ARG(jobs && count > 0, "wc_sum_slices_wb_multi: bad argument");
+    for (int base = 0; base < count; base += SUMJ_MAX) {
+        SumJobs j;
+        const int m = count - base < SUMJ_MAX ? count - base : SUMJ_MAX;
+        long nmax = 0;
+        for (int q = 0; q < SUMJ_MAX; ++q) {
+            const int64_t* e = jobs + (long)(base + (q < m ? q : 0)) * 7;
+            j.part[q] = reinterpret_cast<const float*>(e[0]);
+            j.out_w[q] = reinterpret_cast<float*>(e[1]);
+            j.out_b[q] = reinterpret_cast<float*>(e[2]);
+            j.nslices[q] = (int)e[3]; j.rows[q] = (int)e[4]; j.cols[q] = (int)e[5];
+            const unsigned bits = (unsigned)e[6];
+            memcpy(&j.alpha[q], &bits, 4);
+            WC_CHECK_ARG(j.part[q] && j.out_w[q] && j.out_b[q] && j.nslices[q] > 0 && j.rows[q] > 0 && j.cols[q] > 0,
+                         "wc_sum_slices_wb_multi: bad job");
+            const long n = (long)j.rows[q] * (j.cols[q] + 1);
+            if (q < m && n > nmax) nmax = n;
+        }
+        long bx = wc_cdiv(nmax, 256 * 4);          // <= 4 elements per thread of the largest job
+        if (bx < 1) bx = 1;
+        if (bx > 256) bx = 256;
+        hipLaunchKernelGGL(sum_slices_wb_multi_kernel, dim3((unsigned)bx, m), dim3(256), 0, (hipStream_t)stream, j);
+        WC_LAUNCH_CHECK("sum_slices_wb_multi_kernel");
+    }
     return WC_OK;
 }
 

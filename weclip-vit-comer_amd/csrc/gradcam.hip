@@ -759,13 +759,25 @@ __global__ __launch_bounds__(256) void rowvec_matmul_kernel(const float* __restr
     float acc[RVM_PB];
 #pragma unroll
     for (int k = 0; k < RVM_PB; ++k) acc[k] = 0.f;
-    if (e < E)
-        for (int n = nbeg + wv; n < nend; n += 4) {
+    if (e < E) {
+        int n = nbeg + wv;
+        for (; n + 12 < nend; n += 16) {              // four W rows in flight per wave (one per iteration: latency bound)
+            float w4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w4[u] = W[(long)(n + 4 * u) * E + e];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < RVM_PB; ++k)
+                    if (p0 + k < P) acc[k] = fmaf(c[(long)(p0 + k) * N + n + 4 * u], w4[u], acc[k]);
+        }
+        for (; n < nend; n += 4) {
             const float w = W[(long)n * E + e];
 #pragma unroll
             for (int k = 0; k < RVM_PB; ++k)
                 if (p0 + k < P) acc[k] = fmaf(c[(long)(p0 + k) * N + n], w, acc[k]);
         }
+    }
 #pragma unroll
     for (int k = 0; k < RVM_PB; ++k) red[wv][k][lane] = acc[k];
     __syncthreads();

@@ -184,7 +184,48 @@ class HeadEngine:
 
     # ------------------------------------------------------------------------------ backward
     def backward(self, ctx, dseg, dap):
-        """dseg (B,nc,h,w) / dap (B,hw,hw) fp32 (either may be None).  Returns {param name: grad}."""
+        """dseg (B,nc,h,w) / dap (B,hw,hw) fp32 (either may be None).  Returns {param name: grad}.
+        The split-K reductions of all weight gradients are collected and run as ONE launch at the end
+        (wc_sum_slices_wb_multi; 16 launches of 5-7 us at the launch floor otherwise)."""
+        self._pending = []
+        try:
+            grads = self._backward_impl(ctx, dseg, dap)
+            self._flush_reductions()
+        finally:
+            self._pending = None
+        return grads
+
+    def _reduce(self, part, gw, gb, ns, N_, K_, alpha, groups=1, sw=0, sb=0):
+        """dW / db = alpha * sum of the `ns` split-K slices of `part`: queued while a backward pass is collecting,
+        launched right away otherwise."""
+        from . import _lib as L
+        if getattr(self, "_pending", None) is None:
+            if groups == 1:
+                L.lib().wc_sum_slices_wb(L.ptr(part, F32), L.ptr(gw, F32), L.ptr(gb, F32), ns, N_, K_, alpha, L.stream())
+            else:
+                L.lib().wc_sum_slices_wb_grouped(L.ptr(part, F32), L.ptr(gw, F32), L.ptr(gb, F32), ns, N_, K_, alpha, groups,
+                                                 sw, sb, L.stream())
+            return
+        import struct
+        abits = struct.unpack("<I", struct.pack("<f", float(alpha)))[0]
+        per = ns * N_ * (K_ + 1)
+        for g in range(groups):
+            self._pending.append((part, part.data_ptr() + 4 * g * per, gw.data_ptr() + 4 * g * sw, gb.data_ptr() + 4 * g * sb,
+                                  ns, N_, K_, abits))
+
+    def _flush_reductions(self):
+        jobs = self._pending
+        if not jobs:
+            return
+        import ctypes
+        from . import _lib as L
+        flat = []
+        for j in jobs:
+            flat.extend(j[1:])
+        arr = (ctypes.c_int64 * len(flat))(*flat)
+        L.lib().wc_sum_slices_wb_multi(arr, len(jobs), L.stream())      # the partial buffers stay referenced by `jobs` until here
+
+    def _backward_impl(self, ctx, dseg, dap):
         B, h, w, ex = ctx["B"], ctx["h"], ctx["w"], ctx["ex"]
         E, hw, M, nc, n = self.E, h * w, B * h * w, self.nc, self.index
         dev = ctx["F32"].device
@@ -297,8 +338,7 @@ class HeadEngine:
             tiles = ((N_ + 127) // 128) * ((K_ + 1 + 127) // 128) * n
             ns = max(1, min(_WGRAD_WGS // tiles, M // 256))       # one round of workgroups (2 per CU), few partials
             part, ns = ops.wgrad_partials(dy, x, M, N_, K_, lda=lda, ldx=ldx, slices=ns, bias=True, xmap=xmap, groups=n, gA=gA, gX=gX)
-            L.lib().wc_sum_slices_wb_grouped(L.ptr(part, F32), L.ptr(gw, F32), L.ptr(gb, F32), ns, N_, K_, inv, n, sw, sb,
-                                             L.stream())
+            self._reduce(part, gw, gb, ns, N_, K_, inv, groups=n, sw=sw, sb=sb)
 
         # proj_2: dY = dcat[:, l*E:(l+1)*E], X = t1[l];   proj: dY = dt1[l], X = patch rows of block output l
         run(dcat.hi, n * E, E, ctx["t1b"].hi, E, M * E, E, E, None, dst[2][0], dst[3][0], st[2], st[3])
@@ -328,8 +368,7 @@ class HeadEngine:
             ns *= 2
         part, ns = ops.wgrad_partials(dy16, x16, M, N_, K_, lda=lda, ldx=ldx, slices=ns, bias=True, xmap=xmap)
         gw, gb = self._dest(wname, (N_, K_)), self._dest(bname, (N_,))
-        from . import _lib as L
-        L.lib().wc_sum_slices_wb(L.ptr(part, F32), L.ptr(gw, F32), L.ptr(gb, F32), ns, N_, K_, inv, L.stream())
+        self._reduce(part, gw, gb, ns, N_, K_, inv)
         grads[wname], grads[bname] = gw, gb
 
     def _block_bwd(self, c, dx2, B, Lq, prefix, grads, inv):
