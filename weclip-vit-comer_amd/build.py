@@ -16,7 +16,7 @@ OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libweclip_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
-         "-Wno-unused-result", "-I", CSRC]
+         "-Wno-unused-result", "-I", CSRC] + os.environ.get("WECLIP_HIPCC_FLAGS", "").split()      # extra flags: experiments
 
 
 def _sources():
