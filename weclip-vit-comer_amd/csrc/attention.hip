@@ -338,7 +338,41 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(const __half* __re
     }
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / ltot;
-    if (qrow < L) {
+#ifdef WC_NO_OSTAGE
+    constexpr bool OSTAGE = false;
+#else
+    constexpr bool OSTAGE = NW == 8;
+#endif
+    if constexpr (OSTAGE) {
+        // O (fp16) leaves through LDS as whole rows: a lane owns a query, so direct stores are 8-byte pieces at a row pitch
+        // (64 lines touched per store instruction); each wave parks its 32 x DH tile in its own slice of the (now free) K/V
+        // buffers and writes 16 bytes per lane, DH * 2 contiguous bytes per row.  All waves are past the loop's last barrier.
+        constexpr int OPITCH = DH * 2 + 8;                 // bytes; 8-byte aligned rows, 2-way bank spread
+        constexpr int CPR = DH / 8;                        // 16-byte chunks per row
+        char* stg = smem + wave * (32 * OPITCH);
+    #pragma unroll
+        for (int d = 0; d < DT; ++d)
+    #pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                __half hv[4];
+    #pragma unroll
+                for (int k = 0; k < 4; ++k) hv[k] = __float2half(o[d][g * 4 + k] * inv);
+                *reinterpret_cast<uint2*>(stg + l31 * OPITCH + (d * 32 + 8 * g + 4 * hh) * 2) = *reinterpret_cast<uint2*>(hv);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int qw0 = q_origin + qb * (NW * 32) + wave * 32;          // first query row of this wave
+    #pragma unroll
+        for (int i = 0; i < 32 * CPR / 64; ++i) {
+            const int r = i * (64 / CPR) + lane / CPR, ch = lane % CPR;
+            if (qw0 + r < L) {
+                const uint2 lo2 = *reinterpret_cast<const uint2*>(stg + r * OPITCH + ch * 16);
+                const uint2 hi2 = *reinterpret_cast<const uint2*>(stg + r * OPITCH + ch * 16 + 8);
+                u32x4 v = {lo2.x, lo2.y, hi2.x, hi2.y};
+                *reinterpret_cast<u32x4*>(out + ((long)b * L + qw0 + r) * E + (long)h * DH + ch * 8) = v;
+            }
+        }
+    } else if (qrow < L) {          // 4-wave form (small batches): direct stores -- the staging code makes it spill (90 -> 102 us)
         __half* orow = out + ((long)b * L + qrow) * E + (long)h * DH;
 #pragma unroll
         for (int d = 0; d < DT; ++d)
@@ -348,10 +382,17 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(const __half* __re
 #pragma unroll
                 for (int k = 0; k < 4; ++k) hv[k] = __float2half(o[d][g * 4 + k] * inv);
                 *reinterpret_cast<uint2*>(orow + d * 32 + 8 * g + 4 * hh) = *reinterpret_cast<uint2*>(hv);
-                if (out32)
+            }
+    }
+    if (qrow < L) {
+        if (out32) {
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<float4*>(out32 + ((long)b * L + qrow) * E + (long)h * DH + d * 32 + 8 * g + 4 * hh) =
                         make_float4(o[d][g * 4] * inv, o[d][g * 4 + 1] * inv, o[d][g * 4 + 2] * inv, o[d][g * 4 + 3] * inv);
-            }
+        }
         if (hh == 0) lse[((long)b * H + h) * L + qrow] = m + log2f(ltot);
     }
 }
