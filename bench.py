@@ -289,10 +289,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    # WECLIP_DIST_BACKEND=gloo is a rehearsal switch: N ranks sharing the GPUs that exist (LOCAL_RANK modulo the device
+    # count), gradients exchanged through the host -- exercises the launcher, rendezvous, barriers, graph capture with a
+    # process group alive and the rank-0 JSON on a one-GPU box.  The measured path is RCCL ("nccl"), one rank per GPU.
+    backend = os.environ.get("WECLIP_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
         if dist.get_world_size() != world:
             sys.exit("bench.py: RCCL reports a different world size than the launcher")
     import __graft_entry__
