@@ -104,11 +104,21 @@ __global__ __launch_bounds__(256) void par_affinity_reg_kernel(const float* __re
     const float c0 = I[p], c1 = I[HW + p], c2 = I[2 * HW + p];
     float v0[T], v1[T], v2[T];
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    // the 8 neighbours of a dilation d (build_taps order: rows y-d, y, y+d x columns x-d, x, x+d without the centre) from
+    // three clamped row offsets and three clamped columns: 6 clamps + 8 adds per dilation instead of 16 clamps + 8 multiplies
+    constexpr int RY[8] = {0, 0, 0, 1, 1, 2, 2, 2}, CX[8] = {0, 1, 2, 0, 2, 0, 1, 2};
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const long o = (long)clampi(y + taps.dy[t], H - 1) * W + clampi(x + taps.dx[t], W - 1);
-        v0[t] = I[o]; v1[t] = I[HW + o]; v2[t] = I[2 * HW + o];
-        s0 += v0[t]; s1 += v1[t]; s2 += v2[t];
+    for (int dl = 0; dl < ND; ++dl) {
+        const int d = taps.dx[8 * dl + 2];
+        const int rw[3] = {clampi(y - d, H - 1) * W, y * W, clampi(y + d, H - 1) * W};
+        const int cl[3] = {clampi(x - d, W - 1), x, clampi(x + d, W - 1)};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = 8 * dl + u;
+            const int o = rw[RY[u]] + cl[CX[u]];
+            v0[t] = I[o]; v1[t] = I[HW + o]; v2[t] = I[2 * HW + o];
+            s0 += v0[t]; s1 += v1[t]; s2 += v2[t];
+        }
     }
     const float m0 = s0 / T, m1 = s1 / T, m2 = s2 / T;
     float q0 = 0.f, q1 = 0.f, q2 = 0.f;
