@@ -64,9 +64,13 @@ class PAR(nn.Module):
         # the bytes of the HBM-bound sweep; |rounding error| <= max weight * 7.7e-6, error-diffused: csrc/par.hip)
         from .. import config
         h16 = T == 48 and not config.exact() and os.environ.get("WECLIP_PAR_F16", "1") != "0"
-        # group so that aff + masks of a group stay inside the 256 MiB Infinity Cache across the sweeps
+        # group so that aff + masks of a group stay (mostly) inside the 256 MiB Infinity Cache across the sweeps: measured
+        # at 512x512, C = 3, 16 images (fast form, 35.7 MB per image): groups of 6 / 7 / 8 / 9 / 16 -> 2.27 / 2.28 / 2.24 /
+        # 2.39 / 2.71 ms; the groups are balanced (16 images = 8 + 8, not 6 + 6 + 4)
         per_img = ((T // 2 + 1 if h16 else T) + 3 * C) * h * w * 4
-        group = max(1, min(b, (240 << 20) // max(per_img, 1)))   # measured best: 4 images at 512x512, C=3
+        gmax = max(1, min(b, (288 << 20) // max(per_img, 1)))
+        n_groups = -(-b // gmax)
+        group = -(-b // n_groups)
         if os.environ.get("WECLIP_PAR_GROUP"):
             group = max(1, min(b, int(os.environ["WECLIP_PAR_GROUP"])))
         out = torch.empty_like(masks)
