@@ -117,6 +117,29 @@ def test_val_mode_original_sizes(tmp_path):
     assert set(np.unique(labels[0].cpu().numpy())) <= {0, 4, 8}
 
 
+def test_coco_train_reads_labels_from_its_own_png_directory(tmp_path):
+    """The COCO model looks its GT PNGs up under <root>/SegmentationClass/train (model_attn_aff_coco.py:78,134), the VOC
+    model under <root>/SegmentationClassAug; labels read from the PNGs give the same pseudo-labels as labels passed in."""
+    from PIL import Image
+    from weclip_vit_comer_amd.WeCLIP_model.model_attn_aff_coco import WeCLIP
+    d = tmp_path / "SegmentationClass" / "train"
+    d.mkdir(parents=True)
+    for i, ids in enumerate(synth.TINY_LABELS):
+        png = np.zeros((H, W), np.uint8)
+        for j, c in enumerate(ids):
+            png[4 + 8 * j: 12 + 8 * j, 4:20] = c + 1
+        png[-3:, -3:] = 255
+        Image.fromarray(png).save(d / f"{1000 + i}.png")
+    sd = synth.make_clip_state_dict(**synth.TINY)
+    bg, fg = synth.make_text_features(20, 25, synth.TINY["embed_dim"])
+    m = WeCLIP(num_classes=21, clip_model=sd, embedding_dim=256, in_channels=[64] * 4,
+               dataset_root_path=str(tmp_path), device="cuda", text_features=(bg.cuda(), fg.cuda())).eval()
+    img = synth.make_images(2, H, W).cuda()
+    _, from_png, _ = m(img, [1000, 1001], mode="train")                     # integer image ids, as the COCO loader yields
+    _, given, _ = m(img, ["a", "b"], mode="train", labels=[sorted(ids) for ids in synth.TINY_LABELS])
+    assert torch.equal(from_png, given) and from_png.max().item() > 0
+
+
 def test_train_step_bucket_gradients_match_autograd_path():
     """TrainStep lets the HIP head write its gradients straight into the flat all-reduce bucket
     (HeadEngine.direct_grads); they must equal the gradients autograd receives without it."""

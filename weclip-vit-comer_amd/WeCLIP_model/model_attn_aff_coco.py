@@ -2,6 +2,8 @@
 model with CAM threshold 0.7, the last 10 attention maps in the seg-trans branch (switch at
 iteration 40000), an encoder that is not frozen by name, and `mode='val'` returning
 `(seg, None, attn_pred)` right after the decoder."""
+import os
+
 from .model_attn_aff_voc import WeCLIP as _VocWeCLIP, reshape_transform  # noqa: F401
 
 
@@ -15,3 +17,6 @@ class WeCLIP(_VocWeCLIP):
         super().__init__(*args, **kwargs)
         for p in self.encoder.parameters():     # the COCO model never freezes the encoder (:62-63);
             p.requires_grad = True              # it still only ever runs under no_grad / GradCAM
+        # GT PNGs: <root>/SegmentationClass/train/<name>.png (:78, :134) -- the VOC model reads <root>/SegmentationClassAug
+        root = kwargs.get("dataset_root_path", args[4] if len(args) > 4 else None)
+        self.root_path = os.path.join(root, "SegmentationClass", "train") if root else None
