@@ -382,11 +382,60 @@ def make_tiny_coco_msc():
           "classes predicted:", len(np.unique(np.concatenate([np.asarray(p).ravel() for p in msc_preds]))))
 
 
+COCO_TRAIN_LABELS = [[2, 41], [0, 17, 79]]       # class ids (0..79) present in the two images
+
+
+def make_tiny_coco_train(seg_trans):
+    """The COCO model's TRAIN forward (model_attn_aff_coco.py:100-170 -> clip_tool.perform_single_coco_cam :221-319:
+    80 classes + 23 background prompts, CAM threshold 0.7, GT PNGs under <root>/SegmentationClass/train; beyond
+    iteration 40 000 the seg-trans branch over the last 10 maps)."""
+    from PIL import Image
+    from WeCLIP_model.model_attn_aff_coco import WeCLIP
+    sd = synth.make_clip_state_dict(**TINY)
+    H, W = TINY_HW
+    img = synth.make_images(2, H, W, seed=600)
+    bg, fg = synth.make_text_features(80, 23, TINY["embed_dim"], seed=5)
+    fuse_sd, dec_sd = synth.make_head_state_dicts(width=TINY["width"], num_classes=81, seed=3)
+    with tempfile.TemporaryDirectory() as tmp:
+        ck = os.path.join(tmp, "clip_tiny.pt")
+        torch.save(sd, ck)
+        d = os.path.join(tmp, "SegmentationClass", "train")
+        os.makedirs(d)
+        names = []
+        for i, ids in enumerate(COCO_TRAIN_LABELS):
+            png = np.zeros((H, W), np.uint8)
+            for j, c in enumerate(ids):
+                png[4 + 8 * j: 12 + 8 * j, 4:20] = c + 1
+            png[-3:, -3:] = 255
+            Image.fromarray(png).save(os.path.join(d, f"{2000 + i}.png"))
+            names.append(2000 + i)
+        model = WeCLIP(num_classes=81, clip_model=ck, embedding_dim=256, in_channels=[TINY["width"]] * 4,
+                       dataset_root_path=tmp, device="cpu")
+        model.bg_text_features, model.fg_text_features = bg, fg
+        model.decoder_fts_fuse.load_state_dict(fuse_sd)
+        model.decoder.load_state_dict(dec_sd)
+        model.eval()
+        if seg_trans:
+            model.iter_num = 50000
+        with torch.no_grad():
+            pass
+        seg, cam_labels, ap = model(img, names)
+    out = dict(weights_ck=checksum(sd.values()), img_ck=checksum([img]), seg=seg.detach().numpy(),
+               cam_labels=cam_labels.numpy().astype(np.uint8), attn_pred=ap.detach().numpy())
+    fn = "tiny_coco_train_seg.npz" if seg_trans else "tiny_coco_train.npz"
+    np.savez_compressed(os.path.join(OUT, fn), **out)
+    print(fn, "written; labels present:", np.unique(out["cam_labels"]))
+
+
 if __name__ == "__main__":
     refharness.install()
     torch.manual_seed(0)
     if len(sys.argv) > 1 and sys.argv[1] == "coco":
         make_tiny_coco_msc()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "coco_train":
+        make_tiny_coco_train(False)
+        make_tiny_coco_train(True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "512":        # only the benchmark-size fixtures
         make_vitb_512(False)
@@ -399,3 +448,5 @@ if __name__ == "__main__":
     make_vitb_512(False)
     make_vitb_512(True)
     make_tiny_coco_msc()
+    make_tiny_coco_train(False)
+    make_tiny_coco_train(True)
