@@ -106,6 +106,25 @@ def test_whole_forward_and_backward_match_reference(tiny, golden, seg_trans):
     np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-3, atol=1e-7)
 
 
+@pytest.mark.parametrize("seg_trans", [False, True])
+def test_coco_train_forward_matches_reference(golden, seg_trans):
+    """The oracle's COCO configuration (80 + 23 prompts, CAM threshold 0.7, last 10 maps in the seg-trans branch) against the
+    reference COCO model's own train forward."""
+    g = golden("tiny_coco_train_seg.npz" if seg_trans else "tiny_coco_train.npz")
+    sd = synth.make_clip_state_dict(**synth.TINY)
+    img = synth.make_images(2, H, W, seed=600)
+    _check_inputs(g, sd, img)
+    bg, fg = synth.make_text_features(80, 23, synth.TINY["embed_dim"], seed=5)
+    fuse, dec = synth.make_head_state_dicts(width=synth.TINY["width"], num_classes=81, seed=3)
+    with torch.no_grad():
+        seg, labels, ap = O.weclip_forward(img, [[2, 41], [0, 17, 79]], sd, fuse, dec, bg, fg, heads=1, seg_trans=seg_trans,
+                                           dataset="coco")
+    np.testing.assert_allclose(seg.numpy(), g["seg"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(ap.numpy(), g["attn_pred"], rtol=0, atol=1e-5)
+    assert (labels.numpy() != g["cam_labels"]).mean() <= 1e-3
+    assert set(np.unique(g["cam_labels"])) >= {0, 1, 42}
+
+
 def test_vitb_224_config0_matches_reference(golden):
     """BASELINE config 0: ViT-B/16-sized weights, 224x224, encode + GradCAM + affinity."""
     g = golden("vitb_224.npz")
