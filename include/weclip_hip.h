@@ -402,9 +402,13 @@ int wc_confusion_hist(const long* label_true, const long* label_pred, long* hist
 /* datasets/transforms.py:26-49 (random_scaling), :70-84 (random_fliplr), :119-176 (random_crop, zero padding),
  * :8-15 (normalize_img) + HWC->CHW (datasets/voc.py:137-143) for a batch in one gather kernel.
  * src_u8 (B,Hs,Ws,3) uint8; params: B records of 8 x 32 bit {float scale; int flip, rh, rw, pad_y, pad_x, crop_y, crop_x}
- * (device memory; the random draws are made on the host); dst (B,3,crop,crop) f32; mean3 / std3: HOST float[3].
- * Half-pixel bilinear resampling, rounded to the uint8 grid like the reference's resize output. */
-int wc_augment_normalize(const void* src_u8, const void* params, float* dst, int B, int Hs, int Ws, int crop,
+ * (device memory; the random draws are made on the host); dst (B,3,crop,crop) f32; mean3 / std3: HOST float[3];
+ * coeff_ws: device scratch of *n_ints ints as reported by wc_augment_workspace_ints(B, crop, &n_ints) (the per-coordinate filter tables).
+ * The rescale is Pillow's Image.BILINEAR for 8-bit images reproduced exactly (transforms.py:41: triangle filter of support
+ * max(in/out, 1), double-precision coefficients rounded to 22-bit fixed point, uint8 rounding after the horizontal and after
+ * the vertical pass); in/out <= 4 (the caller checks: rescale_range is [0.5, 2.0]). */
+int wc_augment_workspace_ints(int B, int crop, long* n_ints);       /* HOST out-parameter */
+int wc_augment_normalize(const void* src_u8, const void* params, float* dst, int* coeff_ws, int B, int Hs, int Ws, int crop,
                          const float* mean3, const float* std3, void* stream);
 
 #ifdef __cplusplus

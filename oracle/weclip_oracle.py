@@ -444,26 +444,65 @@ def fast_hist(label_true, label_pred, num_classes):
     return np.bincount(num_classes * lt[keep] + lp[keep], minlength=num_classes ** 2).reshape(num_classes, num_classes)
 
 
+def _pil_coeffs(in_size, out_size):
+    """Pillow's `precompute_coeffs` + `normalize_coeffs_8bpc` for Image.BILINEAR (what datasets/transforms.py:41 calls):
+    triangle filter of support max(in/out, 1); per output coordinate the first tap, the tap count and the coefficients,
+    normalised in double precision (taps accumulated in order) and rounded to 22-bit fixed point."""
+    scale = float(np.float32(in_size) - np.float32(0.0)) / out_size
+    fscale = max(scale, 1.0)
+    support = 1.0 * fscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    ss = 1.0 / fscale
+    center = 0.0 + (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)             # C (int) cast: truncation
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size)
+    n = xmax - xmin
+    k = np.zeros((out_size, ksize), np.float64)
+    ww = np.zeros(out_size, np.float64)
+    for x in range(ksize):
+        a = np.abs(((x + xmin).astype(np.float64) - center + 0.5) * ss)
+        k[:, x] = np.where((x < n) & (a < 1.0), 1.0 - a, 0.0)
+        ww = ww + k[:, x]
+    k = np.where(ww[:, None] != 0.0, k / ww[:, None], k)
+    return xmin, n, (0.5 + k * float(1 << 22)).astype(np.int64)
+
+
+def pil_bilinear_u8(img_u8, rw, rh):
+    """`Image.fromarray(img).resize([rw, rh], resample=Image.BILINEAR)` for an (H,W,C) uint8 array, restated: horizontal
+    pass (fixed-point accumulate from 2^21, >> 22, clip to uint8), then the vertical pass over that uint8 image.
+    Equal to real Pillow on every pixel (tests/test_oracle_golden.py checks it when PIL is importable)."""
+    src = np.asarray(img_u8).astype(np.int64)
+    H, W, C = src.shape
+    xmin, _, kx = _pil_coeffs(W, rw)
+    ymin, _, ky = _pil_coeffs(H, rh)
+    tmp = np.full((H, rw, C), 1 << 21, np.int64)
+    for j in range(kx.shape[1]):
+        tmp += src[:, np.minimum(xmin + j, W - 1), :] * kx[None, :, j, None]     # taps beyond the count have weight 0
+    tmp = np.clip(tmp >> 22, 0, 255)
+    out = np.full((rh, rw, C), 1 << 21, np.int64)
+    for j in range(ky.shape[1]):
+        out += tmp[np.minimum(ymin + j, H - 1)] * ky[:, j, None, None]
+    return np.clip(out >> 22, 0, 255).astype(np.uint8)
+
+
 def augment_normalize(img_u8, scale, flip, pad_y, pad_x, crop_y, crop_x, crop, mean=(123.675, 116.28, 103.53),
                       std=(58.395, 57.12, 57.375)):
     """One image of the train-time input chain, datasets/voc.py:108-143 with the random draws given:
-    random_scaling (transforms.py:26-49; bilinear to (int(s*h), int(s*w)), rounded to uint8 -- half-pixel bilinear
-    here, which is PIL's BILINEAR for s >= 1 only), random_fliplr (:70-84), random_crop (:119-176, zero canvas),
-    normalize_img (:8-15), HWC -> CHW.  img_u8 (H,W,3) uint8 -> (3,crop,crop) f32."""
-    H, W, _ = img_u8.shape
+    random_scaling (transforms.py:26-49: PIL BILINEAR to (int(s*w), int(s*h)), uint8 result), random_fliplr (:70-84),
+    random_crop (:119-176, zero canvas), normalize_img (:8-15, float32), HWC -> CHW.
+    img_u8 (H,W,3) uint8 -> (3,crop,crop) f32."""
+    img = np.asarray(img_u8)
+    H, W, _ = img.shape
     rh, rw = int(scale * H), int(scale * W)
-    x = img_u8.permute(2, 0, 1).float()[None]
-    x = F.interpolate(x, size=(rh, rw), mode="bilinear", align_corners=False)[0]
-    x = torch.clamp(torch.floor(x + 0.5), 0, 255)
+    x = pil_bilinear_u8(img, rw, rh).astype(np.float32)
     if flip:
-        x = x.flip(-1)
+        x = x[:, ::-1]
     ch, cw = max(crop, rh), max(crop, rw)
-    canvas = torch.zeros(3, ch, cw)
-    canvas[:, pad_y:pad_y + rh, pad_x:pad_x + rw] = x
-    out = canvas[:, crop_y:crop_y + crop, crop_x:crop_x + crop]
-    m = torch.tensor(mean).view(3, 1, 1)
-    s = torch.tensor(std).view(3, 1, 1)
-    return (out - m) / s
+    canvas = np.zeros((ch, cw, 3), np.float32)
+    canvas[pad_y:pad_y + rh, pad_x:pad_x + rw] = x
+    out = canvas[crop_y:crop_y + crop, crop_x:crop_x + crop]
+    out = (out - np.asarray(mean, np.float32)) / np.asarray(std, np.float32)
+    return torch.from_numpy(np.ascontiguousarray(out.transpose(2, 0, 1)))
 
 
 # ----------------------------------------------------------------------------- A.10

@@ -16,8 +16,12 @@ Outputs (committed, data only -- no reference source):
                    different sizes at scales (1, 0.75): per-image predictions, both confusion histograms, scores
   vitb_512.npz     the benchmark size: whole `WeCLIP.forward` (VOC model, ViT-B/16-sized synthetic
   vitb_512_seg.npz weights) on image 3 of bench.py's B=16 512x512 batch, normal / seg-trans branch;
+  vitb_512_seg_sink.npz  the seg-trans branch once more with per-block CLS attention sinks (synth.SINK_512) so that
+                   the discrete layer selection is decided by the data, not by fp32 rounding;
                    every stage of the CAM chain recorded by wrapping (not editing) the reference's own
                    functions: class probabilities, CAM maps, affinity, T rows, refined CAMs, PAR rows, labels
+  augment_ref.npz  the reference's train-time input chain (datasets/transforms.py: PIL BILINEAR rescale, flip, zero-pad
+                   + crop, normalise) on six small uint8 images, up- and down-scaling, with every random draw recorded
 Inputs are regenerated from oracle/synth.py seeds; each fixture stores a checksum of the
 weights and the image so a drifting RNG is detected instead of silently mis-compared.
 """
@@ -216,7 +220,7 @@ def make_vitb_224():
 BENCH_IMG = 3          # image of bench.py's batch (synth.make_images(16, 512, 512, seed=100)) the 512x512 fixture is made of
 
 
-def make_vitb_512(seg_trans):
+def make_vitb_512(seg_trans, sink=None):
     """Whole reference `WeCLIP.forward` at the benchmark size on ONE image of the benchmark batch.  The
     intermediate stages are recorded by wrapping the reference's own callables at generation time
     (GradCAM.__call__, compute_trans_mat, perform_single_voc_cam, PAR.forward); nothing is edited."""
@@ -226,7 +230,7 @@ def make_vitb_512(seg_trans):
     from pytorch_grad_cam.base_cam import BaseCAM
 
     H = W = 512
-    sd = synth.make_clip_state_dict(seed=0, with_text=True)
+    sd = synth.make_clip_state_dict(seed=0, with_text=True, cls_sink=sink)
     img = synth.make_images(16, H, W, seed=100)[BENCH_IMG:BENCH_IMG + 1].contiguous()
     ids = synth.make_label_lists(16, 2, seed=7)[BENCH_IMG]
     bg, fg = synth.make_text_features(20, 25, 512)
@@ -301,8 +305,13 @@ def make_vitb_512(seg_trans):
                cam_labels=cam_labels[0].numpy().astype(np.uint8),
                seg=seg[0].detach().numpy().astype(np.float32), attn_pred_rows=ap[0, ::64].detach().numpy().astype(np.float32))
     fn = "vitb_512_seg.npz" if seg_trans else "vitb_512.npz"
+    if sink is not None:
+        assert seg_trans
+        fn = "vitb_512_seg_sink.npz"
+        out["cls_sink"] = np.array(sink, np.float64)
     np.savez_compressed(os.path.join(OUT, fn), **out)
-    print(fn, "written; probs:", out["probs"][:, :2], "labels:", np.unique(out["cam_labels"], return_counts=True))
+    print(fn, "written; probs:", out["probs"][:, :2], "labels:", np.unique(out["cam_labels"], return_counts=True),
+          "layer selection:", out["keep_ref"].astype(int), "A_l:", np.round(out["A64"], 3))
 
 
 COCO_SIZES = [(80, 112), (96, 64), (71, 100)]      # synthetic "original" image sizes (the last one is odd on purpose)
@@ -427,9 +436,73 @@ def make_tiny_coco_train(seg_trans):
     print(fn, "written; labels present:", np.unique(out["cam_labels"]))
 
 
+AUG_SEED, AUG_CROP, AUG_SRC = 31, 64, (54, 76)
+
+
+def augment_inputs():
+    """uint8 (6, 54, 76, 3) "decoded JPEGs": smooth structure + noise, shared by the generator and the tests."""
+    f = synth.make_images(6, AUG_SRC[0], AUG_SRC[1], seed=700)
+    return (f * 58.0 + 118.0).clamp_(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+
+
+def make_augment():
+    """The reference's train-time input chain on six small images: datasets/transforms.py random_scaling (PIL BILINEAR)
+    -> random_fliplr -> random_crop -> normalize_img -> CHW, called in the order of datasets/voc.py:109-143
+    (`VOC12ClsDataset.__transforms`; that module itself needs numpy.lib.utils / imageio / torchvision at import time, so the
+    four calls are made here).  The reference's random sources are replaced by seeded recording proxies of the same
+    generators (`random.Random`, `np.random.RandomState`), so the fixture holds every draw next to the output."""
+    import random as pyrandom
+    import datasets.transforms as T
+    assert T.__file__.startswith(refharness.REF)
+    imgs = augment_inputs().numpy()
+    draws = []
+
+    class Rec:
+        def __init__(self, rng):
+            self.rng = rng
+
+        def __getattr__(self, name):
+            fn = getattr(self.rng, name)
+
+            def call(*a, **k):
+                v = fn(*a, **k)
+                draws[-1].append((name, float(v)))
+                return v
+            return call
+
+    py = Rec(pyrandom.Random(AUG_SEED))
+    nprs = Rec(np.random.RandomState(AUG_SEED))
+    orig_random, orig_randint = T.random, np.random.randint
+    T.random, np.random.randint = py, nprs.randint
+    outs, boxes = [], []
+    try:
+        for b in range(len(imgs)):
+            draws.append([])
+            image = np.array(imgs[b])
+            image = T.random_scaling(image, scale_range=[0.5, 2.0])
+            image = T.random_fliplr(image)
+            image, img_box = T.random_crop(image, crop_size=AUG_CROP, mean_rgb=[0, 0, 0], ignore_index=255)
+            image = T.normalize_img(image)
+            outs.append(np.transpose(image, (2, 0, 1)))
+            boxes.append(img_box)
+    finally:
+        T.random, np.random.randint = orig_random, orig_randint
+    names = [[n for n, _ in d] for d in draws]
+    assert all(n == ["uniform", "random", "randint", "randint", "randrange", "randrange"] for n in names), names
+    vals = np.array([[v for _, v in d] for d in draws], np.float64)            # (6, 6): scale, p_flip, pad_y, pad_x, crop_y, crop_x
+    assert (vals[:, 0] < 0.9).sum() >= 2 and (vals[:, 0] > 1.1).sum() >= 2, vals[:, 0]
+    out = dict(img_ck=checksum([torch.from_numpy(imgs)]), seed=np.int64(AUG_SEED), crop=np.int64(AUG_CROP), draws=vals,
+               out=np.stack(outs).astype(np.float32), img_box=np.stack(boxes).astype(np.int64))
+    np.savez_compressed(os.path.join(OUT, "augment_ref.npz"), **out)
+    print("augment_ref.npz written; scales", np.round(vals[:, 0], 3), "flips", (vals[:, 1] > 0.5).astype(int))
+
+
 if __name__ == "__main__":
     refharness.install()
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "augment":
+        make_augment()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "coco":
         make_tiny_coco_msc()
         sys.exit(0)
@@ -440,6 +513,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "512":        # only the benchmark-size fixtures
         make_vitb_512(False)
         make_vitb_512(True)
+        make_vitb_512(True, synth.SINK_512)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "512sink":
+        make_vitb_512(True, synth.SINK_512)
         sys.exit(0)
     make_tiny_func()
     make_tiny_whole(False)
@@ -447,6 +524,8 @@ if __name__ == "__main__":
     make_vitb_224()
     make_vitb_512(False)
     make_vitb_512(True)
+    make_vitb_512(True, synth.SINK_512)
     make_tiny_coco_msc()
     make_tiny_coco_train(False)
     make_tiny_coco_train(True)
+    make_augment()

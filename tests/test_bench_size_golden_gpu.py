@@ -13,10 +13,9 @@ pytestmark = pytest.mark.gpu
 B, S, K = 16, 512, 2
 
 
-@pytest.fixture(scope="module")
-def bench_model():
+def _make_model(cls_sink=None):
     from weclip_vit_comer_amd.WeCLIP_model.model_attn_aff_voc import WeCLIP
-    sd = synth.make_clip_state_dict(seed=0, with_text=False)
+    sd = synth.make_clip_state_dict(seed=0, with_text=False, cls_sink=cls_sink)
     bg, fg = synth.make_text_features(20, 25, 512)
     fuse, dec = synth.make_head_state_dicts()
     m = WeCLIP(num_classes=21, clip_model=sd, embedding_dim=256, in_channels=[768] * 4, dataset_root_path=None,
@@ -26,20 +25,38 @@ def bench_model():
     return m.eval()
 
 
+@pytest.fixture(scope="module")
+def bench_model():
+    return _make_model()
+
+
+@pytest.fixture(scope="module")
+def sink_model():
+    """The same weights with per-block CLS attention sinks (synth.SINK_512): the six candidate layers of the seg-trans
+    selection then differ in A_l by 2.4 ... 26 from their mean, two orders of magnitude above the reference's fp32
+    quantum, so `vitb_512_seg_sink.npz` tests the discrete decision itself."""
+    return _make_model(synth.SINK_512)
+
+
 def _rel(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return np.abs(a - b).max() / np.abs(b).max()
 
 
-@pytest.mark.parametrize("seg_trans,precision", [(False, "fast"), (True, "fast"), (True, "exact")])
-def test_cam_chain_at_512_matches_reference(golden, bench_model, seg_trans, precision, monkeypatch):
+@pytest.mark.parametrize("seg_trans,precision", [(False, "fast"), (True, "fast"), (True, "exact"),
+                                                 ("sink", "fast"), ("sink", "exact")])
+def test_cam_chain_at_512_matches_reference(golden, request, seg_trans, precision, monkeypatch):
     from weclip_vit_comer_amd import config
     monkeypatch.setattr(config, "precision", precision)
     from weclip_vit_comer_amd import cam_pipeline as CP
     from weclip_vit_comer_amd.clip import clip_tool as CT
-    g = golden("vitb_512_seg.npz" if seg_trans else "vitb_512.npz")
+    sink = seg_trans == "sink"
+    seg_trans = bool(seg_trans)
+    g = golden("vitb_512_seg_sink.npz" if sink else "vitb_512_seg.npz" if seg_trans else "vitb_512.npz")
     i = int(g["img_index"])
-    m = bench_model
+    m = request.getfixturevalue("sink_model" if sink else "bench_model")
+    if sink:
+        assert g["cls_sink"].tolist() == synth.SINK_512
     img = synth.make_images(B, S, S, seed=100)
     assert abs(float(synth.checksum([img[i:i + 1]])) - float(g["img_ck"])) < 1e-6 * abs(float(g["img_ck"]))
     labels = synth.make_label_lists(B, K, seed=7)
@@ -49,7 +66,18 @@ def test_cam_chain_at_512_matches_reference(golden, bench_model, seg_trans, prec
     m.iter_num = 20000 if seg_trans else 0
     keep = None
     with torch.no_grad():
-        if seg_trans:
+        if sink:
+            # the fixture with signal: NOTHING of the reference is fed in; the HIP path's own selection must be the
+            # reference's (and the exact one), and everything downstream is compared end to end
+            xs0, maps0, _, _ = m.encode(img, True)
+            st0 = CT.last_layer_forward(m.encoder, xs0[-1], B, xs0[-1].shape[0] // B)
+            mine = CP.seg_layer_keep(list(maps0) + [st0.mean], m.seg_trans_last)[i].cpu().numpy() > 0
+            A64 = g["A64"]
+            assert np.abs(A64 - A64.mean()).min() > 1.0
+            assert (mine == g["keep_ref"]).all() and (mine == (A64 >= A64.mean())).all(), (mine, g["keep_ref"], A64)
+            assert 0 < mine.sum() < len(mine)
+            del xs0, maps0, st0
+        elif seg_trans:
             # The layer selection keep_l = [sum(seg - map_l) <= mean] is a DISCRETE decision.  With these synthetic
             # weights every layer has A_l = sum(map_l[1:,1:]) = 1023.7 +- 0.04, while the reference forms the sums at
             # magnitude 1e6, where fp32 is quantised to 1/8: its own decision is set by its summation's rounding, not by

@@ -147,3 +147,71 @@ def test_vitb_224_config0_matches_reference(golden):
             np.testing.assert_allclose(T[::28].numpy(), g["trans_rows"], rtol=1e-4, atol=1e-9)
         r = O.refine_cam(T, cam, O.box_mask(cam, 0.4))
         np.testing.assert_allclose(r.numpy(), g["refined"][j], rtol=1e-3, atol=1e-6)
+
+
+def test_vitb_512_seg_sink_matches_reference(golden):
+    """The benchmark-size seg-trans fixture WITH layer-selection signal (synth.SINK_512: the six candidate layers differ by
+    2.4 ... 26 in A_l): the oracle's whole forward on that one image against the reference's own -- selection, transition
+    matrix, refined CAMs, PAR output, labels."""
+    g = golden("vitb_512_seg_sink.npz")
+    sd = synth.make_clip_state_dict(seed=0, with_text=False, cls_sink=synth.SINK_512)
+    if synth.checksum([sd[k] for k in sorted(sd) if k.startswith("visual")]) != g["weights_ck"]:
+        pytest.skip("synthetic RNG stream differs from fixture")
+    i = int(g["img_index"])
+    img = synth.make_images(16, 512, 512, seed=100)[i:i + 1].contiguous()
+    ids = synth.make_label_lists(16, 2, seed=7)[i]
+    assert ids == g["ids"].tolist()
+    bg, fg = synth.make_text_features(20, 25, 512)
+    fuse, dec = synth.make_head_state_dicts()
+    A64 = g["A64"]
+    assert (g["keep_ref"] == (A64 >= A64.mean())).all() and np.abs(A64 - A64.mean()).min() > 1.0
+    with torch.no_grad():
+        seg, labels, ap, aux = O.weclip_forward(img, [ids], sd, fuse, dec, bg, fg, heads=12, seg_trans=True, return_aux=True)
+    a = aux[0]
+    np.testing.assert_allclose(a["probs"][0], g["probs"][0], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(a["cams"], g["cams"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(a["trans"][::64], g["trans_rows"], rtol=2e-3, atol=1e-9)
+    np.testing.assert_allclose(a["refined"], g["refined"], rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(a["par"][:, ::16], g["par_out_rows"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(seg[0].numpy(), g["seg"], rtol=0, atol=2e-4)
+    assert (labels[0].numpy() != g["cam_labels"]).mean() <= 5e-4
+
+
+def _augment_inputs():
+    f = synth.make_images(6, 54, 76, seed=700)
+    return (f * 58.0 + 118.0).clamp_(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+
+
+def test_input_pipeline_oracle_matches_reference_transforms(golden):
+    """f-1: the oracle's restatement of the reference's train-time chain (datasets/transforms.py random_scaling with PIL
+    BILINEAR, random_fliplr, random_crop, normalize_img; order of datasets/voc.py:109-143) against the fixture the
+    reference's own functions produced -- every pixel EQUAL, up- and down-scaling -- and the host-side draws of
+    `data.DeviceAugment` against the recorded draws of the reference's random sources."""
+    from weclip_vit_comer_amd.data import DeviceAugment
+    g = golden("augment_ref.npz")
+    imgs = _augment_inputs()
+    assert synth.checksum([imgs]) == g["img_ck"]
+    crop, d = int(g["crop"]), g["draws"]
+    assert (d[:, 0] < 0.9).sum() >= 2 and (d[:, 0] > 1.1).sum() >= 2
+    aug = DeviceAugment(crop_size=crop, rescale_range=(0.5, 2.0), seed=int(g["seed"]))
+    for b in range(len(imgs)):
+        s, flip, rh, rw, pad_y, pad_x, crop_y, crop_x = aug.draw_one(54, 76)
+        assert [s, pad_y, pad_x, crop_y, crop_x] == [d[b, 0], d[b, 2], d[b, 3], d[b, 4], d[b, 5]] and flip == int(d[b, 1] > 0.5)
+        out = O.augment_normalize(imgs[b], s, flip, pad_y, pad_x, crop_y, crop_x, crop)
+        assert np.array_equal(out.numpy(), g["out"][b]), (b, s, np.abs(out.numpy() - g["out"][b]).max())
+        # img_box of random_crop (transforms.py:160-164) from the same draws
+        box = [max(pad_y - crop_y, 0), min(crop_y + crop, pad_y + rh), max(pad_x - crop_x, 0), min(crop_x + crop, pad_x + rw)]
+        assert box == g["img_box"][b].tolist()
+
+
+def test_pil_bilinear_restatement_equals_pillow():
+    """`O.pil_bilinear_u8` against the installed Pillow itself (same library the reference calls), random sizes and ratios."""
+    Image = pytest.importorskip("PIL.Image")
+    rs = np.random.RandomState(3)
+    for t in range(12):
+        H, W = int(rs.randint(8, 90)), int(rs.randint(8, 120))
+        s = float(rs.uniform(0.3, 2.3))
+        img = rs.randint(0, 256, (H, W, 3)).astype(np.uint8)
+        rw, rh = max(int(s * W), 1), max(int(s * H), 1)
+        ref = np.asarray(Image.fromarray(img).resize([rw, rh], resample=Image.BILINEAR))
+        assert np.array_equal(O.pil_bilinear_u8(img, rw, rh), ref), (H, W, s)

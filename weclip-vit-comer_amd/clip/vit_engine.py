@@ -87,8 +87,9 @@ def run_block(pk, x, B, L, want_mean=True, keep=None, x16_out=None, tag=None):
     x2 = torch.empty(M, E, device=dev, dtype=F32)
     x2h = None
     if x16_out is not None:     # fp16 copy of the block output for the adapter GEMMs (no extra pass)
-        nxt = x16_out.next_slot(M, E, dev, ex) if isinstance(x16_out, X16Stack) else None
-        x2h = nxt or Split(torch.empty(M, E, device=dev, dtype=F16), torch.empty(M, E, device=dev, dtype=F16) if ex else None)
+        exo = ex or bool(int(config.head_lo) & 32)          # the adapters' input tokens carry their fp16 remainder
+        nxt = x16_out.next_slot(M, E, dev, exo) if isinstance(x16_out, X16Stack) else None
+        x2h = nxt or Split(torch.empty(M, E, device=dev, dtype=F16), torch.empty(M, E, device=dev, dtype=F16) if exo else None)
         x16_out.append(x2h)
     ops.gemm(z, pk.pj_w, M, E, 4 * E, bias=pk.pj_b, resid=x1, out32=x2,
              out16=x2h.hi if x2h else None, out16lo=x2h.lo if x2h else None)

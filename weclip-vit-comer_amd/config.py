@@ -11,3 +11,10 @@ precision = os.environ.get("WECLIP_PRECISION", "fast")
 
 def exact():
     return precision == "exact"
+
+
+# `fast` precision only: which operands of the adapter -> fuse chain in front of attn_pred = sigmoid(F^T F) carry their fp16
+# remainder (hi+lo) in the FORWARD GEMMs.  Bit mask: 1 = cat (fuse input), 2 = linear_fuse weight, 4 = t1 (proj output),
+# 8 = proj_2 weights, 16 = proj weights, 32 = the encoder's block outputs (the adapters' input).  attn_pred squares F's rounding error (256-long Gram product) and feeds
+# get_aff_loss and the seg-trans affinity; measured at 512^2 against the reference fixture: see DESIGN.md §3.
+head_lo = int(os.environ.get("WECLIP_HEAD_LO", "0"))

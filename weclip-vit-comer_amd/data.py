@@ -58,30 +58,49 @@ STD = (58.395, 57.12, 57.375)
 
 class DeviceAugment:
     """The reference's train-time augmentation (datasets/voc.py:108-143: random_scaling -> random_fliplr -> random_crop
-    -> normalize_img -> CHW) with the random draws on the host and the pixel work in ONE HIP kernel per batch
-    (csrc/augment.hip): uint8 (B,H,W,3) on the device in, float32 (B,3,crop,crop) normalised out.  The host never
-    touches a pixel, so the loader cannot serialise the step."""
+    -> normalize_img -> CHW) with the random draws on the host and the pixel work in HIP kernels (csrc/augment.hip):
+    uint8 (B,H,W,3) on the device in, float32 (B,3,crop,crop) normalised out, the rescale being Pillow's BILINEAR for
+    8-bit images bit for bit (up- and down-scaling).  The host never touches a pixel, so the loader cannot serialise
+    the step.
 
-    def __init__(self, crop_size=512, rescale_range=(0.5, 2.0), fliplr=True, seed=0, mean=MEAN, std=STD):
+    The draws follow the reference's own sources and order per image -- `random.uniform` (scale, transforms.py:31),
+    `random.random` (flip, :71), `np.random.randint` x 2 (pad offsets, :134-135), `random.randrange` x 2 (crop box,
+    :143-146; without a label map the first box is taken) -- from private `random.Random(seed)` /
+    `np.random.RandomState(seed)` instances, so a loader seeded like the reference's worker produces its crops."""
+
+    def __init__(self, crop_size=512, rescale_range=(0.5, 2.0), fliplr=True, seed=0, mean=MEAN, std=STD, np_seed=None):
+        import random
         import numpy as np
-        self.crop, self.range, self.fliplr = int(crop_size), tuple(rescale_range), bool(fliplr)
-        self.rng = np.random.RandomState(seed)
+        self.crop, self.range, self.fliplr = int(crop_size), tuple(rescale_range) if rescale_range else None, bool(fliplr)
+        self.py_rng = random.Random(seed)
+        self.np_rng = np.random.RandomState(seed if np_seed is None else np_seed)
         self.mean, self.std = tuple(float(v) for v in mean), tuple(float(v) for v in std)
+        self._ws = None
+
+    def draw_one(self, H, W):
+        """(scale, flip, rh, rw, pad_y, pad_x, crop_y, crop_x) of one image."""
+        s = self.py_rng.uniform(*self.range) if self.range else 1.0
+        rh, rw = (int(s * H), int(s * W)) if self.range else (H, W)
+        flip = int(self.py_rng.random() > 0.5) if self.fliplr else 0
+        ch, cw = max(self.crop, rh), max(self.crop, rw)                  # canvas (transforms.py:123-124)
+        pad_y, pad_x = int(self.np_rng.randint(ch - rh + 1)), int(self.np_rng.randint(cw - rw + 1))
+        crop_y = self.py_rng.randrange(0, ch - self.crop + 1, 1)
+        crop_x = self.py_rng.randrange(0, cw - self.crop + 1, 1)
+        return s, flip, rh, rw, pad_y, pad_x, crop_y, crop_x
+
+    @staticmethod
+    def pack(draws):
+        """List of draw_one() tuples -> int32 tensor (B, 8) in the kernel's record layout."""
+        import numpy as np
+        rec = np.zeros((len(draws), 8), np.int32)
+        for b, d in enumerate(draws):
+            rec[b, 0] = np.float32(d[0]).view(np.int32)
+            rec[b, 1:] = d[1:]
+        return torch.from_numpy(rec)
 
     def draw(self, B, H, W):
         """Host-side random parameters of one batch -> int32 tensor (B, 8) in the kernel's record layout."""
-        import numpy as np
-        rec = np.zeros((B, 8), np.int32)
-        for b in range(B):
-            s = self.rng.uniform(*self.range) if self.range else 1.0
-            rh, rw = int(s * H), int(s * W)
-            flip = int(self.fliplr and self.rng.rand() > 0.5)
-            ch, cw = max(self.crop, rh), max(self.crop, rw)                  # canvas (transforms.py:123-124)
-            pad_y, pad_x = int(self.rng.randint(ch - rh + 1)), int(self.rng.randint(cw - rw + 1))
-            crop_y, crop_x = int(self.rng.randint(ch - self.crop + 1)), int(self.rng.randint(cw - self.crop + 1))
-            rec[b, 0] = np.float32(s).view(np.int32)
-            rec[b, 1:] = (flip, rh, rw, pad_y, pad_x, crop_y, crop_x)
-        return torch.from_numpy(rec)
+        return self.pack([self.draw_one(H, W) for _ in range(B)])
 
     def __call__(self, images_u8, params=None):
         """images_u8 (B,H,W,3) uint8 CUDA; params: a draw() result (default: a fresh draw).  -> (B,3,crop,crop) f32."""
@@ -93,9 +112,17 @@ class DeviceAugment:
             raise RuntimeError("DeviceAugment expects uint8 (B, H, W, 3) images")
         if params is None:
             params = self.draw(B, H, W)
+        if not params.is_cuda:
+            rhw = params[:, 2:4]
+            if int(rhw.min()) < 1 or H > 4 * int(rhw[:, 0].min()) or W > 4 * int(rhw[:, 1].min()):
+                raise RuntimeError("DeviceAugment: rescaled size must be >= 1 and down-scaling at most 4x")
         p = params.pin_memory().to(images_u8.device, non_blocking=True) if not params.is_cuda else params
         out = torch.empty(B, 3, self.crop, self.crop, device=images_u8.device, dtype=torch.float32)
+        n = ctypes.c_long(0)
+        L.lib().wc_augment_workspace_ints(B, self.crop, ctypes.byref(n))
+        if self._ws is None or self._ws.numel() < n.value or self._ws.device != images_u8.device:
+            self._ws = torch.empty(n.value, device=images_u8.device, dtype=torch.int32)
         L.lib().wc_augment_normalize(L.ptr(images_u8.contiguous(), torch.uint8, "images"), L.ptr(p, torch.int32, "params"),
-                                     L.ptr(out), B, H, W, self.crop, (ctypes.c_float * 3)(*self.mean),
-                                     (ctypes.c_float * 3)(*self.std), L.stream())
+                                     L.ptr(out), L.ptr(self._ws, torch.int32), B, H, W, self.crop,
+                                     (ctypes.c_float * 3)(*self.mean), (ctypes.c_float * 3)(*self.std), L.stream())
         return out

@@ -88,7 +88,17 @@ class HeadEngine:
         E, hw, M = self.E, h * w, B * h * w
         n = self.index
         wc = self.wcache
-        wc.refresh(self._weight_matrices(), ex, force=self.fuse.training or self.dec.training)
+        hl = 63 if ex else int(config.head_lo)
+        lo_names = set()
+        if hl & 2:
+            lo_names.add("fuse")
+        for l in range(n):
+            if hl & 8:
+                lo_names.add(f"ad{l}.proj_2")
+            if hl & 16:
+                lo_names.add(f"ad{l}.proj")
+        wc.refresh(self._weight_matrices(), ex, force=self.fuse.training or self.dec.training,
+                   lo_names=() if (ex or F_rows is not None) else lo_names)
         if F_rows is not None:
             dev = F_rows.device
             ctx = dict(B=B, L=Lq, h=h, w=w, xs=None, drop=None, ex=ex, front=False)
@@ -100,10 +110,11 @@ class HeadEngine:
         dev = xs[0].hi.device
         ctx = dict(B=B, L=Lq, h=h, w=w, xs=xs, drop=drop_scale, ex=ex, front=True)
         # adapters: t1 = relu(X W1^T + b1); cat[:, l] = t1 W2^T + b2
-        cat = Split(torch.empty(M, n * E, device=dev, dtype=F16), torch.empty(M, n * E, device=dev, dtype=F16) if ex else None)
-        t1b = Split(torch.empty(n, M, E, device=dev, dtype=F16), torch.empty(n, M, E, device=dev, dtype=F16) if ex else None)
-        t1s = [Split(t1b.hi[l], t1b.lo[l] if ex else None) for l in range(n)]
-        grp = self._adapter_groups(xs, B, Lq, C, ex)
+        cat = Split(torch.empty(M, n * E, device=dev, dtype=F16), torch.empty(M, n * E, device=dev, dtype=F16) if hl & 1 else None)
+        t1b = Split(torch.empty(n, M, E, device=dev, dtype=F16), torch.empty(n, M, E, device=dev, dtype=F16) if hl & 4 else None)
+        t1s = [Split(t1b.hi[l], t1b.lo[l] if hl & 4 else None) for l in range(n)]
+        xlo = bool(hl & 32)
+        grp = self._adapter_groups(xs, B, Lq, C, xlo)
         if grp is not None:
             # all n adapters in TWO grouped launches (wc_gemm_f16_grouped) instead of 2 n: the encoder wrote its fp16
             # block outputs into one (n, B*L, C) buffer and the weight cache holds the adapter weights at a uniform stride
@@ -111,19 +122,19 @@ class HeadEngine:
             mods = self.fuse.linears_modulelist
             b1 = torch.stack([m.proj.bias.detach().float() for m in mods])
             b2 = torch.stack([m.proj_2.bias.detach().float() for m in mods])
-            a = Split(xb.hi.view(-1)[C:], xb.lo.view(-1)[C:] if (ex and xb.lo is not None) else None)
+            a = Split(xb.hi.view(-1)[C:], xb.lo.view(-1)[C:] if (xlo and xb.lo is not None) else None)
             ops.gemm(a, wc.w("ad0.proj"), hw, E, C, bias=b1, out16=t1b.hi, out16lo=t1b.lo, act=2, batch=n * B, zdiv=B,
                      sA=Lq * C, sA2=B * Lq * C, sW=0, sW2=sw1, sC=hw * E, sC2=M * E, sB2=E)
             ops.gemm(t1b, wc.w("ad0.proj_2"), M, E, E, bias=b2, out16=cat.hi, out16lo=cat.lo, ldc=n * E, batch=n, zdiv=1,
                      sA2=M * E, sW2=sw2, sC2=E, sB2=E)
         else:
             for l, mlp in enumerate(self.fuse.linears_modulelist):
-                a = Split(xs[l].hi.view(-1)[C:], xs[l].lo.view(-1)[C:] if (ex and xs[l].lo is not None) else None)
+                a = Split(xs[l].hi.view(-1)[C:], xs[l].lo.view(-1)[C:] if (xlo and xs[l].lo is not None) else None)
                 t1 = t1s[l]
                 ops.gemm(a, wc.w(f"ad{l}.proj"), hw, E, C, bias=_f(mlp.proj.bias), out16=t1.hi, out16lo=t1.lo,
                          act=2, batch=B, sA=Lq * C, sW=0, sC=hw * E)
                 ops.gemm(t1, wc.w(f"ad{l}.proj_2"), M, E, E, bias=_f(mlp.proj_2.bias),
-                         out16=cat.hi.view(-1)[l * E:], out16lo=cat.lo.view(-1)[l * E:] if ex else None, ldc=n * E)
+                         out16=cat.hi.view(-1)[l * E:], out16lo=cat.lo.view(-1)[l * E:] if hl & 1 else None, ldc=n * E)
         ctx["t1b"] = t1b
         # fuse (1x1 conv) + Dropout2d
         F32_ = torch.empty(M, E, device=dev, dtype=F32)

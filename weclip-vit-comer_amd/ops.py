@@ -261,17 +261,19 @@ class WeightCache:
         self.versions = None
         self.views = {}
 
-    def refresh(self, named, exact, force=False):
+    def refresh(self, named, exact, force=False, lo_names=()):
         """named: list of (name, 2-D contiguous fp32 CUDA tensor).  force: convert even if no version counter moved
-        (training: an update through `param.data` does not bump `param._version`)."""
+        (training: an update through `param.data` does not bump `param._version`).  lo_names: weights that carry their
+        fp16 remainder in the row-major (forward) copy although `exact` is off."""
         L.require_gpu()
-        key = tuple((n, t.data_ptr(), tuple(t.shape)) for n, t in named) + (bool(exact),)
+        lo_names = frozenset(lo_names)
+        key = tuple((n, t.data_ptr(), tuple(t.shape)) for n, t in named) + (bool(exact), lo_names)
         if key != self.key:
             dev = named[0][1].device
             tot = sum(t.numel() for _, t in named)
             totT = sum(t.shape[1] * ((t.shape[0] + 63) // 64 * 64) for _, t in named)
             self.hi = torch.empty(tot, device=dev, dtype=F16)
-            self.lo = torch.empty(tot, device=dev, dtype=F16) if exact else None
+            self.lo = torch.empty(tot, device=dev, dtype=F16) if (exact or lo_names) else None
             self.hiT = torch.zeros(totT, device=dev, dtype=F16)          # K padding of the transposed copies stays 0
             self.loT = torch.zeros(totT, device=dev, dtype=F16) if exact else None
             rows, self.views, o, oT = [], {}, 0, 0
@@ -279,9 +281,9 @@ class WeightCache:
                 R, C = t.shape
                 ldT = (R + 63) // 64 * 64
                 hi, hiT = self.hi[o:o + R * C].view(R, C), self.hiT[oT:oT + C * ldT].view(C, ldT)
-                lo = self.lo[o:o + R * C].view(R, C) if exact else None
+                lo = self.lo[o:o + R * C].view(R, C) if (exact or n in lo_names) else None
                 loT = self.loT[oT:oT + C * ldT].view(C, ldT) if exact else None
-                rows.append([t.data_ptr(), hi.data_ptr(), lo.data_ptr() if exact else 0, hiT.data_ptr(),
+                rows.append([t.data_ptr(), hi.data_ptr(), lo.data_ptr() if lo is not None else 0, hiT.data_ptr(),
                              loT.data_ptr() if exact else 0, R, C, ldT])
                 self.views[n] = (Split(hi, lo), Split(hiT, loT), ldT)
                 o += R * C

@@ -24,6 +24,10 @@ TINY = dict(width=64, layers=12, embed_dim=32, text_width=64, gain=2.0, seed=0,
             logit_scale=math.log(25.0))
 TINY_HW = (64, 96)
 TINY_LABELS = [[3, 7], [0, 14]]
+# Per-block CLS attention-sink strengths of the second benchmark-size seg-trans fixture (tests/golden/vitb_512_seg_sink.npz):
+# the six layers the VOC seg-trans branch selects from get A_l = sum(map_l[1:, 1:]) between 987 and 1023, every layer >= 2.4
+# away from their mean (the reference's fp32 sums have a quantum of 1/8 there), so the discrete selection carries signal.
+SINK_512 = [0.0] * 6 + [3.0, 5.0, 1.0, 6.0, 4.0, 2.0]
 
 
 def checksum(tensors):
@@ -43,7 +47,7 @@ def _h(t):
 
 def make_clip_state_dict(width=768, layers=12, heads=None, patch=16, grid=14, embed_dim=512,
                          seed=0, gain=1.0, text_width=64, text_layers=1, vocab=49408,
-                         with_text=True, logit_scale=math.log(100.0), qk_corr=0.8):
+                         with_text=True, logit_scale=math.log(100.0), qk_corr=0.8, cls_sink=None):
     """ViT-shaped CLIP state dict accepted by reference `build_model` (clip/model.py:481-529).
 
     `gain` scales the attention in-projection so softmax rows are not uniform; `qk_corr`
@@ -51,6 +55,13 @@ def make_clip_state_dict(width=768, layers=12, heads=None, patch=16, grid=14, em
     attend to each other (random independent Wq/Wk give structureless attention whose
     head/layer mean is uniform, which makes the affinity refinement degenerate).
     The text tower is a minimal stand-in (never on the hot path).
+
+    `cls_sink` (one value per block, or None): makes the CLS token an attention sink of per-block strength, as in
+    trained CLIP models.  Block l's query bias gets a component along the key the CLS token would have if its
+    residual stream still held ln_pre(class_embedding + pos[0]), so every patch row's score against the CLS key rises
+    by about cls_sink[l] and the mass A_l = sum(map_l[1:, 1:]) the seg-trans layer selection compares
+    (clip/clip_tool.py:152-162) differs between blocks by far more than fp32 rounding.  Consumes no random draws: a
+    state dict made with cls_sink=None is bit-identical to one made before the option existed.
     """
     g = torch.Generator().manual_seed(seed)
 
@@ -85,6 +96,19 @@ def make_clip_state_dict(width=768, layers=12, heads=None, patch=16, grid=14, em
         sd[p + "mlp.c_proj.bias"] = _h(rn(width, std=0.02))
         sd[p + "ln_2.weight"] = 1.0 + rn(width, std=0.1)
         sd[p + "ln_2.bias"] = rn(width, std=0.1)
+    if cls_sink is not None:
+        assert len(cls_sink) == layers
+        nh = heads or max(width // 64, 1)
+        e0 = sd["visual.class_embedding"] + sd["visual.positional_embedding"][0]
+        e0 = torch.nn.functional.layer_norm(e0, (width,), sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"], 1e-5)
+        for i, beta in enumerate(cls_sink):
+            p = f"visual.transformer.resblocks.{i}."
+            a = torch.nn.functional.layer_norm(e0, (width,), sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], 1e-5)
+            k = sd[p + "attn.in_proj_weight"][width:2 * width] @ a + sd[p + "attn.in_proj_bias"][width:2 * width]
+            kh = k.view(nh, -1)
+            # score added per head ~ beta: (b_q . k_cls) / sqrt(dh) with b_q = beta * sqrt(dh) * k / |k|^2 per head
+            bq = float(beta) * math.sqrt(kh.shape[1]) * kh / (kh * kh).sum(1, keepdim=True)
+            sd[p + "attn.in_proj_bias"][:width] += bq.reshape(-1)
     sd["logit_scale"] = torch.tensor(float(logit_scale))
     if with_text:
         tw = text_width
