@@ -19,7 +19,8 @@ Prints ONE JSON line on rank 0.
     graph has no per-launch call sites to put the event pairs at).
   * `cpu_baseline`: the CPU oracle (oracle/weclip_oracle.py, a port of the reference's CPU path) on a bounded sample.
   * extra legs at N=1 (`--no-extras` skips them): `seg_trans_branch` (the iter > 15000 affinity branch),
-    `exact_precision` (fp16 hi+lo operands, fp32 PAR), `with_comer` (BASELINE configs[2] as written: + ViT-CoMer
+    `exact_precision` (fp16 hi+lo operands, fp32 PAR), `fast_gemm_fp32_par` (the headline's GEMM precision with the
+    reference's fp32 PAR affinities: what the 16-bit PAR layout alone buys), `with_comer` (BASELINE configs[2] as written: + ViT-CoMer
     inserts; parity unpinned, no reference code), `encoder_only_b32` (BASELINE configs[1]).
 """
 import argparse
@@ -52,6 +53,7 @@ def parse():
                     help="HIP-event pair around 1 of every n instrumented kernel launches (0: none, roofline = null)")
     ap.add_argument("--roof-steps", type=int, default=8, help="eager instrumented steps for the roofline leg")
     ap.add_argument("--cpu-images", type=int, default=2, help="images in the bounded CPU-oracle sample")
+    ap.add_argument("--cpu-images-1thread", type=int, default=1, help="images in the single-thread CPU-oracle sample (0: skip)")
     return ap.parse_args()
 
 
@@ -79,22 +81,37 @@ def cpu_baseline(args):
     import torch
     from oracle import synth
     from oracle import weclip_oracle as O
-    n = args.cpu_images
     sd = synth.make_clip_state_dict(seed=0, with_text=False)
-    fuse, dec = synth.make_head_state_dicts()
-    fuse = {k: v.requires_grad_(True) for k, v in fuse.items()}
-    dec = {k: v.requires_grad_(True) for k, v in dec.items()}
     bg, fg = synth.make_text_features(20, 25, 512)
-    img = synth.make_images(n, args.size, args.size, seed=100)
-    labels = synth.make_label_lists(n, args.classes_per_image)
-    t0 = time.time()
-    seg, cam, ap = O.weclip_forward(img, labels, sd, fuse, dec, bg, fg, heads=12)
-    loss, _, _ = O.train_losses(seg, cam, ap)
-    loss.backward()
-    dt = time.time() - t0
-    return {"value": n / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} images {args.size}x{args.size}, K={args.classes_per_image}: oracle forward "
-                      f"(encoder, GradCAM, affinity, PAR) + losses + head backward, {dt:.1f} s"}
+
+    def run(n):
+        fuse, dec = synth.make_head_state_dicts()
+        fuse = {k: v.requires_grad_(True) for k, v in fuse.items()}
+        dec = {k: v.requires_grad_(True) for k, v in dec.items()}
+        img = synth.make_images(n, args.size, args.size, seed=100)
+        labels = synth.make_label_lists(n, args.classes_per_image)
+        t0 = time.time()
+        seg, cam, ap = O.weclip_forward(img, labels, sd, fuse, dec, bg, fg, heads=12)
+        loss, _, _ = O.train_losses(seg, cam, ap)
+        loss.backward()
+        return time.time() - t0
+
+    what = (f"images {args.size}x{args.size}, K={args.classes_per_image}: oracle forward (encoder, GradCAM, affinity, PAR) + "
+            f"losses + head backward")
+    n = args.cpu_images
+    dt = run(n)
+    out = {"value": n / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{n} {what}, {dt:.1f} s"}
+    if args.cpu_images_1thread > 0:          # n in {1, all cores}
+        allc = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            n1 = args.cpu_images_1thread
+            dt1 = run(n1)
+            out["single_thread"] = {"value": n1 / dt1, "unit": "images/sec", "cores": 1, "sample": f"{n1} {what}, {dt1:.1f} s"}
+        finally:
+            torch.set_num_threads(allc)
+    return out
 
 
 def make_model(dev, comer=False, seg_trans=False):
@@ -169,7 +186,16 @@ def run_leg(args, dev, rank, world, *, comer=False, seg_trans=False, steps=None,
         step(img, labels=labels)
         t_idle += time.perf_counter() - t0
     torch.cuda.synchronize()
-    res = {"value": round(world * args.batch * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3),
+    dp_check = None
+    if world > 1:      # every rank must hold the same parameters after the same number of all-reduced steps
+        import torch.distributed as dist
+        ps = [p.detach().double() for p in model.get_param_groups()[3]]
+        ck = torch.stack([sum(p.sum() for p in ps), sum((p * p).sum() for p in ps)]).to(dev)
+        allck = [torch.zeros_like(ck) for _ in range(world)]
+        dist.all_gather(allck, ck)
+        dp_check = {"params_identical_across_ranks": bool(all(torch.equal(allck[0], c) for c in allck)),
+                    "param_checksum": [float(v) for v in allck[0].tolist()]}
+    res = {"value": round(world * args.batch * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3), "dp_check": dp_check,
            "host_enqueue_ms_per_step": round(t_enq / steps * 1e3, 3),
            "host_cpu_ms_per_step": round(t_cpu / steps * 1e3, 3),
            "host_work_ms_per_step_idle_queue": round(t_idle / 5 * 1e3, 3), "steps": steps,
@@ -337,6 +363,7 @@ def main():
         "host_cpu_ms_per_step": res["host_cpu_ms_per_step"],
         "host_work_ms_per_step_idle_queue": res["host_work_ms_per_step_idle_queue"],
         "launch_mode": res["launch_mode"],
+        "dp_check": res["dp_check"],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -369,6 +396,16 @@ def main():
                 out["exact_precision"] = r
             finally:
                 config.precision = "fast"
+            torch.cuda.empty_cache()
+        if config.precision == "fast" and config.par_q16:
+            # the PAR compression alone: fp16 single-pass GEMMs as in the headline, but PAR on fp32 affinities like the reference
+            config.par_q16 = False
+            try:
+                r, _, _ = run_leg(args, dev, rank, world, steps=few, warmup=2)
+                r["dtype"] = "f16 MFMA operands / f32 accumulate (precision=fast), PAR on fp32 affinities (WECLIP_PAR_F16=0)"
+                out["fast_gemm_fp32_par"] = r
+            finally:
+                config.par_q16 = True
             torch.cuda.empty_cache()
         if not args.comer:
             r, _, _ = run_leg(args, dev, rank, world, comer=True, steps=few, warmup=2)

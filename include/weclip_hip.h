@@ -156,8 +156,14 @@ int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A2, const vo
 
 /* Which kernel wc_gemm_f16 runs for a shape (for profiling / roofline bookkeeping only):
  * 0 = 128x128x64 kernel, 1 = 256x256x64 ping-pong kernel, 2 = ping-pong kernel + 128x128 kernel on the ragged
- * last M % 256 rows (two launches). */
+ * last M % 256 rows (two launches), 3 / 4 = the same two with the 256x192x64 tile (N %% 192 == 0). */
 int wc_gemm_plan(int M, int N, int K, int nseg, int batch);
+/* Tile-width policy of the tall GEMMs: mode 0 = 256x256 only, 1 = by the bytes a launch stages into LDS (default: the
+ * narrower tile only where the wider one would carry dead columns), 2 = 256x192 whenever the shape allows; cost > 0
+ * replaces the relative cost of a byte staged by the 192-column kernel (default 1.0).
+ * Process-wide; for benchmarks and tests (the environment variables WECLIP_GEMM_P192 / WECLIP_GEMM_P192_COST set the
+ * initial values). */
+void wc_gemm_set_p192(int mode, float cost);
 /* out[i] = alpha * sum_s part[s*n + i]: reduction of split-K partial products (the slices are a
  * batched wc_gemm_f16 over K ranges: sA = sW = K/slices, sC = M*N). */
 int wc_sum_slices(const float* part, float* out, int nslices, long n, float alpha, void* stream);

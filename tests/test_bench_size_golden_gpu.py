@@ -131,14 +131,25 @@ def test_cam_chain_at_512_matches_reference(golden, request, seg_trans, precisio
     e["par_out"] = np.abs(par_out[i, :, ::16].cpu().numpy() - g["par_out_rows"]).max()
     e["seg"] = _rel(seg[i].cpu().numpy(), g["seg"])
     e["attn_pred"] = np.abs(ap[i, ::64].cpu().numpy() - g["attn_pred_rows"]).max()
+    # the same error in front of the sigmoid, relative to the largest Gram entry G = F^T F (what a GEMM's error is measured by)
+    pr_, pm_ = g["attn_pred_rows"].astype(np.float64), ap[i, ::64].cpu().numpy().astype(np.float64)
+    ok_ = (pr_ > 1e-4) & (pr_ < 1 - 1e-4) & (pm_ > 0) & (pm_ < 1)
+    lg_ = lambda p_: np.log(p_ / (1 - p_))
+    e["attn_pred_logit"] = np.abs(lg_(pm_[ok_]) - lg_(pr_[ok_])).max() / np.abs(lg_(pr_[ok_])).max()
+    assert ok_.mean() > 0.5
     e["labels"] = float((cam_labels[i].cpu().numpy() != g["cam_labels"]).mean())
     print(f"512^2 image {i} of {B}, seg_trans={seg_trans} [{precision}]: " + "  ".join(f"{k} {v:.2e}" for k, v in e.items()))
     assert e["cam_logits"] < 1e-3, "north-star bound: CAM logits within 1e-3 relative of the reference CPU path"
     # ~3x the errors measured on the MI355X (fast precision, normal branch: tokens 3.0e-4, attn10 2.7e-4, attn_last 9.6e-5,
     # cam_map 4.9e-4, affinity 1.8e-4, trans_rows 2.0e-4, refined 2.2e-4, par 3.4e-4, seg 8.4e-4, attn_pred 5.5e-3 abs
     # (sigmoid of a 256-long Gram product of fp16-rounded adapter outputs), labels 0.012 % of the pixels)
+    # attn_pred = sigmoid(F^T F): the Gram product already runs on hi+lo operands in `fast`; tools/head_lo_probe.py (round 3)
+    # shows where the rest comes from: every operand of the adapter -> fuse chain hi+lo (WECLIP_HEAD_LO=63) still leaves
+    # 3.2e-3, i.e. the fast encoder's token error (3.4e-4 relative) amplified ~10x by the 256-long Gram of width-256
+    # features; `exact` measures 9.6e-4.  In front of the sigmoid the error is ~1e-3 of the largest Gram entry.
     lim = dict(tokens=1e-3, attn10=1e-3, attn_last=5e-4, cam_map=2e-3, affinity=6e-4, aff_rowsum=1e-5, trans_rows=6e-4,
-               trans_diag=5e-4, refined=7e-4, par_in=1e-3, par_out=1e-3, seg=3e-3, attn_pred=1.5e-2, labels=5e-4)
+               trans_diag=5e-4, refined=7e-4, par_in=1e-3, par_out=1e-3, seg=3e-3, labels=5e-4,
+               attn_pred=2e-3 if precision == "exact" else 1e-2, attn_pred_logit=2e-3)
     if seg_trans:       # W = (masked layer mean) * attn_pred; measured fast / exact: affinity 1.9e-4 / 6.3e-5, trans 2.3e-4 / 1.3e-4,
         lim.update(affinity=7e-4, trans_rows=8e-4, trans_diag=8e-4, refined=9e-4, par_in=1.5e-3)      # par 4.6e-4 / 1.6e-4, labels 0.013 % / 0.002 %
     bad = {k: (v, lim[k]) for k, v in e.items() if k in lim and not v < lim[k]}

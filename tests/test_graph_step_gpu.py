@@ -80,3 +80,50 @@ def test_graph_mode_new_signature_gets_its_own_graph_and_dropout_varies():
     assert all(v == v for v in l2 + l3)
     # same input every step: the loss still moves (optimizer updates + a fresh Dropout2d mask per replay)
     assert len(set(l2)) == len(l2)
+
+
+def test_bucketed_signatures_keep_real_label_distributions_to_a_few_graphs():
+    """The reference takes every image's classes from its GT mask (clip/clip_tool.py:111-124): 1..5 per image, so the pair
+    count and the channel capacity change from batch to batch.  TrainStep(graph=True) buckets the signature (pairs padded to
+    a multiple of 8 with dropped dummy pairs, K to the next even number): 50 random label lists need <= 8 captured graphs,
+    and every loss, gradient and the final parameters equal the UNPADDED eager step bit for bit."""
+    import numpy as np
+    from weclip_vit_comer_amd.train_step import TrainStep
+    rs = np.random.RandomState(0)
+    batches = []
+    for s in range(50):
+        labels = [sorted(rs.choice(20, size=int(rs.randint(1, 6)), replace=False).tolist()) for _ in range(2)]
+        batches.append((100 + s, labels))
+
+    class NoStep:          # parameters stay put: a batch whose pseudo-labels hold no foreground pixel has a NaN loss (the
+        def step(self):    # reference's CE over an empty set, scripts/dist_clip_voc.py:105-113) and must not poison the rest
+            pass
+
+        def zero_grad(self):
+            pass
+
+    def run(graph):
+        torch.manual_seed(0)
+        m = _model(train=False)
+        step = TrainStep(m, optimizer=NoStep(), graph=graph)
+        losses, grads = [], []
+        for seed, labels in batches:
+            out = step(synth.make_images(2, H, W, seed=seed).cuda(), labels=labels)
+            losses.append([o.item() for o in out])
+            grads.append(step.bucket.flat.clone())
+        return losses, grads, torch.cat([p.detach().flatten() for p in m.get_param_groups()[3]]), step
+
+    le, ge, pe, _ = run(False)
+    lg, gg, pg, step = run(True)
+    sigs = {(sum(len(l) for l in lab), max(len(l) for l in lab)) for _, lab in batches}
+    captured = [e for e in step._graphs.values() if e["graph"] is not None]
+    print(f"{len(sigs)} distinct (pairs, max classes) among 50 batches -> {len(step._graphs)} bucketed signatures, "
+          f"{len(captured)} captured graphs")
+    assert len(sigs) > 8 >= len(step._graphs)
+    te, tg = torch.tensor(le, dtype=torch.float64), torch.tensor(lg, dtype=torch.float64)
+    assert torch.isfinite(te).all(1).sum().item() >= 40
+    assert torch.equal(torch.isnan(te), torch.isnan(tg)) and torch.equal(te.nan_to_num(), tg.nan_to_num()), (le, lg)
+    for i, (a, b) in enumerate(zip(ge, gg)):
+        assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(a.nan_to_num(), b.nan_to_num()), \
+            (i, batches[i][1], (a - b).abs().max().item())
+    assert torch.equal(pe, pg)

@@ -107,6 +107,71 @@ def test_gemm_tall_pingpong(ops):
     assert _rel(out.cpu().double(), a2.double() @ w2.double().t()) < 2e-6
 
 
+def _set_p192(mode, cost=0.0):
+    import ctypes
+    from weclip_vit_comer_amd import _lib as L
+    L.lib().cdll.wc_gemm_set_p192.argtypes = [ctypes.c_int, ctypes.c_float]
+    L.lib().cdll.wc_gemm_set_p192.restype = None
+    L.lib().cdll.wc_gemm_set_p192(int(mode), float(cost))
+
+
+@pytest.mark.parametrize("M,N,K,nseg", [(16400, 768, 768, 1), (16400, 2304, 768, 1), (16400, 768, 3072, 1), (8300, 1344, 256, 1),
+                                        (16400, 768, 768, 2), (16400, 768, 128, 3)])
+def test_gemm_tall_192_column_tile(ops, M, N, K, nseg):
+    """The 256x192 ping-pong kernel (round 3; N %% 192 == 0, even K-tile count >= 4) against the fp64 product AND, bit for
+    bit, against the 256x256 kernel on the same operands (every output element accumulates the same MFMA k-steps in the same
+    order): the wide fp16 epilogue (QKV: bias, q-scale columns; hi+lo outputs), the narrow fp32 + residual one (proj / fc2:
+    forced-fp16 rounding, fp32 + fp16 outputs), QuickGELU with the saved pre-activation, ReLU' aux, the ragged 16 rows."""
+    import ctypes
+    from weclip_vit_comer_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N + K)
+    a = ops.Split(torch.randn(M, K, generator=g).half().cuda(), (torch.randn(M, K, generator=g) * 1e-3).half().cuda() if nseg > 1 else None)
+    w = ops.Split((torch.randn(N, K, generator=g) * 0.05).half().cuda(), (torch.randn(N, K, generator=g) * 5e-5).half().cuda() if nseg > 2 else None)
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    saved = torch.randn(M, N, generator=g).half().cuda()
+    ref = a.hi.double() @ w.hi.double().t()
+    if nseg > 1:
+        ref += a.lo.double() @ w.hi.double().t()
+    if nseg > 2:
+        ref += a.hi.double() @ w.lo.double().t()
+    ref = (ref + bias.double()).cpu()
+
+    def run(mode):
+        _set_p192(mode)
+        plan = L.lib().cdll.wc_gemm_plan(M, N, K, nseg, 1)
+        o = {}
+        o["h"], o["l"] = torch.zeros(M, N, device="cuda", dtype=torch.float16), torch.zeros(M, N, device="cuda", dtype=torch.float16)
+        ops.gemm(a, w, M, N, K, bias=bias, out16=o["h"], out16lo=o["l"], scale=0.18, scale_cols=N // 3)
+        o["x1"] = torch.zeros(M, N, device="cuda")
+        ops.gemm(a, w, M, N, K, bias=bias, resid=res, out32=o["x1"], round16=True)
+        o["x2"], o["x2h"] = torch.zeros(M, N, device="cuda"), torch.zeros(M, N, device="cuda", dtype=torch.float16)
+        ops.gemm(a, w, M, N, K, bias=bias, resid=res, out32=o["x2"], out16=o["x2h"])
+        o["z"], o["u"] = torch.zeros(M, N, device="cuda", dtype=torch.float16), torch.zeros(M, N, device="cuda")
+        ops.gemm(a, w, M, N, K, bias=bias, out16=o["z"], act=1, pre32=o["u"])
+        o["r"] = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+        ops.gemm(a, w, M, N, K, out16=o["r"], act=5, auxh=saved, ldaux=N)
+        torch.cuda.synchronize()
+        return plan, o
+
+    try:
+        p0, o0 = run(0)
+        p2, o2 = run(2)
+    finally:
+        _set_p192(1)
+    assert p0 in (1, 2) and p2 in (3, 4), (p0, p2)
+    mm = M // 256 * 256      # the ragged M % 256 rows may go to the few-rows kernel (4-way K split) in one mode only
+    for k in o0:
+        assert torch.equal(o0[k][:mm], o2[k][:mm]), (k, (o0[k].float() - o2[k].float()).abs().max().item())
+        assert (o0[k][mm:].float() - o2[k][mm:].float()).abs().max().item() < 2e-3
+    sc = torch.ones(N, dtype=torch.float64)
+    sc[:N // 3] = 0.18
+    assert _rel((o2["h"].float() + o2["l"].float()).cpu().double(), ref * sc) < 2e-6
+    assert _rel(o2["x2"].cpu().double(), ref + res.cpu().double()) < 2e-6
+    assert _rel(o2["u"].cpu().double(), ref) < 2e-6
+    assert _rel(o2["z"].float().cpu().double(), ref * torch.sigmoid(1.702 * ref)) < 1e-3
+
+
 def test_gemm_ragged_rows_split(ops):
     """65 x 4 tiles of 256x256 on 256 CUs: the 16 ragged rows go to a second launch (128x128 kernel);
     residual / fp16 hi+lo outputs / saved pre-activation must line up across the seam."""

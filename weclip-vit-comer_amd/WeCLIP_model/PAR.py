@@ -63,7 +63,7 @@ class PAR(nn.Module):
         # "fast" precision: the affinities live as 16-bit fixed-point pairs + a per-pixel scale between the sweeps (half
         # the bytes of the HBM-bound sweep; |rounding error| <= max weight * 7.7e-6, error-diffused: csrc/par.hip)
         from .. import config
-        h16 = T == 48 and not config.exact() and os.environ.get("WECLIP_PAR_F16", "1") != "0"
+        h16 = T == 48 and not config.exact() and config.par_q16
         # group so that aff + masks of a group stay (mostly) inside the 256 MiB Infinity Cache across the sweeps: measured
         # at 512x512, C = 3, 16 images (fast form, 35.7 MB per image): groups of 6 / 7 / 8 / 9 / 16 -> 2.27 / 2.28 / 2.24 /
         # 2.39 / 2.71 ms; the groups are balanced (16 images = 8 + 8, not 6 + 6 + 4)

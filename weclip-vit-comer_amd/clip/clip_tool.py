@@ -48,9 +48,17 @@ class PairPlan:
 
     The device tensors are allocated once; `update(label_lists)` refills them in place for another batch with the
     same signature (B, P, K) -- what a captured HIP graph of the step needs (train_step.TrainStep(graph=True)):
-    the graph's kernels keep reading the same addresses, only their contents change."""
+    the graph's kernels keep reading the same addresses, only their contents change.
 
-    def __init__(self, label_lists, n_fg, n_bg, device):
+    pad=True buckets the signature so that real label distributions (the reference takes 1..5+ classes per image from
+    the GT mask, clip_tool.py:111-124) need only a handful of captured graphs: the pair count is padded to a multiple
+    of PAD_P with dummy pairs (copies of pair 0 whose slot is -1: their GradCAM is computed and dropped, box_mask skips
+    the write) and K, the channel capacity per image, to the next even number; per-image class counts (nk / nch) stay
+    exact, so every real pair and channel sees the arithmetic of the unpadded plan."""
+    PAD_P = 8
+
+    def __init__(self, label_lists, n_fg, n_bg, device, pad=False):
+        self.pad = bool(pad)
         self.n_fg, self.n_bg, self.device = n_fg, n_bg, torch.device(device)
         host, vk = self._host_arrays(label_lists)
         cuda = self.device.type == "cuda"
@@ -68,16 +76,18 @@ class PairPlan:
         self.text_idx = text_idx.view(self.P, self.Tmax)
 
     @staticmethod
-    def signature(label_lists):
+    def signature(label_lists, pad=False):
         """(B, P, K): batches with equal signatures can share one set of device index tensors."""
-        return len(label_lists), sum(len(l) for l in label_lists), max(len(l) for l in label_lists)
+        P, K = sum(len(l) for l in label_lists), max(len(l) for l in label_lists)
+        if pad:
+            P, K = -(-P // PairPlan.PAD_P) * PairPlan.PAD_P, max(2, K + (K & 1))
+        return len(label_lists), P, K
 
     def _host_arrays(self, label_lists):
         self.label_lists = [list(map(int, l)) for l in label_lists]
         if any(len(l) == 0 for l in self.label_lists):
             raise RuntimeError("every image needs at least one foreground class id")
-        self.B = len(self.label_lists)
-        self.K = max(len(l) for l in self.label_lists)
+        self.B, P_sig, self.K = self.signature(self.label_lists, self.pad)
         self.Tmax = self.K + self.n_bg
         pi, pc, ps, ti, nt = [], [], [], [], []
         for i, ids in enumerate(self.label_lists):
@@ -86,6 +96,11 @@ class PairPlan:
                 pi.append(i); pc.append(j); ps.append(j)
                 ti.append(rows + [0] * (self.Tmax - len(rows)))
                 nt.append(len(rows))
+        self.P_real = len(pi)
+        for _ in range(P_sig - len(pi)):          # dummy pairs (pad=True): pair 0 again, result dropped (slot -1)
+            pi.append(pi[0]); pc.append(pc[0]); ps.append(-1)
+            ti.append(list(ti[0]))
+            nt.append(nt[0])
         nk = [len(l) for l in self.label_lists]
         flat_ti = [v for row in ti for v in row]
         parts = [pi, pc, ps, flat_ti, nt, nk, [k + 1 for k in nk]]
@@ -100,8 +115,8 @@ class PairPlan:
     def update(self, label_lists):
         """Refill the device index tensors for another batch of the same signature (asynchronous copies from the
         pinned staging buffers, ordered on the current stream)."""
-        if self.signature(label_lists) != (self.B, self.P, self.K):
-            raise RuntimeError(f"PairPlan.update: signature {self.signature(label_lists)} != {(self.B, self.P, self.K)}")
+        if self.signature(label_lists, self.pad) != (self.B, self.P, self.K):
+            raise RuntimeError(f"PairPlan.update: signature {self.signature(label_lists, self.pad)} != {(self.B, self.P, self.K)}")
         host, vk = self._host_arrays(label_lists)
         if self.device.type != "cuda":
             self._dev_all.copy_(host)

@@ -18,3 +18,7 @@ def exact():
 # 8 = proj_2 weights, 16 = proj weights, 32 = the encoder's block outputs (the adapters' input).  attn_pred squares F's rounding error (256-long Gram product) and feeds
 # get_aff_loss and the seg-trans affinity; measured at 512^2 against the reference fixture: see DESIGN.md §3.
 head_lo = int(os.environ.get("WECLIP_HEAD_LO", "0"))
+
+# `fast` precision only: PAR affinities kept as 16-bit fixed point between the sweeps (csrc/par.hip wc_par_forward_h); False =
+# fp32 affinities like the reference (WeCLIP_model/PAR.py:64-92) with the fast GEMMs unchanged.
+par_q16 = os.environ.get("WECLIP_PAR_F16", "1") != "0"

@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void box_mask_kernel(const float* __restrict__
             inside = (x >= x0 && x < x1 && y >= y0 && y < y1);
         }
         if (mask_out) mask_out[(long)p * hw + i] = inside ? 1.f : 0.f;
-        V[((long)img * hw + i) * K + slot] = inside ? cp[i] : 0.f;
+        if (slot >= 0) V[((long)img * hw + i) * K + slot] = inside ? cp[i] : 0.f;      // slot -1: a padding pair (PairPlan pad)
     }
 }
 

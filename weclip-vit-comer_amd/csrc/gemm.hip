@@ -93,8 +93,9 @@ __device__ __forceinline__ void gemm_colvals(const GemmArgs& g, int n0, int wc, 
     }
 }
 
-template <bool AUX>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int m0, int n0, int wr, int wc,
+// NI = column tiles (of 32) of the wave's block: 2 (64 x 64) or 1 (64 x 32: the third column tile of the 256x192 kernel).
+template <bool AUX, int NI = 2>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][NI], int m0, int n0, int wr, int wc,
                                               int lane, long zb, char* scratch, const float (&bv)[2],
                                               const float (&sc)[2], long cb, long xb = 0) {
     const int act = g.act;
@@ -119,7 +120,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
             for (int it = 0; it < 4; ++it) {
                 const int grow = m0 + wr * 64 + c * 16 + it * 4 + (lane >> 4);
                 dst[it][0] = dst[it][1] = dst[it][2] = dst[it][3] = 0.f;
-                if (grow < g.M && gcol < g.N) {
+                if (grow < g.M && gcol < g.N && (NI == 2 || c4 < 32)) {
                     const long arow = g.rowmap ? (long)g.rowmap[(grow + g.row0) / g.rpg] * g.rpg + (grow + g.row0) % g.rpg : grow;
                     const float* up = g.aux + arow * g.ldaux + gcol;
                     if (full) {
@@ -138,25 +139,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         for (int c = 0; c < 4; ++c) {            // rows [16c, 16c+16) of the wave's 64x64 sub-tile
             const int mi = c >> 1, rq0 = (c & 1) * 8;
             float* tile = tile0 + (c & 1) * 1024;
-            float v[16];
+            float v[NI * 8];
             if constexpr (AUX) {
                 if (act == 4 && c + 1 < 4) aux_load(c + 1, ua[(c + 1) & 1]);
             }
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int rr = 0; rr < 8; ++rr) v[ni * 8 + rr] = acc[mi][ni][rq0 + rr] + bv[ni];
             if (r16) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = __half2float(__float2half(v[e]));
+                for (int e = 0; e < NI * 8; ++e) v[e] = __half2float(__float2half(v[e]));
             }
             if (has_sc) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] *= sc[e >> 3];
+                for (int e = 0; e < NI * 8; ++e) v[e] *= sc[e >> 3];
             }
-            if constexpr (!AUX) { WC_EPI_ACT(v, 16) }
+            if constexpr (!AUX) { WC_EPI_ACT(v, NI * 8) }
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int rr = 0; rr < 8; ++rr)
                     tile[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * 64 + ni * 32 + (lane & 31)] = v[ni * 8 + rr];
@@ -170,7 +171,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                 const int grow = m0 + wr * 64 + c * 16 + rl;
                 const float4 t4 = *reinterpret_cast<const float4*>(tile + rl * 64 + c4);
                 f[it][0] = t4.x; f[it][1] = t4.y; f[it][2] = t4.z; f[it][3] = t4.w;
-                ok[it] = grow < g.M && gcol < g.N;
+                ok[it] = grow < g.M && gcol < g.N && (NI == 2 || c4 < 32);      // NI == 1: the lanes of columns 32..63 idle
                 o[it] = (long)(grow < g.M ? grow : g.M - 1) * g.ldc + (gcol < g.N ? gcol : 0);
             }
             if constexpr (AUX) {
@@ -235,12 +236,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
     }
     // all 64 residual values of the wave's sub-tile are requested up front: one memory latency, not four
     // (the output may alias the residual, so the compiler cannot hoist these loads over the stores itself)
-    float rva[AUX ? 1 : 2][AUX ? 1 : 2][16];
+    float rva[AUX ? 1 : 2][AUX ? 1 : NI][16];
     if (!AUX && has_res) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
+            for (int ni = 0; ni < NI; ++ni) {
                 const int col = n0 + wc * 64 + ni * 32 + (lane & 31);
                 const int colc = col < g.N ? col : g.N - 1;
                 const int rbase = m0 + wr * 64 + mi * 32 + 4 * (lane >> 5);
@@ -255,7 +256,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
             const int col = n0 + wc * 64 + ni * 32 + (lane & 31);
             const bool colok = col < g.N;
             const int colc = colok ? col : g.N - 1;
@@ -795,6 +796,193 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// 256x192x64 variant of the ping-pong kernel (round 3): for N = 768 / 2304 a 192-column tile gives 4 / 12 tile columns, so
+// 16 images x 1025 tokens (64 full 256-row tiles) make 256 / 768 tiles = EXACTLY 1 / 3 rounds of the 256 CUs, where the
+// 256x256 tile leaves a quarter of the chip idle (192 tiles = 0.75 round, 576 = 2.25 rounds).
+//
+// 8 waves as 4 (rows) x 2 (columns), wave tile 64 x 96 = 2 x 3 MFMA tiles (96 accumulator registers).  A K-tile is staged as
+// SEVEN 8-KiB units (one LDS-DMA instruction per wave and unit), in the order of use:
+//   u0, u1 = A rows mi = 0 of the wave rows {0,1} / {2,3};  u2, u3, u4 = B column tiles j = 0, 1, 2 (both column groups);
+//   u5, u6 = A rows mi = 1
+// into a ring of 14 slots (two K-tiles, 112 KiB), and computed in three phases of 8 MFMAs in snake order:
+//   P0 (mi0,j0) (mi0,j1)   P1 (mi0,j2) (mi1,j2)   P2 (mi1,j1) (mi1,j0)
+// with the fragment reads spread 8 / 8 / 4: P0 reads B0, B1; P1 reads B2, A(mi1); P2 pre-reads A(mi0) of the NEXT K-tile into
+// the registers P1 has just finished with.  As in the 256x256 kernel the two wave halves (waves w and w + 4 share a SIMD) run
+// one barrier apart, so one half's MFMAs overlap the other half's LDS reads, and the DMA instructions are issued between the
+// MFMAs of a phase: P0(t) requests units 5,6 of K-tile t+1, P1(t) units 0,1 of t+2, P2(t) units 2,3,4 of t+2 -- every unit is
+// requested 3-4 phases (1 - 1.3 K-tiles) before the counted wait that needs it, 5 units (40 KiB) stay in flight across the
+// barriers (`s_waitcnt vmcnt(5)` at every wait), and a slot is re-staged only after both halves have passed the
+// `lgkmcnt(0)` behind its last fragment read.
+#define P192_UNIT 8192
+template <bool AUX>
+__global__ __launch_bounds__(512) void gemm_f16_p192_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 14 units [64 rows][64 halfs], XOR-swizzled
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, grp = wave >> 2;      // grp: the half that runs one barrier behind (1)
+    const int gx = g.gx, gy = g.gy;
+    const int lin = blockIdx.x;
+    int tx, ty;
+    if (gy >= 16) {          // XCD-aware order, as in the other kernels
+        const int slot = lin >> 3;
+        ty = (slot / gx) * 8 + (lin & 7);
+        tx = slot - (slot / gx) * gx;
+    } else {
+        ty = lin / gx;
+        tx = lin - ty * gx;
+    }
+    if (ty >= gy) return;
+    const int m0 = ty * 256, n0 = tx * 192;
+
+    // per-thread DMA source of the seven unit kinds: chunk q = wave * 64 + lane -> unit row q >> 3, physical chunk q & 7
+    long offA[2][2], offB[3];
+    {
+        const int row = tid >> 3;
+        const int c = (tid & 7) ^ ((row >> 1) & 7);      // logical chunk this lane must fetch (swizzle on the source)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int a = m0 + (2 * h + (row >> 5)) * 64 + mi * 32 + (row & 31);
+                a = a < g.M ? a : g.M - 1;
+                offA[mi][h] = (long)a * g.lda + c * 8;
+            }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            int b = n0 + (row >> 5) * 96 + j * 32 + (row & 31);
+            b = b < g.N ? b : g.N - 1;
+            offB[j] = (long)b * g.ldw + c * 8;
+        }
+    }
+    const int ktiles = g.K / BK;
+    const int nt = ktiles * g.nseg;                  // even and >= 4 (the launcher checks)
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    // unit u_ (compile time) of K-tile t_ into ring half par_ (compile time)
+#define P192_STAGE(t_, u_, par_)                                                                              \
+    {                                                                                                         \
+        const int seg__ = (t_) / ktiles;                                                                      \
+        const long k0__ = (long)((t_) - seg__ * ktiles) * BK;                                                 \
+        const __half* P__ = ((u_) < 2 || (u_) > 4) ? (seg__ == 0 ? g.A[0] : (seg__ == 1 ? g.A[1] : g.A[2]))   \
+                                                   : (seg__ == 0 ? g.W[0] : (seg__ == 1 ? g.W[1] : g.W[2]));  \
+        const long o__ = (u_) == 0 ? offA[0][0] : (u_) == 1 ? offA[0][1] : (u_) == 2 ? offB[0] : (u_) == 3 ? offB[1] \
+                       : (u_) == 4 ? offB[2] : (u_) == 5 ? offA[1][0] : offA[1][1];                           \
+        char* d__ = smem + ((par_) * 7 + (u_)) * P192_UNIT + wave * 1024;                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(P__ + o__ + k0__), (lds_ptr)d__, 16, 0, 0);                \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }
+    // fragment read addresses (bytes inside the ring half): A unit row (wr & 1) * 32 + l31 of unit (mi ? 5 : 0) + (wr >> 1),
+    // B unit row wc * 32 + l31 of unit 2 + j
+    const int hh = lane >> 5, l31 = lane & 31;
+    int aaddr[4], baddr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int ra = (wr & 1) * 32 + l31, rb = wc * 32 + l31;
+        aaddr[ks] = grp * P192_UNIT + ra * 128 + (((2 * ks + hh) ^ ((ra >> 1) & 7)) << 4);
+        baddr[ks] = rb * 128 + (((2 * ks + hh) ^ ((rb >> 1) & 7)) << 4);
+    }
+    f32x16 accP[2][2], accQ[2][1];      // [mi][j = 0, 1], [mi][j = 2]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accQ[i][0][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accP[i][j][r] = 0.f;
+    }
+    float bvP[2], scP[2], bvQ[2], scQ[2];
+    gemm_colvals(g, n0 + wc * 96, 0, lane, 0, bvP, scP);
+    gemm_colvals(g, n0 + wc * 96 + 64, 0, lane, 0, bvQ, scQ);
+
+    f16x8 fa0[4], fa1[4], fb0[4], fb1[4], fb2[4];
+#define P192_RD_A(f_, par_, mi_)                                                                              \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                          \
+        f_[ks] = *reinterpret_cast<const f16x8*>(smem + ((par_) * 7 + ((mi_) ? 5 : 0)) * P192_UNIT + aaddr[ks]);
+#define P192_RD_B(f_, par_, j_)                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                          \
+        f_[ks] = *reinterpret_cast<const f16x8*>(smem + ((par_) * 7 + 2 + (j_)) * P192_UNIT + baddr[ks]);
+    // one phase: [fragment reads] -> counted wait -> barrier -> 8 MFMAs (two accumulators) with the DMA instructions ST0_..ST2_
+    // after the 1st / 2nd / 3rd MFMA pair -> barrier
+#define P192_PHASE(READS_, WAIT_, ACC0_, FA0_, FB0_, ACC1_, FA1_, FB1_, ST0_, ST1_, ST2_)                     \
+    {                                                                                                         \
+        READS_;                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        WAIT_;                                                                                                \
+        __builtin_amdgcn_s_barrier();                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                    \
+            ACC0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA0_[ks], FB0_[ks], ACC0_, 0, 0, 0);               \
+            ACC1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA1_[ks], FB1_[ks], ACC1_, 0, 0, 0);               \
+            if (ks == 0) { ST0_; }                                                                            \
+            if (ks == 1) { ST1_; }                                                                            \
+            if (ks == 2) { ST2_; }                                                                            \
+        }                                                                                                     \
+        asm volatile("" : "+v"(ACC0_), "+v"(ACC1_));      /* keeps the MFMAs inside their phase */            \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_s_barrier();                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }
+#define P192_W5 asm volatile("s_waitcnt vmcnt(5)" ::: "memory")
+#define P192_W3 asm volatile("s_waitcnt vmcnt(3)" ::: "memory")
+#define P192_W0 asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+    // K-tile t_ in ring half par_.  KIND_ 0: steady state (t + 2 < nt); 1: t = nt - 2; 2: t = nt - 1.
+#define P192_TILE(t_, par_, KIND_)                                                                            \
+    {                                                                                                         \
+        if ((KIND_) == 0) {                                                                                   \
+            P192_PHASE(P192_RD_B(fb0, par_, 0) P192_RD_B(fb1, par_, 1), P192_W5, accP[0][0], fa0, fb0, accP[0][1], fa0, fb1, \
+                       P192_STAGE((t_) + 1, 5, (par_) ^ 1), , P192_STAGE((t_) + 1, 6, (par_) ^ 1));           \
+            P192_PHASE(P192_RD_B(fb2, par_, 2) P192_RD_A(fa1, par_, 1), P192_W5, accQ[0][0], fa0, fb2, accQ[1][0], fa1, fb2, \
+                       P192_STAGE((t_) + 2, 0, par_), , P192_STAGE((t_) + 2, 1, par_));                       \
+            P192_PHASE(P192_RD_A(fa0, (par_) ^ 1, 0), P192_W5, accP[1][1], fa1, fb1, accP[1][0], fa1, fb0,    \
+                       P192_STAGE((t_) + 2, 2, par_), P192_STAGE((t_) + 2, 3, par_), P192_STAGE((t_) + 2, 4, par_)); \
+        } else if ((KIND_) == 1) {                                                                            \
+            P192_PHASE(P192_RD_B(fb0, par_, 0) P192_RD_B(fb1, par_, 1), P192_W5, accP[0][0], fa0, fb0, accP[0][1], fa0, fb1, \
+                       P192_STAGE((t_) + 1, 5, (par_) ^ 1), , P192_STAGE((t_) + 1, 6, (par_) ^ 1));           \
+            P192_PHASE(P192_RD_B(fb2, par_, 2) P192_RD_A(fa1, par_, 1), P192_W5, accQ[0][0], fa0, fb2, accQ[1][0], fa1, fb2, , , ); \
+            P192_PHASE(P192_RD_A(fa0, (par_) ^ 1, 0), P192_W3, accP[1][1], fa1, fb1, accP[1][0], fa1, fb0, , , ); \
+        } else {                                                                                              \
+            P192_PHASE(P192_RD_B(fb0, par_, 0) P192_RD_B(fb1, par_, 1), P192_W0, accP[0][0], fa0, fb0, accP[0][1], fa0, fb1, , , ); \
+            P192_PHASE(P192_RD_B(fb2, par_, 2) P192_RD_A(fa1, par_, 1), , accQ[0][0], fa0, fb2, accQ[1][0], fa1, fb2, , , ); \
+            P192_PHASE(, , accP[1][1], fa1, fb1, accP[1][0], fa1, fb0, , , );                                  \
+        }                                                                                                     \
+    }
+    // prologue: K-tile 0 complete (slots 0..6) and units 0..4 of K-tile 1 (slots 7..11): what P1(-1) and P2(-1) would have
+    // requested; K-tile 0's units 0..3 landed (8 newer requests may stay in flight)
+    P192_STAGE(0, 0, 0); P192_STAGE(0, 1, 0); P192_STAGE(0, 2, 0); P192_STAGE(0, 3, 0); P192_STAGE(0, 4, 0); P192_STAGE(0, 5, 0);
+    P192_STAGE(0, 6, 0); P192_STAGE(1, 0, 1); P192_STAGE(1, 1, 1); P192_STAGE(1, 2, 1); P192_STAGE(1, 3, 1); P192_STAGE(1, 4, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    P192_RD_A(fa0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) __builtin_amdgcn_s_barrier();      // the second half runs one barrier behind the first
+
+    int t = 0;
+    for (; t + 2 < nt; t += 2) {
+        P192_TILE(t, 0, 0);
+        P192_TILE(t + 1, 1, 0);
+    }
+    P192_TILE(t, 0, 1);
+    P192_TILE(t + 1, 1, 2);
+#undef P192_TILE
+#undef P192_PHASE
+#undef P192_RD_A
+#undef P192_RD_B
+#undef P192_STAGE
+#undef P192_W5
+#undef P192_W3
+#undef P192_W0
+    if (grp == 0) __builtin_amdgcn_s_barrier();      // re-align the two halves
+    __syncthreads();                                 // every wave is done with the ring: epilogue scratch
+    gemm_epilogue<AUX, 2>(g, accP, m0 + wr * 64, n0 + wc * 96, 0, 0, lane, 0, smem + wave * 8192, bvP, scP, 0);
+    gemm_epilogue<AUX, 1>(g, accQ, m0 + wr * 64, n0 + wc * 96 + 64, 0, 0, lane, 0, smem + wave * 8192, bvQ, scQ, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Weight-gradient GEMM on row-major operands ("KM" layout):  C[n, k] = sum_m dY[m, n] * X[m, k]
 // (reference: what autograd computes for nn.Linear / 1x1 nn.Conv2d weights, WeCLIP_model/segformer_head.py:22-28,
 //  Decoder/TransDecoder.py:98-125).  The contraction index m (tokens) is the ROW index of both operands, so the
@@ -1173,10 +1361,30 @@ extern "C" int wc_sum_slices(const float* part, float* out, int nslices, long n,
 }
 
 // Which kernel a shape takes: 0 = 128x128 kernel, 1 = 256x256 ping-pong kernel, 2 = ping-pong kernel on the
-// full 256-row tiles + the 128x128 kernel on the ragged last M % 256 rows (see wc_gemm_f16).
+// full 256-row tiles + the 128x128 / few-rows kernel on the ragged last M % 256 rows (see wc_gemm_f16), 3 / 4 = the same
+// two with the 256x192 tile.
+// Tile width (round 3, measured: profiles/r03_gemm_tiles.txt): the 192-column tile was built to remove the tile
+// quantisation of N = 768 / 2304 (256 / 768 tiles = whole rounds of the 256 CUs instead of 0.75 / 2.25 rounds) and is
+// bit-identical to the 256-column one, but on the encoder shapes it is SLOWER: proj 37.7 -> 45.0 us, fc2 91.4 -> 109.7,
+// QKV 79.7 -> 81.1, fc1 106.0 -> 114.4.  The launch time follows the bytes staged into LDS (tiles x (256 + tile width) rows
+// per K-tile: +17 % for the narrower tile), not the number of busy CUs: the K loop is paced by the operand delivery
+// (per CU the LDS-DMA path, 1.26 us per K-tile with 24 CUs active; contention between CUs adds to it: 1.66 us at 192 CUs),
+// so filling the idle quarter of the chip only raises the contention.  The 192-column tile is therefore taken only where it
+// stages FEWER bytes (N = 192, 384, 576: the 256-column tile would carry dead columns), never in the training step.
+static int g_p192_mode = -1;             // 0: never, 1: by staged bytes, 2: whenever the shape allows
+static float g_p192_cost = 1.0f;         // relative cost of a byte staged by the 192-column kernel
+extern "C" void wc_gemm_set_p192(int mode, float cost) {
+    g_p192_mode = mode;
+    if (cost > 0.f) g_p192_cost = cost;
+}
+
 static int gemm_plan(int M, int N, int K, int nseg, int batch, bool row_mapped_aux) {
     static const int pp_mode = getenv("WECLIP_GEMM_PP") ? atoi(getenv("WECLIP_GEMM_PP")) : 1;
     static const int pp_min_tiles = getenv("WECLIP_GEMM_PP_MIN_TILES") ? atoi(getenv("WECLIP_GEMM_PP_MIN_TILES")) : 160;
+    if (g_p192_mode < 0) {
+        g_p192_mode = getenv("WECLIP_GEMM_P192") ? atoi(getenv("WECLIP_GEMM_P192")) : 1;
+        if (getenv("WECLIP_GEMM_P192_COST")) g_p192_cost = (float)atof(getenv("WECLIP_GEMM_P192_COST"));
+    }
     const long gx = wc_cdiv(N, 256), gy = wc_cdiv(M, 256);
     if (!pp_mode || batch != 1 || (long)K * nseg < 2 * BK || gx * gy < pp_min_tiles) return 0;
     static int n_cu = 0;
@@ -1186,7 +1394,16 @@ static int gemm_plan(int M, int N, int K, int nseg, int batch, bool row_mapped_a
             hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
             n_cu = 256;
     }
-    const bool split = M % 256 != 0 && !row_mapped_aux && wc_cdiv(gx * (gy - 1), n_cu) < wc_cdiv(gx * gy, n_cu);
+    const bool can_split = M % 256 != 0 && !row_mapped_aux;
+    const bool split = can_split && wc_cdiv(gx * (gy - 1), n_cu) < wc_cdiv(gx * gy, n_cu);
+    const long nt = (long)(K / BK) * nseg;
+    if (g_p192_mode && N % 192 == 0 && nt >= 4 && nt % 2 == 0) {
+        const long gx2 = N / 192;
+        const bool split2 = can_split && wc_cdiv(gx2 * (gy - 1), n_cu) < wc_cdiv(gx2 * gy, n_cu);
+        const float c256 = (float)(gx * (split ? gy - 1 : gy)) * (256 + 256);
+        const float c192 = (float)(gx2 * (split2 ? gy - 1 : gy)) * (256 + 192) * g_p192_cost;
+        if (g_p192_mode >= 2 || c192 < c256) return split2 ? 4 : 3;
+    }
     return split ? 2 : 1;
 }
 
@@ -1252,14 +1469,18 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
     g.auxvec = (act == 5 && ldaux % 4 == 0 && sX2 % 4 == 0 && (uintptr_t)auxh % 8 == 0) ? 1 : 0;
     g.gx = wc_cdiv(N, BN);
     const int plan = gemm_plan(M, N, K, nseg, batch, false);
-    if (plan) {   // tall GEMM: 256x256 ping-pong kernel
-        g.gx = wc_cdiv(N, 256);
+    if (plan) {   // tall GEMM: 256x256 / 256x192 ping-pong kernel
+        const bool p192 = plan >= 3;
+        const int tn = p192 ? 192 : 256;
+        g.gx = wc_cdiv(N, tn);
         g.gy = wc_cdiv(M, 256);
         dim3 gridp((unsigned)(g.gx * (g.gy >= 16 ? (g.gy + 7) / 8 * 8 : g.gy)), 1, 1);
         static bool lds_attr_set = false;
-        if (!lds_attr_set) {      // 128 KiB of dynamic LDS is above the default per-kernel limit
+        if (!lds_attr_set) {      // 128 / 112 KiB of dynamic LDS are above the default per-kernel limit
             WC_CHECK_ARG(hipFuncSetAttribute((const void*)gemm_f16_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PP_SLOT) == hipSuccess &&
-                         hipFuncSetAttribute((const void*)gemm_f16_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PP_SLOT) == hipSuccess,
+                         hipFuncSetAttribute((const void*)gemm_f16_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PP_SLOT) == hipSuccess &&
+                         hipFuncSetAttribute((const void*)gemm_f16_p192_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 14 * P192_UNIT) == hipSuccess &&
+                         hipFuncSetAttribute((const void*)gemm_f16_p192_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 14 * P192_UNIT) == hipSuccess,
                          "wc_gemm_f16: cannot reserve 128 KiB of LDS");
             lds_attr_set = true;
         }
@@ -1267,19 +1488,28 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
         // count over a multiple of the CU count (ViT-B fc1 at 16 x 1025 tokens: 65 x 12 tiles = 3.05 rounds):
         // those rows then go to the 128x128 kernel in a second, small launch.
         const int m_main = M / 256 * 256, m_rem = M - m_main;
-        const bool split = plan == 2;
+        const bool split = plan == 2 || plan == 4;
         if (split) {
             g.M = m_main;
             g.gy -= 1;
             gridp.x = (unsigned)(g.gx * (g.gy >= 16 ? (g.gy + 7) / 8 * 8 : g.gy));
         }
         const int pr = wc_prof_begin(stream);
-        if (act >= 4)
-            hipLaunchKernelGGL(gemm_f16_pp_kernel<true>, gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
-        else
-            hipLaunchKernelGGL(gemm_f16_pp_kernel<false>, gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
-        wc_prof_end(pr, act >= 4 ? "gemm_f16_pp_kernel<true>" : "gemm_f16_pp_kernel<false>", 2.0 * g.M * N * K, stream);
-        WC_LAUNCH_CHECK("gemm_f16_pp_kernel");
+        if (p192) {
+            if (act >= 4)
+                hipLaunchKernelGGL(gemm_f16_p192_kernel<true>, gridp, dim3(512), 14 * P192_UNIT, (hipStream_t)stream, g);
+            else
+                hipLaunchKernelGGL(gemm_f16_p192_kernel<false>, gridp, dim3(512), 14 * P192_UNIT, (hipStream_t)stream, g);
+            wc_prof_end(pr, act >= 4 ? "gemm_f16_p192_kernel<true>" : "gemm_f16_p192_kernel<false>", 2.0 * g.M * N * K, stream);
+            WC_LAUNCH_CHECK("gemm_f16_p192_kernel");
+        } else {
+            if (act >= 4)
+                hipLaunchKernelGGL(gemm_f16_pp_kernel<true>, gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
+            else
+                hipLaunchKernelGGL(gemm_f16_pp_kernel<false>, gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
+            wc_prof_end(pr, act >= 4 ? "gemm_f16_pp_kernel<true>" : "gemm_f16_pp_kernel<false>", 2.0 * g.M * N * K, stream);
+            WC_LAUNCH_CHECK("gemm_f16_pp_kernel");
+        }
         if (!split) return WC_OK;
         for (int i = 0; i < nseg; ++i) g.A[i] += (long)m_main * lda;
         if (g.resid) g.resid += (long)m_main * ldr;

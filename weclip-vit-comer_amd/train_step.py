@@ -64,15 +64,21 @@ class TrainStep:
     what the step costs on the host otherwise (BENCH_r01: 9.8 ms of enqueue per 14.5 ms step).  Inputs are copied
     into static buffers (images; the pair index tensors via PairPlan.update); the gradient all-reduce and the
     optimizer stay outside the graph (RCCL and the host-computed learning-rate schedule).  The first step of a new
-    signature runs eagerly (it also warms every lazy initialisation), the second captures."""
+    signature runs eagerly (it also warms every lazy initialisation), the second captures.
 
-    def __init__(self, model, optimizer=None, radius=8, ignore_index=255, bucket=True, graph=False):
+    pad_plans (default on in graph mode): the signature is BUCKETED (clip_tool.PairPlan pad=True: pair count to a multiple
+    of 8 with dropped dummy pairs, channel capacity K to the next even number), so batches whose images carry 1..5
+    classes share a few graphs instead of one per distinct (pair count, max classes); losses, gradients and parameters
+    stay bit-identical to the unpadded eager step (tests/test_graph_step_gpu.py)."""
+
+    def __init__(self, model, optimizer=None, radius=8, ignore_index=255, bucket=True, graph=False, pad_plans=True):
         self.model = model
         self.opt = optimizer or make_optimizer(model)
         self.radius, self.ignore = radius, ignore_index
         self._mask = {}
         self.bucket = GradBucket(model.get_param_groups()[3]) if bucket else None
         self.graph = bool(graph)
+        self.pad_plans = bool(pad_plans)
         self._graphs = {}
         self._pool = None
         eng = getattr(model, "head_engine", None)
@@ -137,7 +143,7 @@ class TrainStep:
         from .clip.clip_tool import PairPlan
         m = self.model
         seg_trans = (m.iter_num + 1) > m.seg_trans_after
-        return (tuple(img.shape), PairPlan.signature(labels), bool(seg_trans), bool(m.training))
+        return (tuple(img.shape), PairPlan.signature(labels, self.pad_plans), bool(seg_trans), bool(m.training))
 
     def _graphed(self, img, labels):
         from .clip.clip_tool import PairPlan
@@ -147,7 +153,7 @@ class TrainStep:
         if ent is None:                      # first step of this signature: eager (warms lazy state), sets up the statics
             ent = self._graphs[sig] = {"graph": None, "img": torch.empty_like(img, dtype=torch.float32).contiguous(),
                                        "plan": PairPlan(labels, m.fg_text_features.shape[0], m.bg_text_features.shape[0],
-                                                        img.device)}
+                                                        img.device, pad=self.pad_plans)}
             ent["img"].copy_(img)
             return self._fwd_bwd(ent["img"], None, labels, plan=ent["plan"])
         ent["img"].copy_(img)
