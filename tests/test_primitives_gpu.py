@@ -163,7 +163,7 @@ def test_gemm_tall_192_column_tile(ops, M, N, K, nseg):
     mm = M // 256 * 256      # the ragged M % 256 rows may go to the few-rows kernel (4-way K split) in one mode only
     for k in o0:
         assert torch.equal(o0[k][:mm], o2[k][:mm]), (k, (o0[k].float() - o2[k].float()).abs().max().item())
-        assert (o0[k][mm:].float() - o2[k][mm:].float()).abs().max().item() < 2e-3
+        assert (o0[k][mm:].float() - o2[k][mm:].float()).abs().max().item() <= 2e-3 * max(1.0, o0[k][mm:].float().abs().max().item())
     sc = torch.ones(N, dtype=torch.float64)
     sc[:N // 3] = 0.18
     assert _rel((o2["h"].float() + o2["l"].float()).cpu().double(), ref * sc) < 2e-6
