@@ -130,6 +130,8 @@ int wc_aff_loss_bwd(const int64_t* cam_label, const float* coef, float* dap, int
  *           clip/model.py:186-188): v *= d/du[u*sigmoid(1.702u)] at u = aux[arow*ldaux + n],
  *           arow = rowmap[m / rpg]*rpg + m % rpg (rowmap NULL: arow = m).
  *           act 5 (backward of ReLU, segformer_head.py:26): v *= (auxh[m*ldaux + n] > 0), auxh fp16.
+ *           act 6: exact GELU 0.5 v (1 + erf(v / sqrt 2)) (nn.GELU of the ViT-CoMer inserts); act 7: its backward,
+ *           v *= Phi(u) + u phi(u) at u = aux[...] as for act 4.
  *           cscale (optional): v *= cscale[z*sCS + n] after the bias (Dropout2d mask/(1-p) of image z,
  *           segformer_head.py:78).
  * batch > 1: operand/output/residual batch strides sA/sW/sC/sR in elements.  K % 64 == 0, lda/ldw % 8 == 0. */
@@ -358,6 +360,10 @@ int wc_colscale_split(const float* x, const float* cs, float* out32, void* hi, v
  *              uint32; ws: workspace of N*M*S*2 + N*M*n_levels*Lq*P*4 int32; a level may have at most 16384 pixels. */
 int wc_msda_fwd(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
                 float* out, int N, int Lq, int M, int D, int P, void* stream);
+/* The same with an optional fp16 copy of the output (the MFMA operand of MSDeformAttn's output projection); out or out16
+ * may be NULL. */
+int wc_msda_fwd_h(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
+                  float* out, void* out16, int N, int Lq, int M, int D, int P, void* stream);
 int wc_msda_bwd(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
                 const float* gout, float* gvalue, float* gloc, float* gattn, void* gmax, void* ws, int N, int Lq, int M,
                 int D, int P, void* stream);
@@ -403,6 +409,33 @@ int wc_flip_avg(const float* segs, float* out, int C, int Hs, int Ws, int Hd, in
 int wc_resize_argmax(const float* seg, long* pred, int C, int Hs, int Ws, int Hd, int Wd, void* stream);
 int wc_confusion_hist(const long* label_true, const long* label_pred, long* hist, int* flag, long n, int nc,
                       void* stream);
+
+/* ---- fused glue of the ViT-CoMer insert engine (csrc/comer.hip; no reference code exists: ViT_CoMer.pdf §3.2-3.3) ---- */
+/* MRFP's depth-wise convolutions on token rows x (N, S, C) f32, S = sum of the n_levels maps h_shapes = {H0, W0, H1, W1, ...}:
+ * 3x3 filters w3 (C/2, 9) + b3 on channels [0, C/2), 5x5 filters w5 (C/2, 25) + b5 on [C/2, C), zero padding, all levels in
+ * one launch.  y (f32, may be NULL) = conv + bias; g16 (f16, may be NULL) = GELU(y) (erf form), the next FC's operand. */
+int wc_mrfp_dwconv_fwd(const float* x, const float* w3, const float* b3, const float* w5, const float* b5, float* y,
+                       void* g16, const int* h_shapes, int n_levels, int N, int C, void* stream);
+/* Backward: dx32 / dx16 (either may be NULL) = gradient w.r.t. x; dw3 / db3 / dw5 / db5 = alpha * filter / bias gradients
+ * (two-stage fixed-order reduction); part: workspace of N * ceil(S / 128) * C * 26 floats. */
+int wc_mrfp_dwconv_bwd(const float* dy, const float* x, const float* w3, const float* w5, float* dx32, void* dx16,
+                       float* dw3, float* db3, float* dw5, float* db5, float* part, float alpha, const int* h_shapes,
+                       int n_levels, int N, int C, void* stream);
+/* MSDeformAttn's sampling_offsets | attention_weights outputs ow (N*Lq, ld) [M*nL*P*2 offsets, then M*nL*P logits per row]
+ * -> loc (N,Lq,M,nL,P,2) = ref + offset / (W_l, H_l) and attn (N,Lq,M,nL,P) = softmax over nL*P.  ref (Lq, nl_ref, 2),
+ * nl_ref = 1 (one point for all levels) or n_levels.  bias_off (M*nL*P*2) / bias_aw (M*nL*P), optional: the two Linears'
+ * biases, added here when the fused GEMM ran without one. */
+int wc_msda_prep_fwd(const float* ow, const float* bias_off, const float* bias_aw, const float* ref, float* loc, float* attn,
+                     const int* h_shapes, int n_levels, int N, int Lq, int M, int P, int ld, int nl_ref, void* stream);
+/* Its backward: dow (N*Lq, ld) as f32 and / or f16 from the gradients of loc and attn; columns >= 3*M*nL*P are zeroed. */
+int wc_msda_prep_bwd(const float* gloc, const float* gattn, const float* attn, float* dow32, void* dow16,
+                     const int* h_shapes, int n_levels, int N, int Lq, int M, int P, int ld, void* stream);
+/* dst[b][r][0:C] (f16; row stride ld_dst, batch stride s_dst) = src[b][r][0:C] (f32 if src_is_f32 else f16; ld_src, s_src). */
+int wc_rows_copy_f16(const void* src, int src_is_f32, void* dst, int B, int R, int C, long ld_src, long s_src,
+                     long ld_dst, long s_dst, void* stream);
+/* dst[b][r][0:C] (f32, dense rows of C, batch stride s_dst) += alpha * src[b][r][0:C] (f32; ld_src, s_src). */
+int wc_rows_add_f32(const float* src, float* dst, int B, int R, int C, long ld_src, long s_src, long s_dst, float alpha,
+                    void* stream);
 
 /* ---- device-side input pipeline ------------------------------------------------------------ */
 /* datasets/transforms.py:26-49 (random_scaling), :70-84 (random_fliplr), :119-176 (random_crop, zero padding),

@@ -204,3 +204,58 @@ def test_msda_backward_is_bit_reproducible():
         grads.append((vg.grad.clone(), lg.grad.clone(), ag.grad.clone()))
     assert all(torch.equal(a, b) for a, b in zip(*grads))
     assert grads[0][0].abs().max().item() > 0
+
+
+def test_comer_engine_matches_fp64_evaluation_and_module_form(monkeypatch):
+    """comer_engine.py (one explicit forward / backward on fused launches) and the module-by-module autograd form of the same
+    network (comer.py + hip_functional.py) against an fp64 CPU evaluation of that network (stock torch modules, deformable
+    attention by grid_sample: oracle/comer_oracle.py): output, the gradients reaching the four adapter maps, and every
+    parameter gradient.  The zero-initialised gates / offset / weight Linears are randomised so that every path carries
+    signal.  The sampling-offset gradients are sums of a kinked (bilinear) derivative: fp16 operand rounding moves them by up
+    to ~10 % in BOTH forms; the engine must be as close to fp64 as the module form is."""
+    import copy
+    from weclip_vit_comer_amd.WeCLIP_model import comer as CM
+    B, H, W, dim = 2, 128, 160, 256
+    h, w = H // 16, W // 16
+    torch.manual_seed(0)
+    net = CM.CoMerInteraction(dim)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for t in net.cti:
+            t.gamma.copy_(torch.randn(dim, generator=g) * 0.5)
+            for a in (t.to_v, t.to_c):
+                a.sampling_offsets.weight.copy_(torch.randn(a.sampling_offsets.weight.shape, generator=g) * 0.02)
+                a.attention_weights.weight.copy_(torch.randn(a.attention_weights.weight.shape, generator=g) * 0.05)
+                a.attention_weights.bias.copy_(torch.randn(a.attention_weights.bias.shape, generator=g) * 0.2)
+    img = torch.randn(B, 3, H, W, generator=g)
+    maps0 = [torch.randn(B, h * w, dim, generator=g) for _ in range(11)]
+    gy = torch.randn(B, dim, h, w, generator=g)
+    ref = copy.deepcopy(net).double()
+    monkeypatch.setattr(CM, "ms_deform_attn_core", lambda value, shapes, loc, attn: CO.ms_deform_attn(value, shapes, loc, attn))
+    maps = [m.double().requires_grad_(True) for m in maps0]
+    y = ref(img.double(), maps, (h, w))
+    y.backward(gy.double())
+    monkeypatch.undo()
+    R = (y.detach(), [maps[b].grad for b in net.stage_blocks], {n: p.grad for n, p in ref.named_parameters()})
+    assert all(v.abs().max().item() > 0 for v in R[2].values())
+    net = net.cuda()
+    rel = lambda a, b: (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+    errs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("WECLIP_COMER_ENGINE", mode)
+        for p in net.parameters():
+            p.grad = None
+        maps = [m.cuda().requires_grad_(True) for m in maps0]
+        y = net(img.cuda(), maps, (h, w))
+        y.backward(gy.cuda())
+        errs[mode] = (rel(y.detach().cpu().double(), R[0]),
+                      max(rel(maps[b].grad.cpu().double(), r) for b, r in zip(net.stage_blocks, R[1])),
+                      {n: rel(p.grad.cpu().double(), R[2][n]) for n, p in net.named_parameters()})
+    assert net._engine is not None
+    (ym, mm, pm), (ye, me, pe) = errs["0"], errs["1"]
+    med = sorted(pe.values())[len(pe) // 2]
+    print(f"comer vs fp64: module form y {ym:.1e} d(maps) {mm:.1e} worst dparam {max(pm.values()):.1e} | engine y {ye:.1e} "
+          f"d(maps) {me:.1e} worst dparam {max(pe.values()):.1e} median {med:.1e}")
+    assert ye < 3e-3 and me < 1e-2 and med < 5e-3, (ye, me, med)
+    bad = {n: (pe[n], pm[n]) for n in pe if pe[n] > max(2e-2, 1.5 * pm[n])}
+    assert not bad, bad

@@ -1,0 +1,33 @@
+"""The ViT-CoMer inserts alone (CoMerInteraction forward + backward at the benchmark geometry): ms per pass.
+    python tools/comer_bench.py [batch] [size]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from weclip_vit_comer_amd.WeCLIP_model.comer import CoMerInteraction
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+n = int(os.environ.get("CB_ITERS", "5"))
+torch.manual_seed(0)
+net = CoMerInteraction(256).cuda()
+img = torch.randn(B, 3, S, S, device="cuda")
+h = w = S // 16
+maps = [torch.randn(B, h * w, 256, device="cuda", requires_grad=True) if i in net.stage_blocks else None for i in range(11)]
+gy = torch.randn(B, 256, h, w, device="cuda")
+
+
+def step():
+    for p in net.parameters():
+        p.grad = None
+    y = net(img, maps, (h, w))
+    y.backward(gy)
+
+
+for _ in range(2):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+    step()
+torch.cuda.synchronize()
+print(f"CoMerInteraction fwd+bwd, B={B} {S}x{S}: {(time.perf_counter() - t0) / n * 1e3:.2f} ms per pass (eager, {n} passes)")

@@ -16,6 +16,7 @@ GroupNorm + ReLU are csrc/convstem.hip.  Parity is pinned only against oracle/co
 modules (no reference exists).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -245,9 +246,24 @@ class CoMerInteraction(nn.Module):
         self.mrfp = nn.ModuleList([MRFP(dim) for _ in stage_blocks])
         self.cti = nn.ModuleList([CTI(dim, heads, points) for _ in stage_blocks])
         self.fuse = nn.Conv2d(2 * len(stage_blocks) * dim, dim, 1)
+        self._engine = None
+
+    def _forward_engine(self, img, adapter_maps, hw):
+        """CUDA path: the conv stem on its autograd Functions, everything behind it as ONE explicit forward / backward
+        engine on fused HIP launches (comer_engine.py); same arithmetic as the module-by-module form below."""
+        from ..comer_engine import ComerEngine, ComerFunction
+        if self._engine is None:
+            self._engine = ComerEngine(self)
+        h, w = hw
+        c0, shapes = self.spm(img)
+        maps = [adapter_maps[b] for b in self.stage_blocks]
+        y = ComerFunction.apply(self._engine, tuple(tuple(s) for s in shapes), (h, w), c0, *maps, *self._engine.params())
+        return y.view(img.shape[0], h * w, -1).transpose(1, 2).reshape(img.shape[0], -1, h, w)
 
     def forward(self, img, adapter_maps, hw):
         """adapter_maps: list of (B, h*w, dim) adapter outputs, one per ViT block; hw = (h, w)."""
+        if img.is_cuda and len(self.stage_blocks) == 4 and os.environ.get("WECLIP_COMER_ENGINE", "1") != "0":
+            return self._forward_engine(img, adapter_maps, hw)
         h, w = hw
         c, shapes = self.spm(img)
         outs = []

@@ -1,0 +1,397 @@
+"""The ViT-CoMer inserts as ONE explicit forward / backward engine on the HIP path.
+
+There is no CoMer code in the reference repository (only ViT_CoMer.pdf §3.2-3.3 and the brief): the network is this
+package's own `WeCLIP_model.comer.CoMerInteraction` (MRFP + bidirectional CTI with multi-scale deformable attention on the
+adapter outputs of four ViT blocks, fused by a 1x1 conv into the decoder input).  Its module-by-module autograd form
+(comer.py + hip_functional.py) launches ~1 070 kernels per pass, a third of them conversions, transposes, concatenations
+and element-wise glue; this engine runs the same arithmetic on token rows end to end:
+
+  * every activation that feeds a GEMM leaves its producer as the fp16 MFMA operand (LayerNorm, GEMM epilogue, deformable
+    attention, the depth-wise conv kernel): no split / cast passes; all weights are converted (row-major and transposed)
+    by ONE launch per step (ops.WeightCache), `sampling_offsets` and `attention_weights` run as one GEMM on stacked weights;
+  * residual adds, the CTI gate `gamma`, the exact GELU (forward and derivative) live in GEMM epilogues (csrc/gemm.hip
+    act 6 / 7, cscale, resid); the soft-max over the sampling weights and the sampling-location arithmetic are one small
+    kernel each way (csrc/comer.hip msda_prep_*);
+  * MRFP's depth-wise 3x3 / 5x5 convolutions of all pyramid levels are one launch on NHWC rows with the GELU fused
+    (csrc/comer.hip mrfp_dwconv_*): no NCHW transposes, no channel concatenations;
+  * the backward pass is written out (no autograd graph inside): weight gradients by the split-K row-major GEMM
+    (gemm_km), their reductions collected into one launch, gradients carried multiplied by GRAD_SCALE like the head's.
+
+The conv stem (`SpatialPrior`) stays on its autograd Functions (hip_functional.conv3x3_rows / groupnorm_relu_rows); the
+engine starts from its output and hands its gradient back.  Parity: against the module-by-module form
+(tests/test_comer_gpu.py), which is itself pinned only to oracle/comer_oracle.py and stock torch ("parity unpinned").
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from . import config, ops
+from .ops import F16, F32, Split
+
+GS = 4096.0
+INV = 1.0 / GS
+
+
+def _shape_array(shapes):
+    return L.int_array([v for hw in shapes for v in hw])
+
+
+class ComerEngine:
+    def __init__(self, net):
+        self.net = net
+        self.wc = ops.WeightCache()
+        self._ref = {}
+
+    # ------------------------------------------------------------------------------------------ parameters
+    def params(self):
+        """Every parameter the engine differentiates (all of the inserts except the conv stem), in a fixed order."""
+        net = self.net
+        out = []
+        for m, c in zip(net.mrfp, net.cti):
+            out += [m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, m.dw3.weight, m.dw3.bias, m.dw5.weight, m.dw5.bias]
+            out += [c.nv_q.weight, c.nv_q.bias, c.nv_f.weight, c.nv_f.bias, c.gamma, c.nc_q.weight, c.nc_q.bias,
+                    c.nc_f.weight, c.nc_f.bias, c.ffn_norm.weight, c.ffn_norm.bias,
+                    c.ffn[0].weight, c.ffn[0].bias, c.ffn[2].weight, c.ffn[2].bias]
+            for a in (c.to_v, c.to_c):
+                out += [a.sampling_offsets.weight, a.sampling_offsets.bias, a.attention_weights.weight, a.attention_weights.bias,
+                        a.value_proj.weight, a.value_proj.bias, a.output_proj.weight, a.output_proj.bias]
+        out += [net.fuse.weight, net.fuse.bias]
+        return out
+
+    def _mats(self):
+        f = lambda t: t.detach() if (t.dtype == F32 and t.is_contiguous()) else t.detach().float().contiguous()
+        out = []
+        for i, (m, c) in enumerate(zip(self.net.mrfp, self.net.cti)):
+            out += [(f"m{i}.fc1", f(m.fc1.weight)), (f"m{i}.fc2", f(m.fc2.weight)), (f"f{i}.0", f(c.ffn[0].weight)),
+                    (f"f{i}.2", f(c.ffn[2].weight))]
+            for tag, a in (("v", c.to_v), ("c", c.to_c)):
+                out += [(f"{tag}{i}.vp", f(a.value_proj.weight)), (f"{tag}{i}.op", f(a.output_proj.weight)),
+                        (f"{tag}{i}.ow", [f(a.sampling_offsets.weight), f(a.attention_weights.weight)])]
+        out.append(("fuse", f(self.net.fuse.weight).flatten(1)))
+        return out
+
+    def ref_points(self, shapes, dev):
+        """(sum H*W, 2) reference points (x, y) in [0,1] of the pixels of the given maps, in row order."""
+        key = (tuple(shapes), str(dev))
+        if key not in self._ref:
+            pts = []
+            for h, w in shapes:
+                ys, xs = torch.meshgrid((torch.arange(h, device=dev) + 0.5) / h, (torch.arange(w, device=dev) + 0.5) / w, indexing="ij")
+                pts.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+            self._ref[key] = torch.cat(pts, 0).float().contiguous()
+        return self._ref[key]
+
+    # ------------------------------------------------------------------------------------------ small wrappers
+    @staticmethod
+    def _b(p):
+        return p.detach().float().contiguous()
+
+    def _ln16(self, x, ln):
+        return ops.layernorm(x, self._b(ln.weight), self._b(ln.bias), eps=ln.eps, want32=False, want16=True)[1].hi
+
+    def _msda_fwd(self, value, shapes, ow, ld, att, ref, B, Lq):
+        """value (B*S, 256) f32, ow (B*Lq, ld) f32 -> (o16 (B*Lq, 256) f16, loc, attn)."""
+        M, P, nL = att.n_heads, att.n_points, len(shapes)
+        D = att.d_model // M
+        dev = value.device
+        loc = torch.empty(B * Lq * M * nL * P * 2, device=dev, dtype=F32)
+        attn = torch.empty(B * Lq * M * nL * P, device=dev, dtype=F32)
+        hs = _shape_array(shapes)
+        lib = L.lib()
+        lib.wc_msda_prep_fwd(L.ptr(ow, F32), L.ptr(self._b(att.sampling_offsets.bias), F32), L.ptr(self._b(att.attention_weights.bias), F32),
+                             L.ptr(ref, F32), L.ptr(loc), L.ptr(attn), hs, nL, B, Lq, M, P, ld, 1, L.stream())
+        o16 = torch.empty(B * Lq, M * D, device=dev, dtype=F16)
+        lib.wc_msda_fwd_h(L.ptr(value, F32), hs, nL, L.ptr(loc), L.ptr(attn), None, L.ptr(o16), B, Lq, M, D, P, L.stream())
+        return o16, loc, attn
+
+    def _msda_bwd(self, value, shapes, loc, attn, gout, att, B, Lq, ld):
+        """-> (dvalue (B*S, 256) f32, dow16 (B*Lq, ld) f16 with zeroed padding columns)."""
+        M, P, nL = att.n_heads, att.n_points, len(shapes)
+        D = att.d_model // M
+        S = sum(h * w for h, w in shapes)
+        dev = value.device
+        gv = torch.empty_like(value)
+        gl, ga = torch.empty_like(loc), torch.empty_like(attn)
+        gmax = torch.empty(1, device=dev, dtype=torch.int32)
+        ws = torch.empty(B * M * (2 * S + nL * Lq * P * 4), device=dev, dtype=torch.int32)
+        hs = _shape_array(shapes)
+        lib = L.lib()
+        lib.wc_msda_bwd(L.ptr(value, F32), hs, nL, L.ptr(loc), L.ptr(attn), L.ptr(gout, F32, "gout"), L.ptr(gv), L.ptr(gl), L.ptr(ga),
+                        L.ptr(gmax), L.ptr(ws), B, Lq, M, D, P, L.stream())
+        dow16 = torch.empty(B * Lq, ld, device=dev, dtype=F16)
+        lib.wc_msda_prep_bwd(L.ptr(gl), L.ptr(ga), L.ptr(attn), None, L.ptr(dow16), hs, nL, B, Lq, M, P, ld, L.stream())
+        return gv, dow16
+
+    @staticmethod
+    def _f16(x, alpha=1.0, cs=None):
+        """fp32 rows -> fp16 operand (optionally x alpha, x a column scale)."""
+        rows = x.shape[0]
+        return ops.colscale_split(x, cs, rows, want32=False, with_lo=False, alpha=alpha)[1].hi
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, c0, shapes, hw, maps):
+        """c0 (B, S, C) pyramid tokens of the stem; shapes [(H, W)] x 3; maps: the 4 adapter outputs (B, h*w, C).
+        -> (y rows (B*h*w, C) f32, ctx)."""
+        net = self.net
+        B, S, C = c0.shape
+        h, w = hw
+        nhw = h * w
+        Mc, Mv = B * S, B * nhw
+        dev = c0.device
+        lib = L.lib()
+        self.wc.refresh(self._mats(), False, force=True)
+        W = self.wc.w
+        hs3 = _shape_array(shapes)
+        n16 = shapes[0][0] * shapes[0][1]              # the 1/16 level's rows inside an image's S rows
+        if shapes[1] != (h, w):
+            raise RuntimeError("ComerEngine: the stem's middle level must be the 1/16 map")
+        ref_v = self.ref_points([(h, w)], dev)
+        ref_c = self.ref_points(shapes, dev)
+        c = c0.detach().float().contiguous().view(Mc, C)
+        c16 = torch.empty(Mc, C, device=dev, dtype=F16)
+        lib.wc_rows_copy_f16(L.ptr(c, F32), 1, L.ptr(c16), 1, Mc, C, C, 0, C, 0, L.stream())
+        nst = len(net.stage_blocks)
+        cat16 = torch.empty(Mv, 2 * nst * C, device=dev, dtype=F16)
+        st = []
+        for i in range(nst):
+            m, t = net.mrfp[i], net.cti[i]
+            hid = m.fc1.weight.shape[0]
+            s = {}
+            v = maps[i].detach().float().contiguous().view(Mv, C)
+            # ---- MRFP: c1 = c + fc2(gelu(dwconv(fc1(c))))
+            x1 = torch.empty(Mc, hid, device=dev, dtype=F32)
+            ops.gemm(c16, W(f"m{i}.fc1"), Mc, hid, C, bias=self._b(m.fc1.bias), out32=x1)
+            x2 = torch.empty(Mc, hid, device=dev, dtype=F32)
+            g16 = torch.empty(Mc, hid, device=dev, dtype=F16)
+            lib.wc_mrfp_dwconv_fwd(L.ptr(x1), L.ptr(self._b(m.dw3.weight).view(-1), F32), L.ptr(self._b(m.dw3.bias), F32),
+                                   L.ptr(self._b(m.dw5.weight).view(-1), F32), L.ptr(self._b(m.dw5.bias), F32), L.ptr(x2), L.ptr(g16),
+                                   hs3, len(shapes), B, hid, L.stream())
+            c1 = torch.empty(Mc, C, device=dev, dtype=F32)
+            ops.gemm(g16, W(f"m{i}.fc2"), Mc, C, hid, bias=self._b(m.fc2.bias), resid=c, out32=c1)
+            # ---- CTI-toV: v1 = v + gamma * out_proj(msda(LN(v) -> offsets / weights, value_proj(LN(c1))))
+            q1 = self._ln16(v, t.nv_q)
+            f1 = self._ln16(c1, t.nv_f)
+            val1 = torch.empty(Mc, C, device=dev, dtype=F32)
+            ops.gemm(f1, W(f"v{i}.vp"), Mc, C, C, bias=self._b(t.to_v.value_proj.bias), out32=val1)
+            n1 = W(f"v{i}.ow").hi.shape[0]
+            ld1 = (n1 + 63) // 64 * 64
+            ow1 = torch.empty(Mv, ld1, device=dev, dtype=F32)
+            ops.gemm(q1, W(f"v{i}.ow"), Mv, n1, C, out32=ow1, ldc=ld1)
+            o1, loc1, at1 = self._msda_fwd(val1, shapes, ow1, ld1, t.to_v, ref_v, B, nhw)
+            v1 = torch.empty(Mv, C, device=dev, dtype=F32)
+            ops.gemm(o1, W(f"v{i}.op"), Mv, C, C, bias=self._b(t.to_v.output_proj.bias), cscale=self._b(t.gamma).view(1, C), sCS=0,
+                     resid=v, out32=v1)
+            lib.wc_rows_copy_f16(L.ptr(v1, F32), 1, L.ptr(cat16.view(-1)[2 * i * C:]), 1, Mv, C, C, 0, 2 * nst * C, 0, L.stream())
+            # ---- CTI-toC: c2 = c1 + out_proj(msda(LN(c1), value_proj(LN(v1))))
+            q2 = self._ln16(c1, t.nc_q)
+            f2 = self._ln16(v1, t.nc_f)
+            val2 = torch.empty(Mv, C, device=dev, dtype=F32)
+            ops.gemm(f2, W(f"c{i}.vp"), Mv, C, C, bias=self._b(t.to_c.value_proj.bias), out32=val2)
+            n2 = W(f"c{i}.ow").hi.shape[0]
+            ld2 = (n2 + 63) // 64 * 64
+            ow2 = torch.empty(Mc, ld2, device=dev, dtype=F32)
+            ops.gemm(q2, W(f"c{i}.ow"), Mc, n2, C, out32=ow2, ldc=ld2)
+            o2, loc2, at2 = self._msda_fwd(val2, [(h, w)], ow2, ld2, t.to_c, ref_c, B, S)
+            c2 = torch.empty(Mc, C, device=dev, dtype=F32)
+            ops.gemm(o2, W(f"c{i}.op"), Mc, C, C, bias=self._b(t.to_c.output_proj.bias), resid=c1, out32=c2)
+            # ---- FFN: c3 = c2 + ffn2(gelu(ffn0(LN(c2))))
+            n3 = self._ln16(c2, t.ffn_norm)
+            u = torch.empty(Mc, C, device=dev, dtype=F32)
+            g2 = torch.empty(Mc, C, device=dev, dtype=F16)
+            ops.gemm(n3, W(f"f{i}.0"), Mc, C, C, bias=self._b(t.ffn[0].bias), pre32=u, out16=g2, act=6)
+            c3 = torch.empty(Mc, C, device=dev, dtype=F32)
+            c3_16 = torch.empty(Mc, C, device=dev, dtype=F16)
+            ops.gemm(g2, W(f"f{i}.2"), Mc, C, C, bias=self._b(t.ffn[2].bias), resid=c2, out32=c3, out16=c3_16)
+            lib.wc_rows_copy_f16(L.ptr(c3_16.view(-1)[n16 * C:], F16), 0, L.ptr(cat16.view(-1)[(2 * i + 1) * C:]), B, nhw, C, C, S * C,
+                                 2 * nst * C, nhw * 2 * nst * C, L.stream())
+            s.update(c16=c16, x1=x1, x2=x2, g16=g16, c1=c1, v=v, q1=q1, f1=f1, val1=val1, loc1=loc1, at1=at1, o1=o1, v1=v1, ld1=ld1,
+                     n1=n1, q2=q2, f2=f2, val2=val2, loc2=loc2, at2=at2, o2=o2, c2=c2, ld2=ld2, n2=n2, n3=n3, u=u, g2=g2)
+            st.append(s)
+            c, c16 = c3, c3_16
+        y = torch.empty(Mv, C, device=dev, dtype=F32)
+        ops.gemm(cat16, W("fuse"), Mv, C, 2 * nst * C, bias=self._b(net.fuse.bias), out32=y)
+        ctx = dict(st=st, cat16=cat16, B=B, S=S, C=C, hw=(h, w), shapes=[tuple(x) for x in shapes], n16=n16)
+        return y, ctx
+
+    # ------------------------------------------------------------------------------------------ backward
+    def _wgrad(self, dy16, x16, M, N, K, grads, pw, pb, lda=None):
+        """pw.grad / pb.grad (unscaled) of y = x W^T + b from the fp16 operands dy16 (M, lda >= N) [x GS] and x16 (M, K)."""
+        tiles = ((N + 127) // 128) * ((K + 1 + 127) // 128)
+        ns = 1
+        while ns * 2 * tiles <= 512 and M // (ns * 2) >= 256:
+            ns *= 2
+        part, ns = ops.wgrad_partials(dy16, x16, M, N, K, lda=lda, slices=ns, bias=True)
+        dw = torch.empty(N, K, device=dy16.device, dtype=F32)
+        db = torch.empty(N, device=dy16.device, dtype=F32)
+        self._pending.append((part, dw, db, ns, N, K))
+        if pw is not None:
+            grads[id(pw)] = dw.view(pw.shape)
+        if pb is not None:
+            grads[id(pb)] = db
+        return dw, db
+
+    def _flush(self):
+        import struct
+        jobs = self._pending
+        if not jobs:
+            return
+        abits = struct.unpack("<I", struct.pack("<f", INV))[0]
+        flat = []
+        for part, dw, db, ns, N, K in jobs:
+            flat += [part.data_ptr(), dw.data_ptr(), db.data_ptr(), ns, N, K, abits]
+        arr = (ctypes.c_int64 * len(flat))(*flat)
+        L.lib().wc_sum_slices_wb_multi(arr, len(jobs), L.stream())
+
+    def backward(self, ctx, dy):
+        """dy (B*h*w, C) f32 -> (dc0 (B, S, C), [dv x 4], {id(param): grad})."""
+        self._pending = []
+        try:
+            out = self._backward(ctx, dy)
+            self._flush()
+        finally:
+            self._pending = None
+        return out
+
+    def _ln_bwd(self, dy, x, ln, add, grads):
+        dx, _, dgb = ops.layernorm_bwd(dy, x, self._b(ln.weight), add=add, want32=True, alpha=INV, eps=ln.eps)
+        grads[id(ln.weight)], grads[id(ln.bias)] = dgb[0], dgb[1]
+        return dx
+
+    def _backward(self, ctx, dy):
+        net = self.net
+        B, S, C = ctx["B"], ctx["S"], ctx["C"]
+        h, w = ctx["hw"]
+        shapes, n16 = ctx["shapes"], ctx["n16"]
+        nhw = h * w
+        Mc, Mv = B * S, B * nhw
+        dev = dy.device
+        lib = L.lib()
+        WT = lambda n: self.wc.wT(n)[0]
+        nst = len(net.stage_blocks)
+        grads, dvs = {}, [None] * nst
+        hs3 = _shape_array(shapes)
+        # ---- fuse conv: dcat pieces and the fuse weight gradient (everything from here on is multiplied by GS)
+        dy16 = self._f16(dy.float().contiguous(), alpha=GS)
+        self._wgrad(dy16, ctx["cat16"], Mv, C, 2 * nst * C, grads, net.fuse.weight, net.fuse.bias)
+        fuseT = WT("fuse").hi                                   # (2*nst*C, ldT = C)
+        pieces = []
+        for j in range(2 * nst):
+            d = torch.empty(Mv, C, device=dev, dtype=F32)
+            ops.gemm(dy16, fuseT[j * C:(j + 1) * C], Mv, C, C, out32=d)
+            pieces.append(d)
+        dc3 = None
+        for i in reversed(range(nst)):
+            m, t, s = net.mrfp[i], net.cti[i], ctx["st"][i]
+            hid = m.fc1.weight.shape[0]
+            if dc3 is None:
+                dc3 = torch.zeros(Mc, C, device=dev, dtype=F32)
+            lib.wc_rows_add_f32(L.ptr(pieces[2 * i + 1], F32), L.ptr(dc3.view(-1)[n16 * C:], F32), B, nhw, C, C, nhw * C, S * C, 1.0,
+                                L.stream())
+            # ---- FFN
+            dc3_16 = self._f16(dc3)
+            du16 = torch.empty(Mc, C, device=dev, dtype=F16)
+            ops.gemm(dc3_16, WT(f"f{i}.2"), Mc, C, C, out16=du16, act=7, aux=s["u"], ldaux=C, rpg=1)
+            self._wgrad(dc3_16, s["g2"], Mc, C, C, grads, t.ffn[2].weight, t.ffn[2].bias)
+            dn3 = torch.empty(Mc, C, device=dev, dtype=F32)
+            ops.gemm(du16, WT(f"f{i}.0"), Mc, C, C, out32=dn3)
+            self._wgrad(du16, s["n3"], Mc, C, C, grads, t.ffn[0].weight, t.ffn[0].bias)
+            dc2 = self._ln_bwd(dn3, s["c2"], t.ffn_norm, dc3, grads)
+            # ---- CTI-toC
+            dc2_16 = self._f16(dc2)
+            do2 = torch.empty(Mc, C, device=dev, dtype=F32)
+            ops.gemm(dc2_16, WT(f"c{i}.op"), Mc, C, C, out32=do2)
+            self._wgrad(dc2_16, s["o2"], Mc, C, C, grads, t.to_c.output_proj.weight, t.to_c.output_proj.bias)
+            dval2, dow2 = self._msda_bwd(s["val2"], [(h, w)], s["loc2"], s["at2"], do2, t.to_c, B, S, s["ld2"])
+            dq2 = torch.empty(Mc, C, device=dev, dtype=F32)
+            ops.gemm(dow2, WT(f"c{i}.ow"), Mc, C, s["ld2"], out32=dq2)
+            self._ow_grads(dow2, s["q2"], Mc, s["n2"], s["ld2"], t.to_c, grads)
+            dc1 = self._ln_bwd(dq2, s["c1"], t.nc_q, dc2, grads)
+            dval2_16 = self._f16(dval2)
+            df2 = torch.empty(Mv, C, device=dev, dtype=F32)
+            ops.gemm(dval2_16, WT(f"c{i}.vp"), Mv, C, C, out32=df2)
+            self._wgrad(dval2_16, s["f2"], Mv, C, C, grads, t.to_c.value_proj.weight, t.to_c.value_proj.bias)
+            dv1 = self._ln_bwd(df2, s["v1"], t.nc_f, pieces[2 * i], grads)
+            # ---- CTI-toV: v1 = v + gamma * (o1 Wop^T + bop)
+            gam = self._b(t.gamma)
+            gdv1_16 = self._f16(dv1, cs=gam.view(1, C))
+            do1 = torch.empty(Mv, C, device=dev, dtype=F32)
+            ops.gemm(gdv1_16, WT(f"v{i}.op"), Mv, C, C, out32=do1)
+            dv1_16 = self._f16(dv1)
+            G, gsum = self._wgrad(dv1_16, s["o1"], Mv, C, C, grads, None, None)          # G = dv1^T o1, gsum = dv1^T 1 (unscaled)
+            self._gamma_jobs.append((t, G, gsum))
+            dval1, dow1 = self._msda_bwd(s["val1"], shapes, s["loc1"], s["at1"], do1, t.to_v, B, nhw, s["ld1"])
+            dq1 = torch.empty(Mv, C, device=dev, dtype=F32)
+            ops.gemm(dow1, WT(f"v{i}.ow"), Mv, C, s["ld1"], out32=dq1)
+            self._ow_grads(dow1, s["q1"], Mv, s["n1"], s["ld1"], t.to_v, grads)
+            dvs[i] = self._ln_bwd(dq1, s["v"], t.nv_q, dv1, grads)
+            dval1_16 = self._f16(dval1)
+            df1 = torch.empty(Mc, C, device=dev, dtype=F32)
+            ops.gemm(dval1_16, WT(f"v{i}.vp"), Mc, C, C, out32=df1)
+            self._wgrad(dval1_16, s["f1"], Mc, C, C, grads, t.to_v.value_proj.weight, t.to_v.value_proj.bias)
+            dc1 = self._ln_bwd(df1, s["c1"], t.nv_f, dc1, grads)
+            # ---- MRFP
+            dc1_16 = self._f16(dc1)
+            dx2 = torch.empty(Mc, hid, device=dev, dtype=F32)
+            ops.gemm(dc1_16, WT(f"m{i}.fc2"), Mc, hid, C, out32=dx2, act=7, aux=s["x2"], ldaux=hid, rpg=1)
+            self._wgrad(dc1_16, s["g16"], Mc, C, hid, grads, m.fc2.weight, m.fc2.bias)
+            dx1_16 = torch.empty(Mc, hid, device=dev, dtype=F16)
+            half = hid // 2
+            dw3, db3 = torch.empty(half, 9, device=dev, dtype=F32), torch.empty(half, device=dev, dtype=F32)
+            dw5, db5 = torch.empty(half, 25, device=dev, dtype=F32), torch.empty(half, device=dev, dtype=F32)
+            part = torch.empty(B * ((S + 127) // 128) * hid * 26, device=dev, dtype=F32)
+            lib.wc_mrfp_dwconv_bwd(L.ptr(dx2), L.ptr(s["x1"]), L.ptr(self._b(m.dw3.weight).view(-1), F32), L.ptr(self._b(m.dw5.weight).view(-1), F32),
+                                   None, L.ptr(dx1_16), L.ptr(dw3), L.ptr(db3), L.ptr(dw5), L.ptr(db5), L.ptr(part), INV, hs3,
+                                   len(shapes), B, hid, L.stream())
+            grads[id(m.dw3.weight)], grads[id(m.dw3.bias)] = dw3.view(m.dw3.weight.shape), db3
+            grads[id(m.dw5.weight)], grads[id(m.dw5.bias)] = dw5.view(m.dw5.weight.shape), db5
+            dc = torch.empty(Mc, C, device=dev, dtype=F32)
+            ops.gemm(dx1_16, WT(f"m{i}.fc1"), Mc, C, hid, out32=dc, resid=dc1)
+            self._wgrad(dx1_16, s["c16"], Mc, hid, C, grads, m.fc1.weight, m.fc1.bias)
+            dc3 = dc
+        return dc3, dvs, grads
+
+    def _ow_grads(self, dow16, q16, M, n, ld, att, grads):
+        """Weight / bias gradients of the stacked sampling_offsets | attention_weights GEMM."""
+        dw, db = self._wgrad(dow16, q16, M, n, att.d_model, grads, None, None, lda=ld)
+        self._ow_jobs.append((att, dw, db))
+
+    def run_backward(self, ctx, dy):
+        """backward() plus the tiny post-processing that needs the reduced partials: the stacked gradients are split into
+        their two Linears, and gamma's gradient comes out of the output projection's un-gated weight gradient
+        G = dv1^T o1:  dWop = diag(gamma) G,  dbop = gamma * s,  dgamma = rowsum(Wop * G) + bop * s  (s = dv1^T 1)."""
+        self._ow_jobs, self._gamma_jobs = [], []
+        dc0, dvs, grads = self.backward(ctx, dy)
+        for att, dw, db in self._ow_jobs:
+            n_off = att.sampling_offsets.weight.shape[0]
+            grads[id(att.sampling_offsets.weight)], grads[id(att.attention_weights.weight)] = dw[:n_off], dw[n_off:]
+            grads[id(att.sampling_offsets.bias)], grads[id(att.attention_weights.bias)] = db[:n_off], db[n_off:]
+        for t, G, gsum in self._gamma_jobs:
+            gam, Wop, bop = t.gamma.detach().float(), t.to_v.output_proj.weight.detach().float(), t.to_v.output_proj.bias.detach().float()
+            grads[id(t.to_v.output_proj.weight)] = gam[:, None] * G
+            grads[id(t.to_v.output_proj.bias)] = gam * gsum
+            grads[id(t.gamma)] = (Wop * G).sum(1) + bop * gsum
+        self._ow_jobs, self._gamma_jobs = None, None
+        B, S, C = ctx["B"], ctx["S"], ctx["C"]
+        return (dc0 * INV).view(B, S, C), [d * INV for d in dvs], grads
+
+
+class ComerFunction(torch.autograd.Function):
+    """autograd bridge: (c0, 4 adapter maps, params...) -> fused rows (B*h*w, C); backward = ComerEngine.run_backward."""
+
+    @staticmethod
+    def forward(ctx, engine, shapes, hw, c0, m0, m1, m2, m3, *params):
+        y, c = engine.forward(c0, shapes, hw, [m0, m1, m2, m3])
+        ctx.engine, ctx.c, ctx.map_shapes = engine, c, [m.shape for m in (m0, m1, m2, m3)]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        eng = ctx.engine
+        dc0, dvs, grads = eng.run_backward(ctx.c, dy.contiguous())
+        ctx.c = None
+        out = []
+        for p in eng.params():
+            g = grads.get(id(p))
+            out.append(g.reshape(p.shape) if g is not None else None)
+        return (None, None, None, dc0) + tuple(d.view(s) for d, s in zip(dvs, ctx.map_shapes)) + tuple(out)

@@ -41,12 +41,12 @@ struct GemmArgs {
     __half* C16;
     __half* C16lo;
     long ldc;
-    int act;              // 0 none, 1 QuickGELU x*sigmoid(1.702x), 2 ReLU, 3 sigmoid
+    int act;              // 0 none, 1 QuickGELU x*sigmoid(1.702x), 2 ReLU, 3 sigmoid, 6 GELU (erf); 4 / 5 / 7: see aux / auxh
     int round16;          // round (acc+bias) through fp16 first (forced-fp16 out-proj, myAtt.py:321)
     float scale;          // multiply columns n < scale_cols by scale (q / sqrt(dh), myAtt.py:54)
     int scale_cols;
     float* P32;           // optional fp32 copy of the pre-activation value (acc + bias)
-    const float* aux;     // act 4: v *= QuickGELU'(aux[arow*ldaux + n]), arow = rowmap[m / rpg]*rpg + m % rpg
+    const float* aux;     // act 4: v *= QuickGELU'(aux[arow*ldaux + n]), arow = rowmap[m / rpg]*rpg + m % rpg; act 7: v *= GELU'(aux[..])
     const int* rowmap;
     int row0;             // row index of this launch's first row in the caller's matrix (rowmap arithmetic after a row split)
     int rpg;
@@ -77,6 +77,9 @@ struct GemmArgs {
         _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_) (v_)[e_] = fmaxf((v_)[e_], 0.f);      \
     } else if (act == 3) {                                                                        \
         _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_) (v_)[e_] = __builtin_amdgcn_rcpf(1.0f + __expf(-(v_)[e_])); \
+    } else if (act == 6) {                                                                        \
+        _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_)                                       \
+            (v_)[e_] = 0.5f * (v_)[e_] * (1.0f + erff((v_)[e_] * 0.70710678118654752f));          \
     }
 
 // Per-column epilogue constants of a lane's two output columns (bias, scale): fetched BEFORE the K loop of a
@@ -133,7 +136,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
             }
         };
         if constexpr (AUX) {
-            if (act == 4) aux_load(0, ua[0]);
+            if (act == 4 || act == 7) aux_load(0, ua[0]);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {            // rows [16c, 16c+16) of the wave's 64x64 sub-tile
@@ -141,7 +144,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
             float* tile = tile0 + (c & 1) * 1024;
             float v[NI * 8];
             if constexpr (AUX) {
-                if (act == 4 && c + 1 < 4) aux_load(c + 1, ua[(c + 1) & 1]);
+                if ((act == 4 || act == 7) && c + 1 < 4) aux_load(c + 1, ua[(c + 1) & 1]);
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
@@ -186,6 +189,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                             const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u[k]));
                             f[it][k] *= sg * (1.0f + 1.702f * u[k] * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
                         }
+                    } else if (act == 7) {
+                        const float (&u)[4] = ua[c & 1][it];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)      // d/du [u * Phi(u)] = Phi(u) + u * phi(u)
+                            f[it][k] *= 0.5f * (1.0f + erff(u[k] * 0.70710678118654752f)) + u[k] * 0.3989422804014327f * __expf(-0.5f * u[k] * u[k]);
                     } else {
                         const __half* hp = g.auxh + xb + (long)grow * g.ldaux + gcol;
                         if (full && g.auxvec) {          // one 8-byte load of the four saved activations
@@ -283,6 +291,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                         const float u = g.aux[arow * g.ldaux + colc];
                         const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u));
                         uv[r] = sg * (1.0f + 1.702f * u * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
+                    } else if (act == 7) {
+                        const long arow = g.rowmap ? (long)g.rowmap[(row + g.row0) / g.rpg] * g.rpg + (row + g.row0) % g.rpg : row;
+                        const float u = g.aux[arow * g.ldaux + colc];
+                        uv[r] = 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
                     } else {
                         uv[r] = __half2float(g.auxh[xb + (long)row * g.ldaux + colc]) > 0.f ? 1.f : 0.f;   // ReLU'
                     }
@@ -1448,9 +1460,10 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
     WC_CHECK_ARG(((uintptr_t)A0 | (uintptr_t)W0 | (uintptr_t)A1 | (uintptr_t)W1 | (uintptr_t)A2 |
                   (uintptr_t)W2) % 16 == 0, "wc_gemm_f16: operands must be 16-byte aligned");
     WC_CHECK_ARG((C32 || C16) && ldc >= N && batch >= 1 && batch <= 65535, "wc_gemm_f16: bad output");
-    WC_CHECK_ARG(act >= 0 && act <= 5, "wc_gemm_f16: act must be 0..5");
+    WC_CHECK_ARG(act >= 0 && act <= 7, "wc_gemm_f16: act must be 0..7");
     WC_CHECK_ARG(act != 5 || (auxh && ldaux >= N), "wc_gemm_f16: act 5 needs auxh, ldaux");
-    WC_CHECK_ARG(act != 4 || (aux && rpg > 0 && ldaux >= N), "wc_gemm_f16: act 4 needs aux, rpg, ldaux");
+    WC_CHECK_ARG((act != 4 && act != 7) || (aux && rpg > 0 && ldaux >= N), "wc_gemm_f16: act 4 / 7 need aux, rpg, ldaux");
+    const bool use_aux = act == 4 || act == 5 || act == 7;      // the epilogue variant that reads a side input
     GemmArgs g;
     g.A[0] = (const __half*)A0; g.A[1] = (const __half*)A1; g.A[2] = (const __half*)A2;
     g.W[0] = (const __half*)W0; g.W[1] = (const __half*)W1; g.W[2] = (const __half*)W2;
@@ -1464,7 +1477,7 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
     // wide epilogue needs every 4-column group of a row 16-B (fp32) / 8-B (fp16) addressable
     g.vec = (ldc % 4 == 0 && sC % 4 == 0 && sC2 % 4 == 0 && (!resid || (ldr % 4 == 0 && sR % 4 == 0 && (uintptr_t)resid % 16 == 0)) &&
              (!C32 || (uintptr_t)C32 % 16 == 0) && (!C16 || (uintptr_t)C16 % 8 == 0) && (!C16lo || (uintptr_t)C16lo % 8 == 0) &&
-             (act != 4 || (ldaux % 4 == 0 && (uintptr_t)aux % 16 == 0)))
+             ((act != 4 && act != 7) || (ldaux % 4 == 0 && (uintptr_t)aux % 16 == 0)))
                 ? 1 : 0;
     g.auxvec = (act == 5 && ldaux % 4 == 0 && sX2 % 4 == 0 && (uintptr_t)auxh % 8 == 0) ? 1 : 0;
     g.gx = wc_cdiv(N, BN);
@@ -1496,18 +1509,18 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
         }
         const int pr = wc_prof_begin(stream);
         if (p192) {
-            if (act >= 4)
+            if (use_aux)
                 hipLaunchKernelGGL(gemm_f16_p192_kernel<true>, gridp, dim3(512), 14 * P192_UNIT, (hipStream_t)stream, g);
             else
                 hipLaunchKernelGGL(gemm_f16_p192_kernel<false>, gridp, dim3(512), 14 * P192_UNIT, (hipStream_t)stream, g);
-            wc_prof_end(pr, act >= 4 ? "gemm_f16_p192_kernel<true>" : "gemm_f16_p192_kernel<false>", 2.0 * g.M * N * K, stream);
+            wc_prof_end(pr, use_aux ? "gemm_f16_p192_kernel<true>" : "gemm_f16_p192_kernel<false>", 2.0 * g.M * N * K, stream);
             WC_LAUNCH_CHECK("gemm_f16_p192_kernel");
         } else {
-            if (act >= 4)
+            if (use_aux)
                 hipLaunchKernelGGL(gemm_f16_pp_kernel<true>, gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
             else
                 hipLaunchKernelGGL(gemm_f16_pp_kernel<false>, gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
-            wc_prof_end(pr, act >= 4 ? "gemm_f16_pp_kernel<true>" : "gemm_f16_pp_kernel<false>", 2.0 * g.M * N * K, stream);
+            wc_prof_end(pr, use_aux ? "gemm_f16_pp_kernel<true>" : "gemm_f16_pp_kernel<false>", 2.0 * g.M * N * K, stream);
             WC_LAUNCH_CHECK("gemm_f16_pp_kernel");
         }
         if (!split) return WC_OK;
@@ -1526,11 +1539,11 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
     static const int skinny_env = getenv("WECLIP_GEMM_SKINNY") ? atoi(getenv("WECLIP_GEMM_SKINNY")) : 1;
     if (skinny_env && M <= 32 && batch == 1 && N >= 256) {      // a few rows against many weight rows
         const int prs = wc_prof_begin(stream);
-        if (act >= 4)
+        if (use_aux)
             hipLaunchKernelGGL(gemm_skinny_kernel<true>, dim3(wc_cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, g);
         else
             hipLaunchKernelGGL(gemm_skinny_kernel<false>, dim3(wc_cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, g);
-        wc_prof_end(prs, act >= 4 ? "gemm_skinny_kernel<true>" : "gemm_skinny_kernel<false>", 2.0 * M * N * K, stream);
+        wc_prof_end(prs, use_aux ? "gemm_skinny_kernel<true>" : "gemm_skinny_kernel<false>", 2.0 * M * N * K, stream);
         WC_LAUNCH_CHECK("gemm_skinny_kernel");
         return WC_OK;
     }
@@ -1551,14 +1564,14 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
     const bool ring = ring_env && (long)g.gx * g.gy * batch <= n_cu128 && K / BK * nseg >= 3;
     const size_t lds = (ring ? 4 : 2) * 2 * BM * BK * 2;
     const int pr = wc_prof_begin(stream);
-    if (act >= 4) {
+    if (use_aux) {
         if (ring) hipLaunchKernelGGL((gemm_f16_kernel<true, 4>), grid, dim3(256), lds, (hipStream_t)stream, g);
         else hipLaunchKernelGGL((gemm_f16_kernel<true, 2>), grid, dim3(256), lds, (hipStream_t)stream, g);
     } else {
         if (ring) hipLaunchKernelGGL((gemm_f16_kernel<false, 4>), grid, dim3(256), lds, (hipStream_t)stream, g);
         else hipLaunchKernelGGL((gemm_f16_kernel<false, 2>), grid, dim3(256), lds, (hipStream_t)stream, g);
     }
-    wc_prof_end(pr, act >= 4 ? (ring ? "gemm_f16_kernel<true, 4>" : "gemm_f16_kernel<true, 2>")
+    wc_prof_end(pr, use_aux ? (ring ? "gemm_f16_kernel<true, 4>" : "gemm_f16_kernel<true, 2>")
                              : (ring ? "gemm_f16_kernel<false, 4>" : "gemm_f16_kernel<false, 2>"), 2.0 * g.M * N * K * batch, stream);
     WC_LAUNCH_CHECK("gemm_f16_kernel");
     return WC_OK;

@@ -24,8 +24,8 @@ struct MsdaShapes {
 };
 
 __global__ __launch_bounds__(1024) void msda_fwd_kernel(const float* __restrict__ value, const float* __restrict__ loc,
-                                const float* __restrict__ attn, float* __restrict__ out, MsdaShapes sh, int S, int Lq,
-                                int M, int D, int P) {
+                                const float* __restrict__ attn, float* __restrict__ out, __half* __restrict__ out16,
+                                MsdaShapes sh, int S, int Lq, int M, int D, int P) {
     const long nq = blockIdx.x;                  // n * Lq + q
     const int n = nq / Lq;
     const int m = threadIdx.x / D, d = threadIdx.x - m * D;
@@ -52,7 +52,8 @@ __global__ __launch_bounds__(1024) void msda_fwd_kernel(const float* __restrict_
             }
         }
     }
-    out[nq * M * D + (long)m * D + d] = acc;
+    if (out) out[nq * M * D + (long)m * D + d] = acc;
+    if (out16) out16[nq * M * D + (long)m * D + d] = __float2half(acc);       // the output projection's MFMA operand
 }
 
 __device__ __forceinline__ float head_sum(float v, int D) {   // sum over the D consecutive lanes of a head
@@ -272,16 +273,25 @@ static int fill_shapes(MsdaShapes* sh, const int* h_shapes, int n_levels, int* S
     return 0;
 }
 
+extern "C" int wc_msda_fwd_h(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
+                             float* out, void* out16, int N, int Lq, int M, int D, int P, void* stream);
+
 extern "C" int wc_msda_fwd(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
                            float* out, int N, int Lq, int M, int D, int P, void* stream) {
+    return wc_msda_fwd_h(value, h_shapes, n_levels, loc, attn, out, nullptr, N, Lq, M, D, P, stream);
+}
+
+// out (f32) and / or out16 (f16): (N, Lq, M*D)
+extern "C" int wc_msda_fwd_h(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
+                             float* out, void* out16, int N, int Lq, int M, int D, int P, void* stream) {
     MsdaShapes sh;
     int S = 0;
-    WC_CHECK_ARG(value && h_shapes && loc && attn && out && N > 0 && Lq > 0 && M > 0 && P > 0, "wc_msda_fwd: bad argument");
+    WC_CHECK_ARG(value && h_shapes && loc && attn && (out || out16) && N > 0 && Lq > 0 && M > 0 && P > 0, "wc_msda_fwd: bad argument");
     WC_CHECK_ARG(fill_shapes(&sh, h_shapes, n_levels, &S) == 0, "wc_msda_fwd: 1..8 levels with positive sizes");
     WC_CHECK_ARG((D == 16 || D == 32 || D == 64) && M * D <= 1024 && (M * D) % 64 == 0,
                  "wc_msda_fwd: head dim 16/32/64, heads*dim a multiple of 64 and <= 1024");
     hipLaunchKernelGGL(msda_fwd_kernel, dim3((unsigned)((long)N * Lq)), dim3(M * D), 0, (hipStream_t)stream, value, loc, attn,
-                       out, sh, S, Lq, M, D, P);
+                       out, (__half*)out16, sh, S, Lq, M, D, P);
     WC_LAUNCH_CHECK("msda_fwd_kernel");
     return WC_OK;
 }

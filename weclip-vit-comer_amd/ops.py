@@ -262,36 +262,46 @@ class WeightCache:
         self.views = {}
 
     def refresh(self, named, exact, force=False, lo_names=()):
-        """named: list of (name, 2-D contiguous fp32 CUDA tensor).  force: convert even if no version counter moved
-        (training: an update through `param.data` does not bump `param._version`).  lo_names: weights that carry their
-        fp16 remainder in the row-major (forward) copy although `exact` is off."""
+        """named: list of (name, 2-D contiguous fp32 CUDA tensor) -- or (name, [tensors]) for matrices of equal width that
+        are STACKED along the rows into one operand (e.g. two Linears that share their input run as one GEMM).
+        force: convert even if no version counter moved (training: an update through `param.data` does not bump
+        `param._version`).  lo_names: weights that carry their fp16 remainder in the row-major (forward) copy although
+        `exact` is off."""
         L.require_gpu()
         lo_names = frozenset(lo_names)
-        key = tuple((n, t.data_ptr(), tuple(t.shape)) for n, t in named) + (bool(exact), lo_names)
+        named = [(n, list(t) if isinstance(t, (list, tuple)) else [t]) for n, t in named]
+        flat = [t for _, ts in named for t in ts]
+        key = tuple((n, tuple((t.data_ptr(), tuple(t.shape)) for t in ts)) for n, ts in named) + (bool(exact), lo_names)
         if key != self.key:
-            dev = named[0][1].device
-            tot = sum(t.numel() for _, t in named)
-            totT = sum(t.shape[1] * ((t.shape[0] + 63) // 64 * 64) for _, t in named)
+            dev = flat[0].device
+            tot = sum(t.numel() for t in flat)
+            totT = sum(ts[0].shape[1] * ((sum(t.shape[0] for t in ts) + 63) // 64 * 64) for _, ts in named)
             self.hi = torch.empty(tot, device=dev, dtype=F16)
             self.lo = torch.empty(tot, device=dev, dtype=F16) if (exact or lo_names) else None
             self.hiT = torch.zeros(totT, device=dev, dtype=F16)          # K padding of the transposed copies stays 0
             self.loT = torch.zeros(totT, device=dev, dtype=F16) if exact else None
             rows, self.views, o, oT = [], {}, 0, 0
-            for n, t in named:
-                R, C = t.shape
+            for n, ts in named:
+                R, C = sum(t.shape[0] for t in ts), ts[0].shape[1]
                 ldT = (R + 63) // 64 * 64
+                has_lo = exact or n in lo_names
                 hi, hiT = self.hi[o:o + R * C].view(R, C), self.hiT[oT:oT + C * ldT].view(C, ldT)
-                lo = self.lo[o:o + R * C].view(R, C) if (exact or n in lo_names) else None
+                lo = self.lo[o:o + R * C].view(R, C) if has_lo else None
                 loT = self.loT[oT:oT + C * ldT].view(C, ldT) if exact else None
-                rows.append([t.data_ptr(), hi.data_ptr(), lo.data_ptr() if lo is not None else 0, hiT.data_ptr(),
-                             loT.data_ptr() if exact else 0, R, C, ldT])
+                r0 = 0
+                for t in ts:            # each source converts into its row block / its column block of the transposed copy
+                    if t.shape[1] != C or (len(ts) > 1 and r0 % 4):
+                        raise RuntimeError("WeightCache: stacked matrices need equal widths and row counts that are multiples of 4")
+                    rows.append([t.data_ptr(), hi.data_ptr() + 2 * r0 * C, (lo.data_ptr() + 2 * r0 * C) if has_lo else 0,
+                                 hiT.data_ptr() + 2 * r0, (loT.data_ptr() + 2 * r0) if exact else 0, t.shape[0], C, ldT])
+                    r0 += t.shape[0]
                 self.views[n] = (Split(hi, lo), Split(hiT, loT), ldT)
                 o += R * C
                 oT += C * ldT
             self.table = torch.tensor(rows, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
             self.count = len(rows)
             self.key, self.versions = key, None
-        versions = tuple(t._version for _, t in named)
+        versions = tuple(t._version for t in flat)
         if force or versions != self.versions:
             L.lib().wc_convert_weights(L.ptr(self.table, torch.int64, "table"), self.count, 32, L.stream())
             self.versions = versions
