@@ -360,13 +360,19 @@ int wc_colscale_split(const float* x, const float* cs, float* out32, void* hi, v
  *              uint32; ws: workspace of N*M*S*2 + N*M*n_levels*Lq*P*4 int32; a level may have at most 16384 pixels. */
 int wc_msda_fwd(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
                 float* out, int N, int Lq, int M, int D, int P, void* stream);
-/* The same with an optional fp16 copy of the output (the MFMA operand of MSDeformAttn's output projection); out or out16
- * may be NULL. */
-int wc_msda_fwd_h(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
-                  float* out, void* out16, int N, int Lq, int M, int D, int P, void* stream);
+/* The same with the value tensor as f32 or f16 (value_is_f16: half the gather traffic; needs D % 4 == 0 and M*D/4 dividing
+ * 256) and an optional fp16 copy of the output (the MFMA operand of MSDeformAttn's output projection); out or out16 may be
+ * NULL. */
+int wc_msda_fwd_h(const void* value, int value_is_f16, const int* h_shapes, int n_levels, const float* loc,
+                  const float* attn, float* out, void* out16, int N, int Lq, int M, int D, int P, void* stream);
 int wc_msda_bwd(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
                 const float* gout, float* gvalue, float* gloc, float* gattn, void* gmax, void* ws, int N, int Lq, int M,
                 int D, int P, void* stream);
+/* The same with value and / or the output gradient gout as f16 (*_is_f16) and the value gradient as f32 (gvalue) and / or
+ * f16 (gvalue16: the operand of the value projection's gradient GEMMs); either of the two may be NULL. */
+int wc_msda_bwd_h(const void* value, int value_is_f16, const int* h_shapes, int n_levels, const float* loc,
+                  const float* attn, const void* gout, int gout_is_f16, float* gvalue, void* gvalue16, float* gloc,
+                  float* gattn, void* gmax, void* ws, int N, int Lq, int M, int D, int P, void* stream);
 
 /* Depth-wise conv2d (stride 1, zero "same" padding k/2, odd k <= 7) of the MRFP block of the ViT-CoMer inserts
  * (nn.Conv2d(C, C, k, padding=k//2, groups=C); no reference code).  x, y, dy, dx: (N, C, H, W) f32;
@@ -416,9 +422,11 @@ int wc_confusion_hist(const long* label_true, const long* label_pred, long* hist
  * one launch.  y (f32, may be NULL) = conv + bias; g16 (f16, may be NULL) = GELU(y) (erf form), the next FC's operand. */
 int wc_mrfp_dwconv_fwd(const float* x, const float* w3, const float* b3, const float* w5, const float* b5, float* y,
                        void* g16, const int* h_shapes, int n_levels, int N, int C, void* stream);
-/* Backward: dx32 / dx16 (either may be NULL) = gradient w.r.t. x; dw3 / db3 / dw5 / db5 = alpha * filter / bias gradients
- * (two-stage fixed-order reduction); part: workspace of N * ceil(S / 128) * C * 26 floats. */
-int wc_mrfp_dwconv_bwd(const float* dy, const float* x, const float* w3, const float* w5, float* dx32, void* dx16,
+/* Backward: dy (f16 if dy_is_f16 else f32); dx32 / dx16 (either may be NULL) = gradient w.r.t. x; dw3 / db3 / dw5 / db5 =
+ * alpha * filter / bias gradients (two-stage fixed-order reduction); part: workspace of n_parts * C * 26 floats with n_parts
+ * from wc_mrfp_dwconv_parts (HOST out-parameter). */
+int wc_mrfp_dwconv_parts(const int* h_shapes, int n_levels, int N, int C, long* n_parts);
+int wc_mrfp_dwconv_bwd(const void* dy, int dy_is_f16, const float* x, const float* w3, const float* w5, float* dx32, void* dx16,
                        float* dw3, float* db3, float* dw5, float* db5, float* part, float alpha, const int* h_shapes,
                        int n_levels, int N, int C, void* stream);
 /* MSDeformAttn's sampling_offsets | attention_weights outputs ow (N*Lq, ld) [M*nL*P*2 offsets, then M*nL*P logits per row]

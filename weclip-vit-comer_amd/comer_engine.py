@@ -91,7 +91,7 @@ class ComerEngine:
         return ops.layernorm(x, self._b(ln.weight), self._b(ln.bias), eps=ln.eps, want32=False, want16=True)[1].hi
 
     def _msda_fwd(self, value, shapes, ow, ld, att, ref, B, Lq):
-        """value (B*S, 256) f32, ow (B*Lq, ld) f32 -> (o16 (B*Lq, 256) f16, loc, attn)."""
+        """value (B*S, 256) f16, ow (B*Lq, ld) f32 -> (o16 (B*Lq, 256) f16, loc, attn)."""
         M, P, nL = att.n_heads, att.n_points, len(shapes)
         D = att.d_model // M
         dev = value.device
@@ -102,23 +102,23 @@ class ComerEngine:
         lib.wc_msda_prep_fwd(L.ptr(ow, F32), L.ptr(self._b(att.sampling_offsets.bias), F32), L.ptr(self._b(att.attention_weights.bias), F32),
                              L.ptr(ref, F32), L.ptr(loc), L.ptr(attn), hs, nL, B, Lq, M, P, ld, 1, L.stream())
         o16 = torch.empty(B * Lq, M * D, device=dev, dtype=F16)
-        lib.wc_msda_fwd_h(L.ptr(value, F32), hs, nL, L.ptr(loc), L.ptr(attn), None, L.ptr(o16), B, Lq, M, D, P, L.stream())
+        lib.wc_msda_fwd_h(L.ptr(value, F16), 1, hs, nL, L.ptr(loc), L.ptr(attn), None, L.ptr(o16), B, Lq, M, D, P, L.stream())
         return o16, loc, attn
 
     def _msda_bwd(self, value, shapes, loc, attn, gout, att, B, Lq, ld):
-        """-> (dvalue (B*S, 256) f32, dow16 (B*Lq, ld) f16 with zeroed padding columns)."""
+        """-> (dvalue16 (B*S, 256) f16, dow16 (B*Lq, ld) f16 with zeroed padding columns)."""
         M, P, nL = att.n_heads, att.n_points, len(shapes)
         D = att.d_model // M
         S = sum(h * w for h, w in shapes)
         dev = value.device
-        gv = torch.empty_like(value)
+        gv = torch.empty(value.shape, device=dev, dtype=F16)          # (value is f16 already)
         gl, ga = torch.empty_like(loc), torch.empty_like(attn)
         gmax = torch.empty(1, device=dev, dtype=torch.int32)
         ws = torch.empty(B * M * (2 * S + nL * Lq * P * 4), device=dev, dtype=torch.int32)
         hs = _shape_array(shapes)
         lib = L.lib()
-        lib.wc_msda_bwd(L.ptr(value, F32), hs, nL, L.ptr(loc), L.ptr(attn), L.ptr(gout, F32, "gout"), L.ptr(gv), L.ptr(gl), L.ptr(ga),
-                        L.ptr(gmax), L.ptr(ws), B, Lq, M, D, P, L.stream())
+        lib.wc_msda_bwd_h(L.ptr(value, F16), 1, hs, nL, L.ptr(loc), L.ptr(attn), L.ptr(gout, F16, "gout"), 1, None, L.ptr(gv), L.ptr(gl),
+                          L.ptr(ga), L.ptr(gmax), L.ptr(ws), B, Lq, M, D, P, L.stream())
         dow16 = torch.empty(B * Lq, ld, device=dev, dtype=F16)
         lib.wc_msda_prep_bwd(L.ptr(gl), L.ptr(ga), L.ptr(attn), None, L.ptr(dow16), hs, nL, B, Lq, M, P, ld, L.stream())
         return gv, dow16
@@ -172,8 +172,8 @@ class ComerEngine:
             # ---- CTI-toV: v1 = v + gamma * out_proj(msda(LN(v) -> offsets / weights, value_proj(LN(c1))))
             q1 = self._ln16(v, t.nv_q)
             f1 = self._ln16(c1, t.nv_f)
-            val1 = torch.empty(Mc, C, device=dev, dtype=F32)
-            ops.gemm(f1, W(f"v{i}.vp"), Mc, C, C, bias=self._b(t.to_v.value_proj.bias), out32=val1)
+            val1 = torch.empty(Mc, C, device=dev, dtype=F16)          # fp16 values: half the gather traffic of the deformable attention
+            ops.gemm(f1, W(f"v{i}.vp"), Mc, C, C, bias=self._b(t.to_v.value_proj.bias), out16=val1)
             n1 = W(f"v{i}.ow").hi.shape[0]
             ld1 = (n1 + 63) // 64 * 64
             ow1 = torch.empty(Mv, ld1, device=dev, dtype=F32)
@@ -186,8 +186,8 @@ class ComerEngine:
             # ---- CTI-toC: c2 = c1 + out_proj(msda(LN(c1), value_proj(LN(v1))))
             q2 = self._ln16(c1, t.nc_q)
             f2 = self._ln16(v1, t.nc_f)
-            val2 = torch.empty(Mv, C, device=dev, dtype=F32)
-            ops.gemm(f2, W(f"c{i}.vp"), Mv, C, C, bias=self._b(t.to_c.value_proj.bias), out32=val2)
+            val2 = torch.empty(Mv, C, device=dev, dtype=F16)
+            ops.gemm(f2, W(f"c{i}.vp"), Mv, C, C, bias=self._b(t.to_c.value_proj.bias), out16=val2)
             n2 = W(f"c{i}.ow").hi.shape[0]
             ld2 = (n2 + 63) // 64 * 64
             ow2 = torch.empty(Mc, ld2, device=dev, dtype=F32)
@@ -253,10 +253,11 @@ class ComerEngine:
             self._pending = None
         return out
 
-    def _ln_bwd(self, dy, x, ln, add, grads):
-        dx, _, dgb = ops.layernorm_bwd(dy, x, self._b(ln.weight), add=add, want32=True, alpha=INV, eps=ln.eps)
+    def _ln_bwd(self, dy, x, ln, add, grads, want16=False):
+        """dx = LN_bwd(dy) + add (f32) [and its f16 copy: the next GEMMs' operand, no separate conversion pass]."""
+        dx, dx16, dgb = ops.layernorm_bwd(dy, x, self._b(ln.weight), add=add, want32=True, want16=want16, alpha=INV, eps=ln.eps)
         grads[id(ln.weight)], grads[id(ln.bias)] = dgb[0], dgb[1]
-        return dx
+        return (dx, dx16) if want16 else dx
 
     def _backward(self, ctx, dy):
         net = self.net
@@ -296,53 +297,50 @@ class ComerEngine:
             dn3 = torch.empty(Mc, C, device=dev, dtype=F32)
             ops.gemm(du16, WT(f"f{i}.0"), Mc, C, C, out32=dn3)
             self._wgrad(du16, s["n3"], Mc, C, C, grads, t.ffn[0].weight, t.ffn[0].bias)
-            dc2 = self._ln_bwd(dn3, s["c2"], t.ffn_norm, dc3, grads)
+            dc2, dc2_16 = self._ln_bwd(dn3, s["c2"], t.ffn_norm, dc3, grads, want16=True)
             # ---- CTI-toC
-            dc2_16 = self._f16(dc2)
-            do2 = torch.empty(Mc, C, device=dev, dtype=F32)
-            ops.gemm(dc2_16, WT(f"c{i}.op"), Mc, C, C, out32=do2)
+            do2 = torch.empty(Mc, C, device=dev, dtype=F16)
+            ops.gemm(dc2_16, WT(f"c{i}.op"), Mc, C, C, out16=do2)
             self._wgrad(dc2_16, s["o2"], Mc, C, C, grads, t.to_c.output_proj.weight, t.to_c.output_proj.bias)
-            dval2, dow2 = self._msda_bwd(s["val2"], [(h, w)], s["loc2"], s["at2"], do2, t.to_c, B, S, s["ld2"])
+            dval2_16, dow2 = self._msda_bwd(s["val2"], [(h, w)], s["loc2"], s["at2"], do2, t.to_c, B, S, s["ld2"])
             dq2 = torch.empty(Mc, C, device=dev, dtype=F32)
             ops.gemm(dow2, WT(f"c{i}.ow"), Mc, C, s["ld2"], out32=dq2)
             self._ow_grads(dow2, s["q2"], Mc, s["n2"], s["ld2"], t.to_c, grads)
             dc1 = self._ln_bwd(dq2, s["c1"], t.nc_q, dc2, grads)
-            dval2_16 = self._f16(dval2)
             df2 = torch.empty(Mv, C, device=dev, dtype=F32)
             ops.gemm(dval2_16, WT(f"c{i}.vp"), Mv, C, C, out32=df2)
             self._wgrad(dval2_16, s["f2"], Mv, C, C, grads, t.to_c.value_proj.weight, t.to_c.value_proj.bias)
-            dv1 = self._ln_bwd(df2, s["v1"], t.nc_f, pieces[2 * i], grads)
+            dv1, dv1_16 = self._ln_bwd(df2, s["v1"], t.nc_f, pieces[2 * i], grads, want16=True)
             # ---- CTI-toV: v1 = v + gamma * (o1 Wop^T + bop)
             gam = self._b(t.gamma)
             gdv1_16 = self._f16(dv1, cs=gam.view(1, C))
-            do1 = torch.empty(Mv, C, device=dev, dtype=F32)
-            ops.gemm(gdv1_16, WT(f"v{i}.op"), Mv, C, C, out32=do1)
-            dv1_16 = self._f16(dv1)
+            do1 = torch.empty(Mv, C, device=dev, dtype=F16)
+            ops.gemm(gdv1_16, WT(f"v{i}.op"), Mv, C, C, out16=do1)
             G, gsum = self._wgrad(dv1_16, s["o1"], Mv, C, C, grads, None, None)          # G = dv1^T o1, gsum = dv1^T 1 (unscaled)
             self._gamma_jobs.append((t, G, gsum))
-            dval1, dow1 = self._msda_bwd(s["val1"], shapes, s["loc1"], s["at1"], do1, t.to_v, B, nhw, s["ld1"])
+            dval1_16, dow1 = self._msda_bwd(s["val1"], shapes, s["loc1"], s["at1"], do1, t.to_v, B, nhw, s["ld1"])
             dq1 = torch.empty(Mv, C, device=dev, dtype=F32)
             ops.gemm(dow1, WT(f"v{i}.ow"), Mv, C, s["ld1"], out32=dq1)
             self._ow_grads(dow1, s["q1"], Mv, s["n1"], s["ld1"], t.to_v, grads)
             dvs[i] = self._ln_bwd(dq1, s["v"], t.nv_q, dv1, grads)
-            dval1_16 = self._f16(dval1)
             df1 = torch.empty(Mc, C, device=dev, dtype=F32)
             ops.gemm(dval1_16, WT(f"v{i}.vp"), Mc, C, C, out32=df1)
             self._wgrad(dval1_16, s["f1"], Mc, C, C, grads, t.to_v.value_proj.weight, t.to_v.value_proj.bias)
-            dc1 = self._ln_bwd(df1, s["c1"], t.nv_f, dc1, grads)
+            dc1, dc1_16 = self._ln_bwd(df1, s["c1"], t.nv_f, dc1, grads, want16=True)
             # ---- MRFP
-            dc1_16 = self._f16(dc1)
-            dx2 = torch.empty(Mc, hid, device=dev, dtype=F32)
-            ops.gemm(dc1_16, WT(f"m{i}.fc2"), Mc, hid, C, out32=dx2, act=7, aux=s["x2"], ldaux=hid, rpg=1)
+            dx2 = torch.empty(Mc, hid, device=dev, dtype=F16)          # fp16 out: the epilogue's wide (row-major) path
+            ops.gemm(dc1_16, WT(f"m{i}.fc2"), Mc, hid, C, out16=dx2, act=7, aux=s["x2"], ldaux=hid, rpg=1)
             self._wgrad(dc1_16, s["g16"], Mc, C, hid, grads, m.fc2.weight, m.fc2.bias)
             dx1_16 = torch.empty(Mc, hid, device=dev, dtype=F16)
             half = hid // 2
             dw3, db3 = torch.empty(half, 9, device=dev, dtype=F32), torch.empty(half, device=dev, dtype=F32)
             dw5, db5 = torch.empty(half, 25, device=dev, dtype=F32), torch.empty(half, device=dev, dtype=F32)
-            part = torch.empty(B * ((S + 127) // 128) * hid * 26, device=dev, dtype=F32)
-            lib.wc_mrfp_dwconv_bwd(L.ptr(dx2), L.ptr(s["x1"]), L.ptr(self._b(m.dw3.weight).view(-1), F32), L.ptr(self._b(m.dw5.weight).view(-1), F32),
-                                   None, L.ptr(dx1_16), L.ptr(dw3), L.ptr(db3), L.ptr(dw5), L.ptr(db5), L.ptr(part), INV, hs3,
-                                   len(shapes), B, hid, L.stream())
+            npart = ctypes.c_long(0)
+            lib.wc_mrfp_dwconv_parts(hs3, len(shapes), B, hid, ctypes.byref(npart))
+            part = torch.empty(npart.value * hid * 26, device=dev, dtype=F32)
+            lib.wc_mrfp_dwconv_bwd(L.ptr(dx2), 1, L.ptr(s["x1"]), L.ptr(self._b(m.dw3.weight).view(-1), F32),
+                                   L.ptr(self._b(m.dw5.weight).view(-1), F32), None, L.ptr(dx1_16), L.ptr(dw3), L.ptr(db3), L.ptr(dw5),
+                                   L.ptr(db5), L.ptr(part), INV, hs3, len(shapes), B, hid, L.stream())
             grads[id(m.dw3.weight)], grads[id(m.dw3.bias)] = dw3.view(m.dw3.weight.shape), db3
             grads[id(m.dw5.weight)], grads[id(m.dw5.bias)] = dw5.view(m.dw5.weight.shape), db5
             dc = torch.empty(Mc, C, device=dev, dtype=F32)

@@ -15,101 +15,161 @@
 struct CmLevels {
     int n;
     int H[CM_MAX_LEVELS], W[CM_MAX_LEVELS], start[CM_MAX_LEVELS];
+    int sstart[CM_MAX_LEVELS], nstrips;      // horizontal strips of 8 pixels (depth-wise conv kernels): first strip per level, total
 };
 
 __device__ __forceinline__ float cm_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
+// Depth-wise kernels: a thread owns one channel of a horizontal STRIP of CM_SW consecutive pixels of one map row, so a row
+// segment of CM_SW + k - 1 inputs loaded once serves all k taps of the strip's pixels (3.75 / 7.5 loads per output for the
+// 3x3 / 5x5 filters instead of 9 / 25); consecutive lanes are consecutive channels (coalesced NHWC rows), and the channel
+// halves (3x3 | 5x5) fall on whole waves (C/2 a multiple of 64) or the branch is per lane (C = 64).
+#define CM_SW 8
+
+__device__ __forceinline__ void cm_strip(const CmLevels& lv, int t, int& l, int& py, int& x0) {
+    l = 0;
+    while (l + 1 < lv.n && t >= lv.sstart[l + 1]) ++l;
+    const int local = t - lv.sstart[l], spr = (lv.W[l] + CM_SW - 1) / CM_SW;
+    py = local / spr;
+    x0 = (local - py * spr) * CM_SW;
+}
+
+__device__ __forceinline__ float cm_ld(const float* p) { return *p; }
+__device__ __forceinline__ float cm_ld(const __half* p) { return __half2float(*p); }
+
+// out[o] += sum_{dy,dx} w[(dy+R)*K + dx+R] * in(py+dy, x0+o+dx)   (FLIP: w index mirrored = transposed convolution)
+template <int K, bool FLIP, typename T>
+__device__ __forceinline__ void cm_conv_strip(const T* __restrict__ xb, const float* __restrict__ wc, int H, int W, int C, int py,
+                                              int x0, float (&out)[CM_SW]) {
+    constexpr int R = K / 2;
+    float wr[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) wr[i] = wc[FLIP ? K * K - 1 - i : i];
+#pragma unroll
+    for (int dy = -R; dy <= R; ++dy) {
+        const int yy = py + dy;
+        if (yy < 0 || yy >= H) continue;
+        float xs[CM_SW + K - 1];
+#pragma unroll
+        for (int j = 0; j < CM_SW + K - 1; ++j) {
+            const int xx = x0 + j - R;
+            xs[j] = (xx >= 0 && xx < W) ? cm_ld(xb + ((long)yy * W + xx) * C) : 0.f;
+        }
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx)
+#pragma unroll
+            for (int o = 0; o < CM_SW; ++o) out[o] = fmaf(wr[(dy + R) * K + dx], xs[o + dx], out[o]);
+    }
+}
+
 // x (N, S, C) f32 rows; w3 (C/2, 9), b3 (C/2), w5 (C/2, 25), b5 (C/2).  y = conv + bias (f32, optional), g16 = gelu(y) (f16).
-// thread = (pixel, channel); a workgroup = 256 / C pixels x C channels (C = 64, 128 or 256).
+// grid (ceil(nstrips / (256 / C)), N); thread = (strip lane, channel)
 __global__ __launch_bounds__(256) void mrfp_dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w3,
                                                                const float* __restrict__ b3, const float* __restrict__ w5,
                                                                const float* __restrict__ b5, float* __restrict__ y,
                                                                __half* __restrict__ g16, CmLevels lv, int S, int C) {
-    const int c = threadIdx.x % C, s = blockIdx.x * (256 / C) + threadIdx.x / C, n = blockIdx.y;
-    if (s >= S) return;
-    int l = 0;
-    while (l + 1 < lv.n && s >= lv.start[l + 1]) ++l;
-    const int H = lv.H[l], W = lv.W[l], p = s - lv.start[l], py = p / W, px = p - py * W;
-    const int half = C >> 1, big = c >= half, k = big ? 5 : 3, r = k >> 1;
-    const float* wc = big ? w5 + (long)(c - half) * 25 : w3 + (long)c * 9;
-    float acc = big ? b5[c - half] : b3[c];
+    const int c = threadIdx.x % C, t = blockIdx.x * (256 / C) + threadIdx.x / C, n = blockIdx.y;
+    if (t >= lv.nstrips) return;
+    int l, py, x0;
+    cm_strip(lv, t, l, py, x0);
+    const int H = lv.H[l], W = lv.W[l], half = C >> 1, big = c >= half;
     const float* xb = x + ((long)n * S + lv.start[l]) * C + c;
-    for (int dy = -r; dy <= r; ++dy) {
-        const int yy = py + dy;
-        if (yy < 0 || yy >= H) continue;
-        for (int dx = -r; dx <= r; ++dx) {
-            const int xx = px + dx;
-            if (xx < 0 || xx >= W) continue;
-            acc = fmaf(wc[(dy + r) * k + dx + r], xb[((long)yy * W + xx) * C], acc);
-        }
+    float out[CM_SW];
+    const float bias = big ? b5[c - half] : b3[c];
+#pragma unroll
+    for (int o = 0; o < CM_SW; ++o) out[o] = bias;
+    if (big) cm_conv_strip<5, false>(xb, w5 + (long)(c - half) * 25, H, W, C, py, x0, out);
+    else cm_conv_strip<3, false>(xb, w3 + (long)c * 9, H, W, C, py, x0, out);
+    const long o0 = ((long)n * S + lv.start[l] + (long)py * W + x0) * C + c;
+#pragma unroll
+    for (int o = 0; o < CM_SW; ++o) {
+        if (x0 + o >= W) break;
+        if (y) y[o0 + (long)o * C] = out[o];
+        if (g16) g16[o0 + (long)o * C] = __float2half(cm_gelu(out[o]));
     }
-    const long o = ((long)n * S + s) * C + c;
-    if (y) y[o] = acc;
-    if (g16) g16[o] = __float2half(cm_gelu(acc));
 }
 
-// dx (N, S, C) = conv^T(dy): dx[p] = sum_taps w[tap] * dy[p - tap]; written as f32 and / or f16
-__global__ __launch_bounds__(256) void mrfp_dwconv_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w3,
+// dx (N, S, C) = conv^T(dy): dx[p] = sum_taps w[tap] * dy[p - tap]; dy f16 or f32; written as f32 and / or f16
+template <typename T>
+__global__ __launch_bounds__(256) void mrfp_dwconv_bwd_data_kernel(const T* __restrict__ dy, const float* __restrict__ w3,
                                                                     const float* __restrict__ w5, float* __restrict__ dx32,
                                                                     __half* __restrict__ dx16, CmLevels lv, int S, int C) {
-    const int c = threadIdx.x % C, s = blockIdx.x * (256 / C) + threadIdx.x / C, n = blockIdx.y;
-    if (s >= S) return;
-    int l = 0;
-    while (l + 1 < lv.n && s >= lv.start[l + 1]) ++l;
-    const int H = lv.H[l], W = lv.W[l], p = s - lv.start[l], py = p / W, px = p - py * W;
-    const int half = C >> 1, big = c >= half, k = big ? 5 : 3, r = k >> 1;
-    const float* wc = big ? w5 + (long)(c - half) * 25 : w3 + (long)c * 9;
-    float acc = 0.f;
-    const float* db = dy + ((long)n * S + lv.start[l]) * C + c;
-    for (int dyy = -r; dyy <= r; ++dyy) {
-        const int yy = py - dyy;                      // output pixel that read this input pixel through tap (dyy, dxx)
-        if (yy < 0 || yy >= H) continue;
-        for (int dxx = -r; dxx <= r; ++dxx) {
-            const int xx = px - dxx;
-            if (xx < 0 || xx >= W) continue;
-            acc = fmaf(wc[(dyy + r) * k + dxx + r], db[((long)yy * W + xx) * C], acc);
-        }
+    const int c = threadIdx.x % C, t = blockIdx.x * (256 / C) + threadIdx.x / C, n = blockIdx.y;
+    if (t >= lv.nstrips) return;
+    int l, py, x0;
+    cm_strip(lv, t, l, py, x0);
+    const int H = lv.H[l], W = lv.W[l], half = C >> 1, big = c >= half;
+    const T* db = dy + ((long)n * S + lv.start[l]) * C + c;
+    float out[CM_SW];
+#pragma unroll
+    for (int o = 0; o < CM_SW; ++o) out[o] = 0.f;
+    if (big) cm_conv_strip<5, true>(db, w5 + (long)(c - half) * 25, H, W, C, py, x0, out);
+    else cm_conv_strip<3, true>(db, w3 + (long)c * 9, H, W, C, py, x0, out);
+    const long o0 = ((long)n * S + lv.start[l] + (long)py * W + x0) * C + c;
+#pragma unroll
+    for (int o = 0; o < CM_SW; ++o) {
+        if (x0 + o >= W) break;
+        if (dx32) dx32[o0 + (long)o * C] = out[o];
+        if (dx16) dx16[o0 + (long)o * C] = __float2half(out[o]);
     }
-    const long o = ((long)n * S + s) * C + c;
-    if (dx32) dx32[o] = acc;
-    if (dx16) dx16[o] = __float2half(acc);
 }
 
-// filter / bias gradients, stage 1: workgroup (chunk of CM_WCH pixels, image) -> part[(n * nchunk + chunk)][c][26]
-// (taps 0..24 [3x3 filters use 0..8] and the bias sum at 25).  256 threads = 256 / C pixel lanes x C channels; the pixel
-// lanes are combined through LDS in a fixed order.
-#define CM_WCH 128
-__global__ __launch_bounds__(256) void mrfp_dwconv_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// acc[(dy+R)*K + dx+R] += sum_o g[o] * x(py+dy, x0+o+dx)
+template <int K, typename T>
+__device__ __forceinline__ void cm_wgrad_strip(const float* __restrict__ xb, const T* __restrict__ gb, int H, int W, int C, int py,
+                                               int x0, float (&acc)[26]) {
+    constexpr int R = K / 2;
+    float g[CM_SW];
+#pragma unroll
+    for (int o = 0; o < CM_SW; ++o) {
+        g[o] = (x0 + o < W) ? cm_ld(gb + ((long)py * W + x0 + o) * C) : 0.f;
+        acc[25] += g[o];
+    }
+#pragma unroll
+    for (int dy = -R; dy <= R; ++dy) {
+        const int yy = py + dy;
+        if (yy < 0 || yy >= H) continue;
+        float xs[CM_SW + K - 1];
+#pragma unroll
+        for (int j = 0; j < CM_SW + K - 1; ++j) {
+            const int xx = x0 + j - R;
+            xs[j] = (xx >= 0 && xx < W) ? xb[((long)yy * W + xx) * C] : 0.f;
+        }
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) {
+            float sum = 0.f;
+#pragma unroll
+            for (int o = 0; o < CM_SW; ++o) sum = fmaf(g[o], xs[o + dx], sum);
+            acc[(dy + R) * K + dx] += sum;
+        }
+    }
+}
+
+// filter / bias gradients, stage 1: workgroup (chunk of CM_WST strips per strip lane, image) -> part[(n * nchunk + chunk)][c][26]
+// (taps 0..24 [3x3 filters use 0..8] and the bias sum at 25).  256 threads = 256 / C strip lanes x C channels; the lanes are
+// combined through LDS in a fixed order.
+#define CM_WST 8
+template <typename T>
+__global__ __launch_bounds__(256) void mrfp_dwconv_bwd_w_kernel(const T* __restrict__ dy, const float* __restrict__ x,
                                                                  float* __restrict__ part, CmLevels lv, int S, int C) {
     __shared__ float red[256 * 26];
     const int c = threadIdx.x % C, pl = threadIdx.x / C, npl = 256 / C, n = blockIdx.y;
-    const int half = C >> 1, big = c >= half, k = big ? 5 : 3, r = k >> 1;
+    const int half = C >> 1, big = c >= half;
     float acc[26];
 #pragma unroll
     for (int t = 0; t < 26; ++t) acc[t] = 0.f;
-    const int s0 = blockIdx.x * CM_WCH;
-    for (int s = s0 + pl; s < s0 + CM_WCH && s < S; s += npl) {
-        int l = 0;
-        while (l + 1 < lv.n && s >= lv.start[l + 1]) ++l;
-        const int H = lv.H[l], W = lv.W[l], p = s - lv.start[l], py = p / W, px = p - py * W;
-        const float g = dy[((long)n * S + s) * C + c];
+    const int t0 = blockIdx.x * (CM_WST * npl);
+    for (int i = 0; i < CM_WST; ++i) {
+        const int t = t0 + i * npl + pl;
+        if (t >= lv.nstrips) break;
+        int l, py, x0;
+        cm_strip(lv, t, l, py, x0);
+        const int H = lv.H[l], W = lv.W[l];
         const float* xb = x + ((long)n * S + lv.start[l]) * C + c;
-        acc[25] += g;
-        if (big) {
-#pragma unroll
-            for (int t = 0; t < 25; ++t) {
-                const int yy = py + t / 5 - 2, xx = px + t % 5 - 2;
-                if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc[t] = fmaf(g, xb[((long)yy * W + xx) * C], acc[t]);
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
-                if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc[t] = fmaf(g, xb[((long)yy * W + xx) * C], acc[t]);
-            }
-        }
+        const T* gb = dy + ((long)n * S + lv.start[l]) * C + c;
+        if (big) cm_wgrad_strip<5>(xb, gb, H, W, C, py, x0, acc);
+        else cm_wgrad_strip<3>(xb, gb, H, W, C, py, x0, acc);
     }
-    (void)k; (void)r;
 #pragma unroll
     for (int t = 0; t < 26; ++t) red[t * 256 + threadIdx.x] = acc[t];
     __syncthreads();
@@ -246,6 +306,12 @@ static int cm_fill_levels(CmLevels* lv, const int* h_shapes, int n_levels, int* 
         s += lv->H[l] * lv->W[l];
     }
     *S = s;
+    int t = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        lv->sstart[l] = t;
+        t += lv->H[l] * ((lv->W[l] + 7) / 8);
+    }
+    lv->nstrips = t;
     return 0;
 }
 
@@ -256,29 +322,44 @@ extern "C" int wc_mrfp_dwconv_fwd(const float* x, const float* w3, const float* 
     WC_CHECK_ARG(x && w3 && b3 && w5 && b5 && (y || g16) && N > 0 && N <= 65535 && (C == 64 || C == 128 || C == 256),
                  "wc_mrfp_dwconv_fwd: bad argument (C = 64, 128 or 256)");
     WC_CHECK_ARG(cm_fill_levels(&lv, h_shapes, n_levels, &S) == 0, "wc_mrfp_dwconv_fwd: 1..8 levels with positive sizes");
-    hipLaunchKernelGGL(mrfp_dwconv_fwd_kernel, dim3(wc_cdiv(S, 256 / C), N), dim3(256), 0, (hipStream_t)stream, x, w3, b3, w5, b5, y,
-                       (__half*)g16, lv, S, C);
+    hipLaunchKernelGGL(mrfp_dwconv_fwd_kernel, dim3(wc_cdiv(lv.nstrips, 256 / C), N), dim3(256), 0, (hipStream_t)stream, x, w3, b3,
+                       w5, b5, y, (__half*)g16, lv, S, C);
     WC_LAUNCH_CHECK("mrfp_dwconv_fwd_kernel");
     return WC_OK;
 }
 
-/* dx32 / dx16 (either may be null): gradient w.r.t. x; dw3 / db3 / dw5 / db5 = alpha * filter / bias gradients;
- * part: workspace of N * ceil(S / 128) * C * 26 floats. */
-extern "C" int wc_mrfp_dwconv_bwd(const float* dy, const float* x, const float* w3, const float* w5, float* dx32, void* dx16,
-                                  float* dw3, float* db3, float* dw5, float* db5, float* part, float alpha, const int* h_shapes,
-                                  int n_levels, int N, int C, void* stream) {
+/* dy: f16 (dy_is_f16) or f32.  dx32 / dx16 (either may be null): gradient w.r.t. x; dw3 / db3 / dw5 / db5 = alpha * filter /
+ * bias gradients; part: workspace of wc_mrfp_dwconv_parts(...) * C * 26 floats. */
+static int cm_wparts(const CmLevels& lv, int C) { return wc_cdiv(lv.nstrips, CM_WST * (256 / C)); }
+
+extern "C" int wc_mrfp_dwconv_parts(const int* h_shapes, int n_levels, int N, int C, long* n_parts) {
+    CmLevels lv;
+    int S = 0;
+    WC_CHECK_ARG(n_parts && N > 0 && (C == 64 || C == 128 || C == 256) && cm_fill_levels(&lv, h_shapes, n_levels, &S) == 0,
+                 "wc_mrfp_dwconv_parts: bad argument");
+    *n_parts = (long)N * cm_wparts(lv, C);
+    return WC_OK;
+}
+
+extern "C" int wc_mrfp_dwconv_bwd(const void* dy, int dy_is_f16, const float* x, const float* w3, const float* w5, float* dx32,
+                                  void* dx16, float* dw3, float* db3, float* dw5, float* db5, float* part, float alpha,
+                                  const int* h_shapes, int n_levels, int N, int C, void* stream) {
     CmLevels lv;
     int S = 0;
     WC_CHECK_ARG(dy && x && w3 && w5 && (dx32 || dx16) && dw3 && db3 && dw5 && db5 && part && N > 0 && N <= 65535 &&
                  (C == 64 || C == 128 || C == 256), "wc_mrfp_dwconv_bwd: bad argument");
     WC_CHECK_ARG(cm_fill_levels(&lv, h_shapes, n_levels, &S) == 0, "wc_mrfp_dwconv_bwd: 1..8 levels with positive sizes");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(mrfp_dwconv_bwd_data_kernel, dim3(wc_cdiv(S, 256 / C), N), dim3(256), 0, st, dy, w3, w5, dx32, (__half*)dx16,
-                       lv, S, C);
-    WC_LAUNCH_CHECK("mrfp_dwconv_bwd_data_kernel");
-    const int nchunk = wc_cdiv(S, CM_WCH);
-    hipLaunchKernelGGL(mrfp_dwconv_bwd_w_kernel, dim3(nchunk, N), dim3(256), 0, st, dy, x, part, lv, S, C);
-    WC_LAUNCH_CHECK("mrfp_dwconv_bwd_w_kernel");
+    const dim3 gd(wc_cdiv(lv.nstrips, 256 / C), N);
+    const int nchunk = cm_wparts(lv, C);
+    if (dy_is_f16) {
+        hipLaunchKernelGGL(mrfp_dwconv_bwd_data_kernel<__half>, gd, dim3(256), 0, st, (const __half*)dy, w3, w5, dx32, (__half*)dx16, lv, S, C);
+        hipLaunchKernelGGL(mrfp_dwconv_bwd_w_kernel<__half>, dim3(nchunk, N), dim3(256), 0, st, (const __half*)dy, x, part, lv, S, C);
+    } else {
+        hipLaunchKernelGGL(mrfp_dwconv_bwd_data_kernel<float>, gd, dim3(256), 0, st, (const float*)dy, w3, w5, dx32, (__half*)dx16, lv, S, C);
+        hipLaunchKernelGGL(mrfp_dwconv_bwd_w_kernel<float>, dim3(nchunk, N), dim3(256), 0, st, (const float*)dy, x, part, lv, S, C);
+    }
+    WC_LAUNCH_CHECK("mrfp_dwconv_bwd kernels");
     hipLaunchKernelGGL(mrfp_dwconv_bwd_w_final_kernel, dim3(wc_cdiv(C * 26, 256)), dim3(256), 0, st, part, dw3, db3, dw5, db5,
                        N * nchunk, C, alpha);
     WC_LAUNCH_CHECK("mrfp_dwconv_bwd_w_final_kernel");

@@ -115,10 +115,122 @@ __global__ __launch_bounds__(1024) void msda_bwd_kernel(const float* __restrict_
     }
 }
 
+// ---- channel-quad forms (round 3): thread = (query, head, 4 consecutive channels).  A corner is then ONE 16-byte load per
+// lane and D/4 lanes cover a head's D channels (a 128-byte line for D = 32), four queries share a 256-thread workgroup
+// (M*D/4 = 64 lanes per query), and the per-sample reductions of the location / weight gradients run over D/4 lanes (3
+// shuffle steps for D = 32) instead of D.  The one-thread-per-channel kernels above issued four times the instructions for
+// the same bytes (forward 237 -> see profiles/r03_comer_*; they remain for D % 4 != 0).
+__device__ __forceinline__ float4 msda_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 msda_ld4(const __half* p) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const h4 v = *reinterpret_cast<const h4*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+
+// VT: value as f32 or f16 (f16 halves the gather traffic that bounds these kernels: 4 corners x nL*P samples per query and head)
+template <typename VT>
+__global__ __launch_bounds__(256) void msda_fwd4_kernel(const VT* __restrict__ value, const float* __restrict__ loc,
+                                const float* __restrict__ attn, float* __restrict__ out, __half* __restrict__ out16,
+                                MsdaShapes sh, int S, long NQ, int Lq, int M, int D, int P) {
+    const int tpq = (M * D) >> 2, j = threadIdx.x % tpq;
+    const long nq = (long)blockIdx.x * (256 / tpq) + threadIdx.x / tpq;
+    if (nq >= NQ) return;
+    const int n = (int)(nq / Lq), dq = D >> 2, m = j / dq, d4 = (j - m * dq) * 4;
+    const VT* vb = value + (long)n * S * M * D + (long)m * D + d4;
+    const float* lb = loc + ((nq * M + m) * sh.n_levels) * P * 2;
+    const float* ab = attn + ((nq * M + m) * sh.n_levels) * P;
+    const long MD = (long)M * D;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = 0; l < sh.n_levels; ++l) {
+        const int H = sh.H[l], W = sh.W[l];
+        const VT* vl = vb + (long)sh.start[l] * MD;
+#pragma unroll 4
+        for (int p = 0; p < P; ++p) {
+            const float x = lb[(l * P + p) * 2] * W - 0.5f, y = lb[(l * P + p) * 2 + 1] * H - 0.5f;
+            const float w = ab[l * P + p];
+            if (y > -1.f && x > -1.f && y < H && x < W) {
+                const int y0 = (int)floorf(y), x0 = (int)floorf(x);
+                const float ly = y - y0, lx = x - x0, hy = 1.f - ly, hx = 1.f - lx;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 v00 = (y0 >= 0 && x0 >= 0) ? msda_ld4(vl + ((long)y0 * W + x0) * MD) : z;
+                const float4 v01 = (y0 >= 0 && x0 + 1 < W) ? msda_ld4(vl + ((long)y0 * W + x0 + 1) * MD) : z;
+                const float4 v10 = (y0 + 1 < H && x0 >= 0) ? msda_ld4(vl + ((long)(y0 + 1) * W + x0) * MD) : z;
+                const float4 v11 = (y0 + 1 < H && x0 + 1 < W) ? msda_ld4(vl + ((long)(y0 + 1) * W + x0 + 1) * MD) : z;
+                const float w00 = w * hy * hx, w01 = w * hy * lx, w10 = w * ly * hx, w11 = w * ly * lx;
+                acc.x += w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x;
+                acc.y += w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y;
+                acc.z += w00 * v00.z + w01 * v01.z + w10 * v10.z + w11 * v11.z;
+                acc.w += w00 * v00.w + w01 * v01.w + w10 * v10.w + w11 * v11.w;
+            }
+        }
+    }
+    const long o = nq * MD + (long)m * D + d4;
+    if (out) *reinterpret_cast<float4*>(out + o) = acc;
+    if (out16) {
+        __half h[4] = {__float2half(acc.x), __float2half(acc.y), __float2half(acc.z), __float2half(acc.w)};
+        *reinterpret_cast<uint2*>(out16 + o) = *reinterpret_cast<const uint2*>(h);
+    }
+}
+
+template <typename VT, typename GT>
+__global__ __launch_bounds__(256) void msda_bwd4_kernel(const VT* __restrict__ value, const float* __restrict__ loc,
+                                const float* __restrict__ attn, const GT* __restrict__ gout,
+                                float* __restrict__ gloc, float* __restrict__ gattn,
+                                MsdaShapes sh, int S, long NQ, int Lq, int M, int D, int P) {
+    const int tpq = (M * D) >> 2, j = threadIdx.x % tpq;
+    const long nq = (long)blockIdx.x * (256 / tpq) + threadIdx.x / tpq;
+    if (nq >= NQ) return;                           // (whole groups of D/4 lanes leave together: the shuffles below stay inside one)
+    const int n = (int)(nq / Lq), dq = D >> 2, m = j / dq, d4 = (j - m * dq) * 4;
+    const long MD = (long)M * D;
+    const VT* vb = value + (long)n * S * MD + (long)m * D + d4;
+    const float* lb = loc + ((nq * M + m) * sh.n_levels) * P * 2;
+    const float* ab = attn + ((nq * M + m) * sh.n_levels) * P;
+    const float4 go = msda_ld4(gout + nq * MD + (long)m * D + d4);
+    for (int l = 0; l < sh.n_levels; ++l) {
+        const int H = sh.H[l], W = sh.W[l];
+        const VT* vl = vb + (long)sh.start[l] * MD;
+#pragma unroll 4
+        for (int p = 0; p < P; ++p) {
+            const float x = lb[(l * P + p) * 2] * W - 0.5f, y = lb[(l * P + p) * 2 + 1] * H - 0.5f;
+            const float w = ab[l * P + p];
+            float gx = 0.f, gy = 0.f, ga = 0.f;
+            if (y > -1.f && x > -1.f && y < H && x < W) {
+                const int y0 = (int)floorf(y), x0 = (int)floorf(x);
+                const float ly = y - y0, lx = x - x0, hy = 1.f - ly, hx = 1.f - lx;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 v00 = (y0 >= 0 && x0 >= 0) ? msda_ld4(vl + ((long)y0 * W + x0) * MD) : z;
+                const float4 v01 = (y0 >= 0 && x0 + 1 < W) ? msda_ld4(vl + ((long)y0 * W + x0 + 1) * MD) : z;
+                const float4 v10 = (y0 + 1 < H && x0 >= 0) ? msda_ld4(vl + ((long)(y0 + 1) * W + x0) * MD) : z;
+                const float4 v11 = (y0 + 1 < H && x0 + 1 < W) ? msda_ld4(vl + ((long)(y0 + 1) * W + x0 + 1) * MD) : z;
+                // per channel: bilinear value, d/dx, d/dy; dotted with the output gradient of the lane's 4 channels
+                const float b0 = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+                const float b1 = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+                const float b2 = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+                const float b3 = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+                ga = go.x * b0 + go.y * b1 + go.z * b2 + go.w * b3;
+                const float dx0 = hy * (v01.x - v00.x) + ly * (v11.x - v10.x), dx1 = hy * (v01.y - v00.y) + ly * (v11.y - v10.y);
+                const float dx2 = hy * (v01.z - v00.z) + ly * (v11.z - v10.z), dx3 = hy * (v01.w - v00.w) + ly * (v11.w - v10.w);
+                const float dy0 = hx * (v10.x - v00.x) + lx * (v11.x - v01.x), dy1 = hx * (v10.y - v00.y) + lx * (v11.y - v01.y);
+                const float dy2 = hx * (v10.z - v00.z) + lx * (v11.z - v01.z), dy3 = hx * (v10.w - v00.w) + lx * (v11.w - v01.w);
+                gx = w * W * (go.x * dx0 + go.y * dx1 + go.z * dx2 + go.w * dx3);     // d/dloc_x (pixel x = loc_x*W - 0.5)
+                gy = w * H * (go.x * dy0 + go.y * dy1 + go.z * dy2 + go.w * dy3);
+            }
+            gx = head_sum(gx, dq); gy = head_sum(gy, dq); ga = head_sum(ga, dq);
+            if (d4 == 0) {
+                const long e = (nq * M + m) * sh.n_levels * P + l * P + p;
+                gloc[e * 2] = gx;
+                gloc[e * 2 + 1] = gy;
+                gattn[e] = ga;
+            }
+        }
+    }
+}
+
 // max |gout| as the bit pattern of a non-negative float (unsigned compare == float compare); *gmax zeroed by the caller
-__global__ __launch_bounds__(256) void msda_absmax_kernel(const float* __restrict__ g, unsigned int* __restrict__ gmax, long n) {
+template <typename GT>
+__global__ __launch_bounds__(256) void msda_absmax_kernel(const GT* __restrict__ g, unsigned int* __restrict__ gmax, long n) {
     float m = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(g[i]));
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf((float)g[i]));
     __shared__ float red[16];
     m = block_max(m, red);
     if (threadIdx.x == 0) atomicMax(gmax, __float_as_uint(m));
@@ -203,9 +315,11 @@ __global__ __launch_bounds__(MSDA_VT) void msda_bucket_kernel(const float* __res
 }
 
 // grid: ceil(S / (256 / D)) x M x N workgroups of 256 threads = 256 / D pixels x D channels
+template <typename GT>
 __global__ __launch_bounds__(256) void msda_gather_kernel(const float* __restrict__ loc, const float* __restrict__ attn,
-                                                           const float* __restrict__ gout, const unsigned int* __restrict__ gmax,
-                                                           const int* __restrict__ ws, float* __restrict__ gvalue, MsdaShapes sh,
+                                                           const GT* __restrict__ gout, const unsigned int* __restrict__ gmax,
+                                                           const int* __restrict__ ws, float* __restrict__ gvalue,
+                                                           __half* __restrict__ gvalue16, MsdaShapes sh,
                                                            int S, int Lq, int M, int D, int P, int N) {
     const int m = blockIdx.y, n = blockIdx.z;
     const int grp = threadIdx.x / D, d = threadIdx.x - grp * D;
@@ -249,13 +363,15 @@ __global__ __launch_bounds__(256) void msda_gather_kernel(const float* __restric
                 const int kk = k + u < cntk ? k + u : k;                    // (clamped: the weight of a padded slot is zeroed below)
                 const long row = __shfl(rowj, kk, D);
                 wk[u] = k + u < cntk ? __shfl(wj, kk, D) : 0.f;
-                gk[u] = gout[row + d];
+                gk[u] = (float)gout[row + d];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc += (long long)rintf(gk[u] * wk[u]);
         }
     }
-    gvalue[(((long)n * S + s) * M + m) * D + d] = gm > 0.f ? (float)acc * (gm / 1099511627776.0f) : 0.f;
+    const float gvv = gm > 0.f ? (float)acc * (gm / 1099511627776.0f) : 0.f;
+    if (gvalue) gvalue[(((long)n * S + s) * M + m) * D + d] = gvv;
+    if (gvalue16) gvalue16[(((long)n * S + s) * M + m) * D + d] = __float2half(gvv);      // the value projection's gradient operand
 }
 
 static int fill_shapes(MsdaShapes* sh, const int* h_shapes, int n_levels, int* S) {
@@ -273,48 +389,63 @@ static int fill_shapes(MsdaShapes* sh, const int* h_shapes, int n_levels, int* S
     return 0;
 }
 
-extern "C" int wc_msda_fwd_h(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
-                             float* out, void* out16, int N, int Lq, int M, int D, int P, void* stream);
+extern "C" int wc_msda_fwd_h(const void* value, int value_is_f16, const int* h_shapes, int n_levels, const float* loc,
+                             const float* attn, float* out, void* out16, int N, int Lq, int M, int D, int P, void* stream);
 
 extern "C" int wc_msda_fwd(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
                            float* out, int N, int Lq, int M, int D, int P, void* stream) {
-    return wc_msda_fwd_h(value, h_shapes, n_levels, loc, attn, out, nullptr, N, Lq, M, D, P, stream);
+    return wc_msda_fwd_h(value, 0, h_shapes, n_levels, loc, attn, out, nullptr, N, Lq, M, D, P, stream);
 }
 
-// out (f32) and / or out16 (f16): (N, Lq, M*D)
-extern "C" int wc_msda_fwd_h(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
-                             float* out, void* out16, int N, int Lq, int M, int D, int P, void* stream) {
+// value f32 or f16 (value_is_f16: needs the channel-quad form, D % 4 == 0); out (f32) and / or out16 (f16): (N, Lq, M*D)
+extern "C" int wc_msda_fwd_h(const void* value, int value_is_f16, const int* h_shapes, int n_levels, const float* loc,
+                             const float* attn, float* out, void* out16, int N, int Lq, int M, int D, int P, void* stream) {
     MsdaShapes sh;
     int S = 0;
     WC_CHECK_ARG(value && h_shapes && loc && attn && (out || out16) && N > 0 && Lq > 0 && M > 0 && P > 0, "wc_msda_fwd: bad argument");
     WC_CHECK_ARG(fill_shapes(&sh, h_shapes, n_levels, &S) == 0, "wc_msda_fwd: 1..8 levels with positive sizes");
     WC_CHECK_ARG((D == 16 || D == 32 || D == 64) && M * D <= 1024 && (M * D) % 64 == 0,
                  "wc_msda_fwd: head dim 16/32/64, heads*dim a multiple of 64 and <= 1024");
-    hipLaunchKernelGGL(msda_fwd_kernel, dim3((unsigned)((long)N * Lq)), dim3(M * D), 0, (hipStream_t)stream, value, loc, attn,
-                       out, (__half*)out16, sh, S, Lq, M, D, P);
+    const int tpq = M * D / 4;
+    const bool quad = D % 4 == 0 && 256 % tpq == 0 && tpq % (D / 4) == 0 && ((uintptr_t)value % 16 == 0) &&
+                      (!out || (uintptr_t)out % 16 == 0) && (!out16 || (uintptr_t)out16 % 8 == 0);
+    WC_CHECK_ARG(quad || !value_is_f16, "wc_msda_fwd: an f16 value tensor needs the channel-quad form (M*D/4 dividing 256, aligned buffers)");
+    if (quad) {
+        const long NQ = (long)N * Lq;
+        const dim3 gd((unsigned)wc_cdiv(NQ, 256 / tpq));
+        if (value_is_f16)
+            hipLaunchKernelGGL(msda_fwd4_kernel<__half>, gd, dim3(256), 0, (hipStream_t)stream, (const __half*)value, loc, attn, out,
+                               (__half*)out16, sh, S, NQ, Lq, M, D, P);
+        else
+            hipLaunchKernelGGL(msda_fwd4_kernel<float>, gd, dim3(256), 0, (hipStream_t)stream, (const float*)value, loc, attn, out,
+                               (__half*)out16, sh, S, NQ, Lq, M, D, P);
+        WC_LAUNCH_CHECK("msda_fwd4_kernel");
+        return WC_OK;
+    }
+    hipLaunchKernelGGL(msda_fwd_kernel, dim3((unsigned)((long)N * Lq)), dim3(M * D), 0, (hipStream_t)stream, (const float*)value, loc,
+                       attn, out, (__half*)out16, sh, S, Lq, M, D, P);
     WC_LAUNCH_CHECK("msda_fwd_kernel");
     return WC_OK;
 }
 
 // gvalue needs no initialisation (every element is written exactly once); gmax: 1 x u32 workspace;
 // ws: N*M*S*2 + N*M*n_levels*Lq*P*4 ints (bucket starts, sizes, and the per-pixel buckets of (sample, corner) ids).
+extern "C" int wc_msda_bwd_h(const void* value, int value_is_f16, const int* h_shapes, int n_levels, const float* loc,
+                             const float* attn, const void* gout, int gout_is_f16, float* gvalue, void* gvalue16, float* gloc,
+                             float* gattn, void* gmax, void* ws, int N, int Lq, int M, int D, int P, void* stream);
+
 extern "C" int wc_msda_bwd(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
                            const float* gout, float* gvalue, float* gloc, float* gattn, void* gmax, void* ws, int N, int Lq,
                            int M, int D, int P, void* stream) {
-    MsdaShapes sh;
-    int S = 0;
-    WC_CHECK_ARG(value && h_shapes && loc && attn && gout && gvalue && gloc && gattn && gmax && N > 0 && Lq > 0 && M > 0 && P > 0,
-                 "wc_msda_bwd: bad argument");
-    WC_CHECK_ARG(fill_shapes(&sh, h_shapes, n_levels, &S) == 0, "wc_msda_bwd: 1..8 levels with positive sizes");
-    WC_CHECK_ARG((D == 16 || D == 32 || D == 64) && M * D <= 1024 && (M * D) % 64 == 0 && M <= 65535 && N <= 65535,
-                 "wc_msda_bwd: head dim 16/32/64, heads*dim a multiple of 64 and <= 1024");
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(msda_bwd_kernel, dim3((unsigned)((long)N * Lq)), dim3(M * D), 0, st, value, loc, attn, gout, gloc, gattn,
-                       sh, S, Lq, M, D, P);
-    WC_LAUNCH_CHECK("msda_bwd_kernel");
+    return wc_msda_bwd_h(value, 0, h_shapes, n_levels, loc, attn, gout, 0, gvalue, nullptr, gloc, gattn, gmax, ws, N, Lq, M, D, P, stream);
+}
+
+template <typename GT>
+static int msda_bwd_value(const float* loc, const float* attn, const GT* gout, float* gvalue, void* gvalue16, void* gmax, void* ws,
+                          const MsdaShapes& sh, int n_levels, int S, int N, int Lq, int M, int D, int P, hipStream_t st) {
     hipMemsetAsync(gmax, 0, sizeof(unsigned int), st);
     const long ng = (long)N * Lq * M * D;
-    hipLaunchKernelGGL(msda_absmax_kernel, dim3((unsigned)(ng / 256 / 8 + 1 > 512 ? 512 : ng / 256 / 8 + 1)), dim3(256), 0, st, gout,
+    hipLaunchKernelGGL(msda_absmax_kernel<GT>, dim3((unsigned)(ng / 256 / 8 + 1 > 512 ? 512 : ng / 256 / 8 + 1)), dim3(256), 0, st, gout,
                        (unsigned int*)gmax, ng);
     WC_LAUNCH_CHECK("msda_absmax_kernel");
     int maxhw = 0;
@@ -329,8 +460,43 @@ extern "C" int wc_msda_bwd(const float* value, const int* h_shapes, int n_levels
     hipLaunchKernelGGL(msda_bucket_kernel, dim3(n_levels, M, N), dim3(MSDA_VT), (size_t)maxhw * 2 * sizeof(int), st, loc, (int*)ws, sh,
                        S, Lq, M, P, N);
     WC_LAUNCH_CHECK("msda_bucket_kernel");
-    hipLaunchKernelGGL(msda_gather_kernel, dim3(wc_cdiv(S, 256 / D), M, N), dim3(256), 0, st, loc, attn, gout,
-                       (const unsigned int*)gmax, (const int*)ws, gvalue, sh, S, Lq, M, D, P, N);
+    hipLaunchKernelGGL(msda_gather_kernel<GT>, dim3(wc_cdiv(S, 256 / D), M, N), dim3(256), 0, st, loc, attn, gout,
+                       (const unsigned int*)gmax, (const int*)ws, gvalue, (__half*)gvalue16, sh, S, Lq, M, D, P, N);
     WC_LAUNCH_CHECK("msda_gather_kernel");
     return WC_OK;
+}
+
+// value / gout f32 or f16 (the f16 forms need the channel-quad kernels); gvalue (f32) and / or gvalue16 (f16)
+extern "C" int wc_msda_bwd_h(const void* value, int value_is_f16, const int* h_shapes, int n_levels, const float* loc,
+                             const float* attn, const void* gout, int gout_is_f16, float* gvalue, void* gvalue16, float* gloc,
+                             float* gattn, void* gmax, void* ws, int N, int Lq, int M, int D, int P, void* stream) {
+    MsdaShapes sh;
+    int S = 0;
+    WC_CHECK_ARG(value && h_shapes && loc && attn && gout && (gvalue || gvalue16) && gloc && gattn && gmax && N > 0 && Lq > 0 && M > 0 && P > 0,
+                 "wc_msda_bwd: bad argument");
+    WC_CHECK_ARG(fill_shapes(&sh, h_shapes, n_levels, &S) == 0, "wc_msda_bwd: 1..8 levels with positive sizes");
+    WC_CHECK_ARG((D == 16 || D == 32 || D == 64) && M * D <= 1024 && (M * D) % 64 == 0 && M <= 65535 && N <= 65535,
+                 "wc_msda_bwd: head dim 16/32/64, heads*dim a multiple of 64 and <= 1024");
+    hipStream_t st = (hipStream_t)stream;
+    const int tpq = M * D / 4;
+    const bool quad = D % 4 == 0 && 256 % tpq == 0 && ((uintptr_t)value % 16 == 0) && ((uintptr_t)gout % 16 == 0);
+    WC_CHECK_ARG(quad || (!value_is_f16 && !gout_is_f16), "wc_msda_bwd: f16 value / gout need the channel-quad form");
+    if (quad) {
+        const long NQ = (long)N * Lq;
+        const dim3 gd((unsigned)wc_cdiv(NQ, 256 / tpq));
+#define MSDA_BWD4(VT, GT)                                                                                            \
+        hipLaunchKernelGGL((msda_bwd4_kernel<VT, GT>), gd, dim3(256), 0, st, (const VT*)value, loc, attn, (const GT*)gout, gloc, \
+                           gattn, sh, S, NQ, Lq, M, D, P)
+        if (value_is_f16) { if (gout_is_f16) MSDA_BWD4(__half, __half); else MSDA_BWD4(__half, float); }
+        else { if (gout_is_f16) MSDA_BWD4(float, __half); else MSDA_BWD4(float, float); }
+#undef MSDA_BWD4
+        WC_LAUNCH_CHECK("msda_bwd4_kernel");
+    } else {
+        hipLaunchKernelGGL(msda_bwd_kernel, dim3((unsigned)((long)N * Lq)), dim3(M * D), 0, st, (const float*)value, loc, attn,
+                           (const float*)gout, gloc, gattn, sh, S, Lq, M, D, P);
+        WC_LAUNCH_CHECK("msda_bwd_kernel");
+    }
+    if (gout_is_f16)
+        return msda_bwd_value<__half>(loc, attn, (const __half*)gout, gvalue, gvalue16, gmax, ws, sh, n_levels, S, N, Lq, M, D, P, st);
+    return msda_bwd_value<float>(loc, attn, (const float*)gout, gvalue, gvalue16, gmax, ws, sh, n_levels, S, N, Lq, M, D, P, st);
 }

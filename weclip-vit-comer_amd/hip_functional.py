@@ -21,89 +21,21 @@ def _rows(x):
     return x.reshape(-1, K), x.shape[:-1]
 
 
-class _LinearFn(torch.autograd.Function):
-    """y = act(x W^T + b); x (M, K) f32, W (N, K), b (N) or None.  K % 64 == 0.  act: 0 none, 2 ReLU."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, act):
-        L.require_gpu()
-        x = x.detach().float().contiguous()
-        M, K = x.shape
-        N = weight.shape[0]
-        if K % 64:
-            raise RuntimeError(f"hip linear: K = {K} must be a multiple of 64")
-        ex = config.exact()
-        x16 = ops.split_f16(x, with_lo=ex)
-        w2 = weight.detach().float().reshape(N, K).contiguous()
-        w16 = ops.split_f16(w2, with_lo=ex)
-        y = torch.empty(M, N, device=x.device, dtype=F32)
-        ops.gemm(x16, w16, M, N, K, bias=bias.detach().float().contiguous() if bias is not None else None, out32=y, act=act)
-        ctx.save_for_backward(x16.hi, w2, y if act == 2 else None)
-        ctx.x_lo, ctx.meta, ctx.has_bias, ctx.wshape = x16.lo, (M, N, K, act, ex), bias is not None, weight.shape
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        xhi, w2, y = ctx.saved_tensors
-        M, N, K, act, ex = ctx.meta
-        dev = dy.device
-        dy = dy.float().contiguous()
-        if act == 2:
-            dy = dy * (y > 0)
-        Np = (N + 63) // 64 * 64
-        if Np != N:                                   # the contraction dimension of dX = dY W must be a multiple of 64
-            pad = torch.zeros(M, Np, device=dev, dtype=F32)
-            pad[:, :N] = dy
-            dy = pad
-        _, dS = ops.colscale_split(dy, None, M, alpha=GRAD_SCALE, want32=False, with_lo=ex)
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            wT, Kp = ops.transpose_f16(w2, N, K, with_lo=ex)          # (K, Np) fp16: W^T with the N columns zero padded
-            dx = torch.empty(M, K, device=dev, dtype=F32)
-            ops.gemm(dS, wT, M, K, Kp, out32=dx, scale=1.0 / GRAD_SCALE, scale_cols=K)
-        if ctx.needs_input_grad[1]:
-            tiles = ((N + 127) // 128) * ((K + 1 + 127) // 128)
-            ns = 1
-            while ns * 2 * tiles <= 512 and M // (ns * 2) >= 256:
-                ns *= 2
-            part, ns = ops.wgrad_partials(dS.hi, xhi, M, N, K, lda=Np, slices=ns, bias=True)
-            dw = torch.empty(N, K, device=dev, dtype=F32)
-            db = torch.empty(N, device=dev, dtype=F32)
-            L.lib().wc_sum_slices_wb(L.ptr(part, F32), L.ptr(dw, F32), L.ptr(db, F32), ns, N, K, 1.0 / GRAD_SCALE, L.stream())
-            dw = dw.view(ctx.wshape)
-            if not ctx.has_bias:
-                db = None
-        return dx, dw, db, None
-
-
 def linear(x, weight, bias=None, act=0):
-    """F.linear(x, weight, bias) [+ ReLU] for x (..., K) on the HIP path; weight may be a 1x1 conv kernel (N, K, 1, 1)."""
+    """F.linear(x, weight, bias) [+ ReLU] for x (..., K) on the HIP path; weight may be a 1x1 conv kernel (N, K, 1, 1).
+    Runs as the registered, differentiable custom op `torch.ops.weclip.linear` (torch_ops.py: forward = MFMA GEMM,
+    backward = weclip::linear_bwd via register_autograd)."""
+    from . import torch_ops  # noqa: F401  (registers torch.ops.weclip.*)
     rows, lead = _rows(x)
-    y = _LinearFn.apply(rows, weight, bias, act)
+    y = torch.ops.weclip.linear(rows, weight, bias, act)
     return y.view(*lead, weight.shape[0])
 
 
-class _LayerNormFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, weight, bias, eps):
-        L.require_gpu()
-        x = x.detach().float().contiguous()
-        w = weight.detach().float().contiguous()
-        y, _ = ops.layernorm(x, w, bias.detach().float().contiguous(), eps=eps, want32=True, want16=False)
-        ctx.save_for_backward(x, w)
-        ctx.eps = eps
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        dx, _, dgb = ops.layernorm_bwd(dy.float().contiguous(), x, w, want32=True, eps=ctx.eps)
-        return dx, dgb[0], dgb[1], None
-
-
 def layer_norm(x, weight, bias, eps=1e-5):
+    """nn.LayerNorm over the last dimension as the differentiable custom op `torch.ops.weclip.layer_norm`."""
+    from . import torch_ops  # noqa: F401
     rows, lead = _rows(x)
-    return _LayerNormFn.apply(rows, weight, bias, eps).view(*lead, x.shape[-1])
+    return torch.ops.weclip.layer_norm(rows, weight, bias, eps).view(*lead, x.shape[-1])
 
 
 def module_linear(mod, x, act=0):

@@ -12,7 +12,7 @@ one Python frame per launch matters there).
 There is NO CPU kernel: a CPU tensor raises NotImplementedError from the dispatcher (no backend registered),
 which is the "fail loudly" contract of the package.
 """
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -167,5 +167,142 @@ def _(attn_pred, cam_label, radius, ignore_index):
     return attn_pred.new_empty((), dtype=F32)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Trainable operators: forward and backward are both registered ops, tied together with `register_autograd`
+# ("ops used by trainable modules need ... register_autograd backward").  hip_functional.linear /
+# layer_norm -- the nn.Linear / 1x1 nn.Conv2d / nn.LayerNorm layers of the module-by-module ViT-CoMer form -- call these.
+GRAD_SCALE = 4096.0
+
+
+@torch.library.custom_op(f"{_LIB}::linear", mutates_args=(), device_types="cuda")
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int) -> Tensor:
+    """y = act(x W^T + b) for fp32 x (M, K), W (N, K) [or a 1x1 conv kernel (N, K, 1, 1)], b (N) or None on the MFMA path
+    (fp16 operands [hi + lo in `exact` precision], fp32 accumulate).  act 0 none / 2 ReLU.  K % 64 == 0."""
+    from . import config, ops
+    x = x.detach().float().contiguous()
+    M, K = x.shape
+    N = weight.shape[0]
+    if K % 64:
+        raise RuntimeError(f"weclip::linear: K = {K} must be a multiple of 64")
+    ex = config.exact()
+    y = torch.empty(M, N, device=x.device, dtype=F32)
+    ops.gemm(ops.split_f16(x, with_lo=ex), ops.split_f16(weight.detach().float().reshape(N, K).contiguous(), with_lo=ex), M, N, K,
+             bias=bias.detach().float().contiguous() if bias is not None else None, out32=y, act=act)
+    return y
+
+
+@linear.register_fake
+def _(x, weight, bias, act):
+    return x.new_empty((x.shape[0], weight.shape[0]), dtype=F32)
+
+
+@torch.library.custom_op(f"{_LIB}::linear_bwd", mutates_args=(), device_types="cuda")
+def linear_bwd(dy: Tensor, x: Tensor, weight: Tensor, y: Tensor, act: int, need_dx: bool, need_dw: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    """Gradients of weclip::linear: (dx (M, K), dW (N, K), db (N)); a (0,) tensor where not needed.  The input gradient is
+    one MFMA GEMM against the transposed weight, the weight + bias gradients the split-K row-major GEMM (csrc/gemm.hip
+    gemm_km_kernel, bias = extra output column); gradients travel multiplied by 2^12 so they sit in fp16's normal range."""
+    from . import _lib as L
+    from . import config, ops
+    M, K = x.shape
+    N = weight.shape[0]
+    dev = dy.device
+    ex = config.exact()
+    dy = dy.float().contiguous()
+    if act == 2:
+        dy = dy * (y > 0)
+    Np = (N + 63) // 64 * 64
+    if Np != N:                                   # the contraction dimension of dX = dY W must be a multiple of 64
+        pad = torch.zeros(M, Np, device=dev, dtype=F32)
+        pad[:, :N] = dy
+        dy = pad
+    _, dS = ops.colscale_split(dy, None, M, alpha=GRAD_SCALE, want32=False, with_lo=ex)
+    w2 = weight.detach().float().reshape(N, K).contiguous()
+    none = dy.new_empty((0,))
+    dx = dw = db = none
+    if need_dx:
+        wT, Kp = ops.transpose_f16(w2, N, K, with_lo=ex)          # (K, Np) fp16: W^T with the N columns zero padded
+        dx = torch.empty(M, K, device=dev, dtype=F32)
+        ops.gemm(dS, wT, M, K, Kp, out32=dx, scale=1.0 / GRAD_SCALE, scale_cols=K)
+    if need_dw:
+        xhi = ops.split_f16(x.detach().float().contiguous()).hi
+        tiles = ((N + 127) // 128) * ((K + 1 + 127) // 128)
+        ns = 1
+        while ns * 2 * tiles <= 512 and M // (ns * 2) >= 256:
+            ns *= 2
+        part, ns = ops.wgrad_partials(dS.hi, xhi, M, N, K, lda=Np, slices=ns, bias=True)
+        dw = torch.empty(N, K, device=dev, dtype=F32)
+        db = torch.empty(N, device=dev, dtype=F32)
+        L.lib().wc_sum_slices_wb(L.ptr(part, F32), L.ptr(dw, F32), L.ptr(db, F32), ns, N, K, 1.0 / GRAD_SCALE, L.stream())
+    return dx, dw, db
+
+
+@linear_bwd.register_fake
+def _(dy, x, weight, y, act, need_dx, need_dw):
+    N, K = weight.shape[0], x.shape[1]
+    e = dy.new_empty((0,), dtype=F32)
+    return (x.new_empty(x.shape, dtype=F32) if need_dx else e, x.new_empty((N, K), dtype=F32) if need_dw else e,
+            x.new_empty((N,), dtype=F32) if need_dw else e)
+
+
+def _linear_setup(ctx, inputs, output):
+    x, weight, bias, act = inputs
+    ctx.save_for_backward(x, weight, output if act == 2 else None)
+    ctx.act, ctx.has_bias, ctx.wshape = act, bias is not None, weight.shape
+
+
+def _linear_backward(ctx, dy):
+    x, weight, y = ctx.saved_tensors
+    need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+    dx, dw, db = torch.ops.weclip.linear_bwd(dy, x, weight, y if y is not None else dy.new_empty((0,)), ctx.act, need_dx, need_dw)
+    return (dx if need_dx else None, dw.view(ctx.wshape) if need_dw else None, db if (need_dw and ctx.has_bias) else None, None)
+
+
+torch.library.register_autograd(f"{_LIB}::linear", _linear_backward, setup_context=_linear_setup)
+
+
+@torch.library.custom_op(f"{_LIB}::layer_norm", mutates_args=(), device_types="cuda")
+def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
+    """Row LayerNorm (fp32 statistics, reference clip/model.py:177-183) of x (rows, D) -> f32; differentiable
+    (weclip::layer_norm_bwd through register_autograd)."""
+    from . import ops
+    y, _ = ops.layernorm(x.detach().float().contiguous(), weight.detach().float().contiguous(), bias.detach().float().contiguous(),
+                         eps=eps, want32=True, want16=False)
+    return y
+
+
+@layer_norm.register_fake
+def _(x, weight, bias, eps):
+    return x.new_empty(x.shape, dtype=F32)
+
+
+@torch.library.custom_op(f"{_LIB}::layer_norm_bwd", mutates_args=(), device_types="cuda")
+def layer_norm_bwd(dy: Tensor, x: Tensor, weight: Tensor, eps: float) -> Tuple[Tensor, Tensor, Tensor]:
+    """(dx, dgamma, dbeta) of weclip::layer_norm (csrc/train_ops.hip ln_bwd, fixed-order column reductions)."""
+    from . import ops
+    dx, _, dgb = ops.layernorm_bwd(dy.float().contiguous(), x.detach().float().contiguous(), weight.detach().float().contiguous(),
+                                   want32=True, eps=eps)
+    return dx, dgb[0].clone(), dgb[1].clone()
+
+
+@layer_norm_bwd.register_fake
+def _(dy, x, weight, eps):
+    return x.new_empty(x.shape, dtype=F32), weight.new_empty(weight.shape, dtype=F32), weight.new_empty(weight.shape, dtype=F32)
+
+
+def _ln_setup(ctx, inputs, output):
+    x, weight, bias, eps = inputs
+    ctx.save_for_backward(x, weight)
+    ctx.eps = eps
+
+
+def _ln_backward(ctx, dy):
+    x, weight = ctx.saved_tensors
+    dx, dg, db = torch.ops.weclip.layer_norm_bwd(dy, x, weight, ctx.eps)
+    return dx, dg, db, None
+
+
+torch.library.register_autograd(f"{_LIB}::layer_norm", _ln_backward, setup_context=_ln_setup)
+
+
 OPS = ("par_forward", "par_labels", "trans_mat", "attention", "linear_f16", "layernorm", "bilinear_resize", "confusion_hist",
-       "seg_loss", "aff_loss")
+       "seg_loss", "aff_loss", "linear", "linear_bwd", "layer_norm", "layer_norm_bwd")
