@@ -231,10 +231,10 @@ def roofline_leg(args, step, loader, dev):
     def peak_of(name):
         return ("hbm", 8000.0, "GB/s") if name.startswith(HBM) else ("mfma", 2500.0, "TFLOP/s")
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
-    # (tools/refresh_profiles.sh + tools/pmc_traffic.py -> profiles/r02_traffic.json; 2*FETCH_SIZE + WRITE_SIZE, KiB,
+    # (tools/refresh_profiles.sh + tools/pmc_traffic.py -> profiles/r03_traffic.json; 2*FETCH_SIZE + WRITE_SIZE, KiB,
     # per the MI355X guide); keyed by the same kernel names.  null when no pass exists for this configuration.
     traffic, tsrc = {}, None
-    for fn in ("r02_traffic.json", "r01_traffic.json"):
+    for fn in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", fn)
         if os.path.exists(tpath) and B == 16 and S == 512 and K == 2:
             traffic = {k: round(v["hbm_bytes_per_launch"]) for k, v in json.load(open(tpath)).items()}

@@ -416,6 +416,19 @@ int wc_resize_argmax(const float* seg, long* pred, int C, int Hs, int Ws, int Hd
 int wc_confusion_hist(const long* label_true, const long* label_pred, long* hist, int* flag, long n, int nc,
                       void* stream);
 
+/* Fused forms of the two calls above for the CTI configurations ((n_levels, P) = (3, 4) or (1, 4); wc_msda_fused_supported
+ * returns 1): the sampling locations and soft-maxed weights are computed inside the forward kernel from the raw rows
+ * ow (N*Lq, ld) = [M*nL*P*2 offsets | M*nL*P logits] of the fused sampling_offsets | attention_weights Linear, their biases
+ * (optional) and the reference points ref (Lq, nl_ref, 2); loc / attn are written for the backward.  The backward writes the
+ * gradient of the raw rows as the f16 GEMM operand dow16 (N*Lq, ld), padding columns zeroed. */
+int wc_msda_fused_supported(int n_levels, int M, int D, int P);
+int wc_msda_fwd_f(const void* value, int value_is_f16, const int* h_shapes, int n_levels, const float* ow, int ld,
+                  const float* bias_off, const float* bias_aw, const float* ref, int nl_ref, float* loc, float* attn,
+                  float* out, void* out16, int N, int Lq, int M, int D, int P, void* stream);
+int wc_msda_bwd_f(const void* value, int value_is_f16, const int* h_shapes, int n_levels, const float* loc,
+                  const float* attn, const void* gout, int gout_is_f16, float* gvalue, void* gvalue16, void* dow16,
+                  int ld, void* gmax, void* ws, int N, int Lq, int M, int D, int P, void* stream);
+
 /* ---- fused glue of the ViT-CoMer insert engine (csrc/comer.hip; no reference code exists: ViT_CoMer.pdf §3.2-3.3) ---- */
 /* MRFP's depth-wise convolutions on token rows x (N, S, C) f32, S = sum of the n_levels maps h_shapes = {H0, W0, H1, W1, ...}:
  * 3x3 filters w3 (C/2, 9) + b3 on channels [0, C/2), 5x5 filters w5 (C/2, 25) + b5 on [C/2, C), zero padding, all levels in

@@ -1,0 +1,31 @@
+"""`bench.py --gpus 2` end to end on the one-GPU box (BASELINE configs[3] rehearsal): the launcher path
+(bench.py starts the two ranks itself before any GPU call), the gloo rendezvous on 127.0.0.1, per-rank loaders, graph
+capture with a process group alive, the flat-bucket all-reduce, the max-over-ranks clock and rank 0's JSON line.  The two
+ranks share the GPU and exchange the bucket through the host (WECLIP_DIST_BACKEND=gloo); the measured path is RCCL, one
+rank per GPU, which this pool cannot run (one GPU per box)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_share_one_gpu_and_stay_in_step():
+    env = dict(os.environ, WECLIP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2",
+           "--size", "128", "--no-extras", "--no-cpu-baseline", "--roof-steps", "0", "--timer-stride", "0"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]           # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert d["scaling"] == "weak" and d["steps"] == 3 and d["value"] > 0
+    assert d["dp_check"]["params_identical_across_ranks"] is True          # both ranks applied the same mean gradient
+    assert d["launch_mode"] == "hipGraph replay"

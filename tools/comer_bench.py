@@ -16,9 +16,16 @@ maps = [torch.randn(B, h * w, 256, device="cuda", requires_grad=True) if i in ne
 gy = torch.randn(B, 256, h, w, device="cuda")
 
 
+STEM = os.environ.get("CB_STEM") == "1"      # the conv stem (SpatialPrior) alone
+
+
 def step():
     for p in net.parameters():
         p.grad = None
+    if STEM:
+        c, _ = net.spm(img)
+        c.backward(torch.ones_like(c))
+        return
     y = net(img, maps, (h, w))
     y.backward(gy)
 
@@ -30,4 +37,4 @@ t0 = time.perf_counter()
 for _ in range(n):
     step()
 torch.cuda.synchronize()
-print(f"CoMerInteraction fwd+bwd, B={B} {S}x{S}: {(time.perf_counter() - t0) / n * 1e3:.2f} ms per pass (eager, {n} passes)")
+print(("SpatialPrior stem only: " if STEM else "") + f"CoMerInteraction fwd+bwd, B={B} {S}x{S}: {(time.perf_counter() - t0) / n * 1e3:.2f} ms per pass (eager, {n} passes)")

@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import synth
+from weclip_vit_comer_amd import synth
 from weclip_vit_comer_amd.WeCLIP_model.PAR import PAR
 
 B, C, H, W = int(os.environ.get("B", 16)), 3, 512, 512

@@ -99,9 +99,14 @@ class ComerEngine:
         attn = torch.empty(B * Lq * M * nL * P, device=dev, dtype=F32)
         hs = _shape_array(shapes)
         lib = L.lib()
+        o16 = torch.empty(B * Lq, M * D, device=dev, dtype=F16)
+        if lib.cdll.wc_msda_fused_supported(nL, M, D, P):        # locations + soft-max inside the attention kernel
+            lib.wc_msda_fwd_f(L.ptr(value, F16), 1, hs, nL, L.ptr(ow, F32), ld, L.ptr(self._b(att.sampling_offsets.bias), F32),
+                              L.ptr(self._b(att.attention_weights.bias), F32), L.ptr(ref, F32), 1, L.ptr(loc), L.ptr(attn), None,
+                              L.ptr(o16), B, Lq, M, D, P, L.stream())
+            return o16, loc, attn
         lib.wc_msda_prep_fwd(L.ptr(ow, F32), L.ptr(self._b(att.sampling_offsets.bias), F32), L.ptr(self._b(att.attention_weights.bias), F32),
                              L.ptr(ref, F32), L.ptr(loc), L.ptr(attn), hs, nL, B, Lq, M, P, ld, 1, L.stream())
-        o16 = torch.empty(B * Lq, M * D, device=dev, dtype=F16)
         lib.wc_msda_fwd_h(L.ptr(value, F16), 1, hs, nL, L.ptr(loc), L.ptr(attn), None, L.ptr(o16), B, Lq, M, D, P, L.stream())
         return o16, loc, attn
 
@@ -112,14 +117,18 @@ class ComerEngine:
         S = sum(h * w for h, w in shapes)
         dev = value.device
         gv = torch.empty(value.shape, device=dev, dtype=F16)          # (value is f16 already)
-        gl, ga = torch.empty_like(loc), torch.empty_like(attn)
         gmax = torch.empty(1, device=dev, dtype=torch.int32)
         ws = torch.empty(B * M * (2 * S + nL * Lq * P * 4), device=dev, dtype=torch.int32)
         hs = _shape_array(shapes)
         lib = L.lib()
+        dow16 = torch.empty(B * Lq, ld, device=dev, dtype=F16)
+        if lib.cdll.wc_msda_fused_supported(nL, M, D, P):        # soft-max / location backward inside the attention kernel
+            lib.wc_msda_bwd_f(L.ptr(value, F16), 1, hs, nL, L.ptr(loc), L.ptr(attn), L.ptr(gout, F16, "gout"), 1, None, L.ptr(gv),
+                              L.ptr(dow16), ld, L.ptr(gmax), L.ptr(ws), B, Lq, M, D, P, L.stream())
+            return gv, dow16
+        gl, ga = torch.empty_like(loc), torch.empty_like(attn)
         lib.wc_msda_bwd_h(L.ptr(value, F16), 1, hs, nL, L.ptr(loc), L.ptr(attn), L.ptr(gout, F16, "gout"), 1, None, L.ptr(gv), L.ptr(gl),
                           L.ptr(ga), L.ptr(gmax), L.ptr(ws), B, Lq, M, D, P, L.stream())
-        dow16 = torch.empty(B * Lq, ld, device=dev, dtype=F16)
         lib.wc_msda_prep_bwd(L.ptr(gl), L.ptr(ga), L.ptr(attn), None, L.ptr(dow16), hs, nL, B, Lq, M, P, ld, L.stream())
         return gv, dow16
 

@@ -226,6 +226,164 @@ __global__ __launch_bounds__(256) void msda_bwd4_kernel(const VT* __restrict__ v
     }
 }
 
+// ---- fused forms (comer_engine.py): the sampling locations and the soft-maxed attention weights are computed INSIDE the
+// kernels from the raw rows ow (N*Lq, ld) = [M*T*2 offsets | M*T logits] of the fused sampling_offsets | attention_weights GEMM
+// (T = NL*P, compile time), their biases and the reference points: loc = ref + (off + b_off) / (W_l, H_l), attn = softmax_T.
+// The forward still writes loc / attn once (the value-gradient bucket / gather kernels and the backward read them); the
+// backward turns the location / weight gradients into the gradient of the raw row in registers (soft-max backward needs all
+// T weight gradients of a head: they are kept by every lane after the head reduction) and writes it as the f16 operand
+// dow16 (N*Lq, ld) of the input-gradient / weight-gradient GEMMs, padding columns zeroed: no gloc / gattn tensors, no
+// separate prep kernels.
+template <typename VT, int NL, int P>
+__global__ __launch_bounds__(256) void msda_fwd4f_kernel(const VT* __restrict__ value, const float* __restrict__ ow,
+                                const float* __restrict__ boff, const float* __restrict__ baw, const float* __restrict__ ref,
+                                float* __restrict__ loc, float* __restrict__ attn, float* __restrict__ out,
+                                __half* __restrict__ out16, MsdaShapes sh, int S, long NQ, int Lq, int M, int D, int ld, int nl_ref) {
+    constexpr int T = NL * P;
+    const int tpq = (M * D) >> 2, j = threadIdx.x % tpq;
+    const long nq = (long)blockIdx.x * (256 / tpq) + threadIdx.x / tpq;
+    if (nq >= NQ) return;
+    const int n = (int)(nq / Lq), q = (int)(nq - (long)n * Lq), dq = D >> 2, m = j / dq, d4 = (j - m * dq) * 4;
+    const long MD = (long)M * D;
+    const float* row = ow + nq * ld;
+    const float* off = row + (long)m * T * 2;
+    const float* lg = row + (long)M * T * 2 + (long)m * T;
+    float aw[T], sx[T], sy[T];
+    float mx = -3.4e38f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        aw[t] = lg[t] + (baw ? baw[m * T + t] : 0.f);
+        mx = fmaxf(mx, aw[t]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        aw[t] = __expf(aw[t] - mx);
+        sum += aw[t];
+    }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const float* rp = ref + ((long)q * nl_ref + (nl_ref > 1 ? l : 0)) * 2;
+        const float rx = rp[0], ry = rp[1], iw = 1.f / sh.W[l], ih = 1.f / sh.H[l];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int t = l * P + p;
+            aw[t] *= inv;
+            sx[t] = rx + (off[t * 2] + (boff ? boff[(m * T + t) * 2] : 0.f)) * iw;
+            sy[t] = ry + (off[t * 2 + 1] + (boff ? boff[(m * T + t) * 2 + 1] : 0.f)) * ih;
+        }
+    }
+    if (d4 == 0) {
+        const long e = (nq * M + m) * T;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            loc[(e + t) * 2] = sx[t];
+            loc[(e + t) * 2 + 1] = sy[t];
+            attn[e + t] = aw[t];
+        }
+    }
+    const VT* vb = value + (long)n * S * MD + (long)m * D + d4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const int H = sh.H[l], W = sh.W[l];
+        const VT* vl = vb + (long)sh.start[l] * MD;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int t = l * P + p;
+            const float x = sx[t] * W - 0.5f, y = sy[t] * H - 0.5f, w = aw[t];
+            if (y > -1.f && x > -1.f && y < H && x < W) {
+                const int y0 = (int)floorf(y), x0 = (int)floorf(x);
+                const float ly = y - y0, lx = x - x0, hy = 1.f - ly, hx = 1.f - lx;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 v00 = (y0 >= 0 && x0 >= 0) ? msda_ld4(vl + ((long)y0 * W + x0) * MD) : z;
+                const float4 v01 = (y0 >= 0 && x0 + 1 < W) ? msda_ld4(vl + ((long)y0 * W + x0 + 1) * MD) : z;
+                const float4 v10 = (y0 + 1 < H && x0 >= 0) ? msda_ld4(vl + ((long)(y0 + 1) * W + x0) * MD) : z;
+                const float4 v11 = (y0 + 1 < H && x0 + 1 < W) ? msda_ld4(vl + ((long)(y0 + 1) * W + x0 + 1) * MD) : z;
+                const float w00 = w * hy * hx, w01 = w * hy * lx, w10 = w * ly * hx, w11 = w * ly * lx;
+                acc.x += w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x;
+                acc.y += w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y;
+                acc.z += w00 * v00.z + w01 * v01.z + w10 * v10.z + w11 * v11.z;
+                acc.w += w00 * v00.w + w01 * v01.w + w10 * v10.w + w11 * v11.w;
+            }
+        }
+    }
+    const long o = nq * MD + (long)m * D + d4;
+    if (out) *reinterpret_cast<float4*>(out + o) = acc;
+    if (out16) {
+        __half h[4] = {__float2half(acc.x), __float2half(acc.y), __float2half(acc.z), __float2half(acc.w)};
+        *reinterpret_cast<uint2*>(out16 + o) = *reinterpret_cast<const uint2*>(h);
+    }
+}
+
+template <typename VT, typename GT, int NL, int P>
+__global__ __launch_bounds__(256) void msda_bwd4f_kernel(const VT* __restrict__ value, const float* __restrict__ loc,
+                                const float* __restrict__ attn, const GT* __restrict__ gout, __half* __restrict__ dow16,
+                                MsdaShapes sh, int S, long NQ, int Lq, int M, int D, int ld) {
+    constexpr int T = NL * P;
+    const int tpq = (M * D) >> 2, j = threadIdx.x % tpq;
+    const long nq = (long)blockIdx.x * (256 / tpq) + threadIdx.x / tpq;
+    if (nq >= NQ) return;
+    const int n = (int)(nq / Lq), dq = D >> 2, m = j / dq, d4 = (j - m * dq) * 4;
+    const long MD = (long)M * D;
+    const VT* vb = value + (long)n * S * MD + (long)m * D + d4;
+    const float* lb = loc + (nq * M + m) * T * 2;
+    const float* ab = attn + (nq * M + m) * T;
+    const float4 go = msda_ld4(gout + nq * MD + (long)m * D + d4);
+    float aw[T], ga[T], gx[T], gy[T];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const int H = sh.H[l], W = sh.W[l];
+        const VT* vl = vb + (long)sh.start[l] * MD;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int t = l * P + p;
+            const float x = lb[t * 2] * W - 0.5f, y = lb[t * 2 + 1] * H - 0.5f;
+            const float w = ab[t];
+            aw[t] = w;
+            float sgx = 0.f, sgy = 0.f, sga = 0.f;
+            if (y > -1.f && x > -1.f && y < H && x < W) {
+                const int y0 = (int)floorf(y), x0 = (int)floorf(x);
+                const float ly = y - y0, lx = x - x0, hy = 1.f - ly, hx = 1.f - lx;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 v00 = (y0 >= 0 && x0 >= 0) ? msda_ld4(vl + ((long)y0 * W + x0) * MD) : z;
+                const float4 v01 = (y0 >= 0 && x0 + 1 < W) ? msda_ld4(vl + ((long)y0 * W + x0 + 1) * MD) : z;
+                const float4 v10 = (y0 + 1 < H && x0 >= 0) ? msda_ld4(vl + ((long)(y0 + 1) * W + x0) * MD) : z;
+                const float4 v11 = (y0 + 1 < H && x0 + 1 < W) ? msda_ld4(vl + ((long)(y0 + 1) * W + x0 + 1) * MD) : z;
+                const float b0 = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+                const float b1 = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+                const float b2 = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+                const float b3 = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+                sga = go.x * b0 + go.y * b1 + go.z * b2 + go.w * b3;
+                const float dx0 = hy * (v01.x - v00.x) + ly * (v11.x - v10.x), dx1 = hy * (v01.y - v00.y) + ly * (v11.y - v10.y);
+                const float dx2 = hy * (v01.z - v00.z) + ly * (v11.z - v10.z), dx3 = hy * (v01.w - v00.w) + ly * (v11.w - v10.w);
+                const float dy0 = hx * (v10.x - v00.x) + lx * (v11.x - v01.x), dy1 = hx * (v10.y - v00.y) + lx * (v11.y - v01.y);
+                const float dy2 = hx * (v10.z - v00.z) + lx * (v11.z - v01.z), dy3 = hx * (v10.w - v00.w) + lx * (v11.w - v01.w);
+                // d out / d offset = d out / d loc / (W, H) and d loc = pixel / (W, H): the two level sizes cancel
+                sgx = w * (go.x * dx0 + go.y * dx1 + go.z * dx2 + go.w * dx3);
+                sgy = w * (go.x * dy0 + go.y * dy1 + go.z * dy2 + go.w * dy3);
+            }
+            gx[t] = head_sum(sgx, dq);
+            gy[t] = head_sum(sgy, dq);
+            ga[t] = head_sum(sga, dq);
+        }
+    }
+    __half* drow = dow16 + nq * ld;
+    if (d4 == 0) {
+        float dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) dot = fmaf(aw[t], ga[t], dot);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            drow[(m * T + t) * 2] = __float2half(gx[t]);
+            drow[(m * T + t) * 2 + 1] = __float2half(gy[t]);
+            drow[M * T * 2 + m * T + t] = __float2half(aw[t] * (ga[t] - dot));
+        }
+    }
+    for (int c = 3 * M * T + j; c < ld; c += tpq) drow[c] = __float2half(0.f);      // K padding of the gradient GEMMs
+}
+
 // max |gout| as the bit pattern of a non-negative float (unsigned compare == float compare); *gmax zeroed by the caller
 template <typename GT>
 __global__ __launch_bounds__(256) void msda_absmax_kernel(const GT* __restrict__ g, unsigned int* __restrict__ gmax, long n) {
@@ -496,6 +654,63 @@ extern "C" int wc_msda_bwd_h(const void* value, int value_is_f16, const int* h_s
                            (const float*)gout, gloc, gattn, sh, S, Lq, M, D, P);
         WC_LAUNCH_CHECK("msda_bwd_kernel");
     }
+    if (gout_is_f16)
+        return msda_bwd_value<__half>(loc, attn, (const __half*)gout, gvalue, gvalue16, gmax, ws, sh, n_levels, S, N, Lq, M, D, P, st);
+    return msda_bwd_value<float>(loc, attn, (const float*)gout, gvalue, gvalue16, gmax, ws, sh, n_levels, S, N, Lq, M, D, P, st);
+}
+
+// Fused forms: see msda_fwd4f_kernel / msda_bwd4f_kernel.  (n_levels, P) must be (3, 4) or (1, 4) [the CTI configurations];
+// wc_msda_fused_supported tells; value f16 or f32 as above.
+extern "C" int wc_msda_fused_supported(int n_levels, int M, int D, int P) {
+    const int tpq = M * D / 4;
+    return (P == 4 && (n_levels == 1 || n_levels == 3) && D % 4 == 0 && tpq > 0 && 256 % tpq == 0 && tpq % (D / 4) == 0) ? 1 : 0;
+}
+
+extern "C" int wc_msda_fwd_f(const void* value, int value_is_f16, const int* h_shapes, int n_levels, const float* ow, int ld,
+                             const float* bias_off, const float* bias_aw, const float* ref, int nl_ref, float* loc, float* attn,
+                             float* out, void* out16, int N, int Lq, int M, int D, int P, void* stream) {
+    MsdaShapes sh;
+    int S = 0;
+    WC_CHECK_ARG(value && h_shapes && ow && ref && loc && attn && (out || out16) && N > 0 && Lq > 0 && M > 0, "wc_msda_fwd_f: bad argument");
+    WC_CHECK_ARG(fill_shapes(&sh, h_shapes, n_levels, &S) == 0 && wc_msda_fused_supported(n_levels, M, D, P) &&
+                 ld >= 3 * M * n_levels * P && (nl_ref == 1 || nl_ref == n_levels) && (uintptr_t)value % 16 == 0 &&
+                 (!out || (uintptr_t)out % 16 == 0) && (!out16 || (uintptr_t)out16 % 8 == 0),
+                 "wc_msda_fwd_f: unsupported configuration (see wc_msda_fused_supported) or misaligned buffers");
+    const long NQ = (long)N * Lq;
+    const dim3 gd((unsigned)wc_cdiv(NQ, 256 / (M * D / 4)));
+    hipStream_t st = (hipStream_t)stream;
+#define MSDA_F(VT, NL_)                                                                                                    \
+    hipLaunchKernelGGL((msda_fwd4f_kernel<VT, NL_, 4>), gd, dim3(256), 0, st, (const VT*)value, ow, bias_off, bias_aw, ref, loc, attn, \
+                       out, (__half*)out16, sh, S, NQ, Lq, M, D, ld, nl_ref)
+    if (value_is_f16) { if (n_levels == 3) MSDA_F(__half, 3); else MSDA_F(__half, 1); }
+    else { if (n_levels == 3) MSDA_F(float, 3); else MSDA_F(float, 1); }
+#undef MSDA_F
+    WC_LAUNCH_CHECK("msda_fwd4f_kernel");
+    return WC_OK;
+}
+
+extern "C" int wc_msda_bwd_f(const void* value, int value_is_f16, const int* h_shapes, int n_levels, const float* loc,
+                             const float* attn, const void* gout, int gout_is_f16, float* gvalue, void* gvalue16, void* dow16,
+                             int ld, void* gmax, void* ws, int N, int Lq, int M, int D, int P, void* stream) {
+    MsdaShapes sh;
+    int S = 0;
+    WC_CHECK_ARG(value && h_shapes && loc && attn && gout && (gvalue || gvalue16) && dow16 && gmax && ws && N > 0 && Lq > 0 && M > 0 &&
+                 M <= 65535 && N <= 65535, "wc_msda_bwd_f: bad argument");
+    WC_CHECK_ARG(fill_shapes(&sh, h_shapes, n_levels, &S) == 0 && wc_msda_fused_supported(n_levels, M, D, P) &&
+                 ld >= 3 * M * n_levels * P && (uintptr_t)value % 16 == 0 && (uintptr_t)gout % 16 == 0,
+                 "wc_msda_bwd_f: unsupported configuration (see wc_msda_fused_supported) or misaligned buffers");
+    const long NQ = (long)N * Lq;
+    const dim3 gd((unsigned)wc_cdiv(NQ, 256 / (M * D / 4)));
+    hipStream_t st = (hipStream_t)stream;
+#define MSDA_B(VT, GT, NL_)                                                                                                \
+    hipLaunchKernelGGL((msda_bwd4f_kernel<VT, GT, NL_, 4>), gd, dim3(256), 0, st, (const VT*)value, loc, attn, (const GT*)gout, \
+                       (__half*)dow16, sh, S, NQ, Lq, M, D, ld)
+#define MSDA_B2(VT, GT) { if (n_levels == 3) MSDA_B(VT, GT, 3); else MSDA_B(VT, GT, 1); }
+    if (value_is_f16) { if (gout_is_f16) MSDA_B2(__half, __half) else MSDA_B2(__half, float) }
+    else { if (gout_is_f16) MSDA_B2(float, __half) else MSDA_B2(float, float) }
+#undef MSDA_B2
+#undef MSDA_B
+    WC_LAUNCH_CHECK("msda_bwd4f_kernel");
     if (gout_is_f16)
         return msda_bwd_value<__half>(loc, attn, (const __half*)gout, gvalue, gvalue16, gmax, ws, sh, n_levels, S, N, Lq, M, D, P, st);
     return msda_bwd_value<float>(loc, attn, (const float*)gout, gvalue, gvalue16, gmax, ws, sh, n_levels, S, N, Lq, M, D, P, st);
