@@ -259,3 +259,29 @@ def test_comer_engine_matches_fp64_evaluation_and_module_form(monkeypatch):
     assert ye < 3e-3 and me < 1e-2 and med < 5e-3, (ye, me, med)
     bad = {n: (pe[n], pm[n]) for n in pe if pe[n] > max(2e-2, 1.5 * pm[n])}
     assert not bad, bad
+
+
+def test_comer_direct_gradient_writes_equal_autograd_accumulation(monkeypatch):
+    """TrainStep lets the insert engine write its parameter gradients straight into the views of the flat all-reduce bucket
+    (CoMerInteraction.direct_grads); the bucket must equal what autograd's per-parameter accumulation produces."""
+    from oracle import synth
+    from weclip_vit_comer_amd.WeCLIP_model.model_attn_aff_voc import WeCLIP
+    from weclip_vit_comer_amd.train_step import TrainStep
+    img = synth.make_images(2, *synth.TINY_HW).cuda()
+    flats = {}
+    for direct in ("1", "0"):
+        monkeypatch.setenv("WECLIP_DIRECT_GRADS", direct)
+        torch.manual_seed(0)
+        sd = synth.make_clip_state_dict(**synth.TINY)
+        bg, fg = synth.make_text_features(20, 25, synth.TINY["embed_dim"])
+        m = WeCLIP(num_classes=21, clip_model=sd, embedding_dim=256, in_channels=[64] * 4, device="cuda",
+                   text_features=(bg.cuda(), fg.cuda()), comer=True).eval()
+        with torch.no_grad():
+            for t in m.comer.cti:
+                t.gamma.fill_(0.3)
+        step = TrainStep(m)
+        assert m.comer.direct_grads == (direct == "1")
+        step(img, labels=synth.TINY_LABELS)
+        flats[direct] = step.bucket.flat.clone()
+    assert flats["1"].abs().max().item() > 0
+    assert torch.equal(flats["1"], flats["0"])

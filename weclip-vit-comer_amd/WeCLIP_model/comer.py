@@ -247,6 +247,9 @@ class CoMerInteraction(nn.Module):
         self.cti = nn.ModuleList([CTI(dim, heads, points) for _ in stage_blocks])
         self.fuse = nn.Conv2d(2 * len(stage_blocks) * dim, dim, 1)
         self._engine = None
+        # set by train_step.TrainStep: the engine may WRITE parameter gradients into `.grad` (views of the flat all-reduce
+        # bucket, zeroed every step) instead of returning tensors that autograd adds to them one launch at a time
+        self.direct_grads = False
 
     def _forward_engine(self, img, adapter_maps, hw):
         """CUDA path: the conv stem on its autograd Functions, everything behind it as ONE explicit forward / backward

@@ -224,6 +224,15 @@ class ComerEngine:
         return y, ctx
 
     # ------------------------------------------------------------------------------------------ backward
+    def _direct(self, p):
+        """Where a parameter's gradient may be WRITTEN (not accumulated): its `.grad` when the owner opted in
+        (`CoMerInteraction.direct_grads`, set by TrainStep: the flat all-reduce bucket is zeroed every step and every gradient
+        is produced exactly once per backward), else None -> a fresh tensor handed back to autograd."""
+        if p is None or not getattr(self.net, "direct_grads", False):
+            return None
+        g = p.grad
+        return g if (g is not None and g.is_contiguous() and g.dtype == F32 and g.data_ptr() % 16 == 0) else None
+
     def _wgrad(self, dy16, x16, M, N, K, grads, pw, pb, lda=None):
         """pw.grad / pb.grad (unscaled) of y = x W^T + b from the fp16 operands dy16 (M, lda >= N) [x GS] and x16 (M, K)."""
         tiles = ((N + 127) // 128) * ((K + 1 + 127) // 128)
@@ -231,8 +240,9 @@ class ComerEngine:
         while ns * 2 * tiles <= 512 and M // (ns * 2) >= 256:
             ns *= 2
         part, ns = ops.wgrad_partials(dy16, x16, M, N, K, lda=lda, slices=ns, bias=True)
-        dw = torch.empty(N, K, device=dy16.device, dtype=F32)
-        db = torch.empty(N, device=dy16.device, dtype=F32)
+        gw, gb = self._direct(pw), self._direct(pb)
+        dw = gw.view(N, K) if gw is not None else torch.empty(N, K, device=dy16.device, dtype=F32)
+        db = gb if gb is not None else torch.empty(N, device=dy16.device, dtype=F32)
         self._pending.append((part, dw, db, ns, N, K))
         if pw is not None:
             grads[id(pw)] = dw.view(pw.shape)
@@ -264,7 +274,12 @@ class ComerEngine:
 
     def _ln_bwd(self, dy, x, ln, add, grads, want16=False):
         """dx = LN_bwd(dy) + add (f32) [and its f16 copy: the next GEMMs' operand, no separate conversion pass]."""
-        dx, dx16, dgb = ops.layernorm_bwd(dy, x, self._b(ln.weight), add=add, want32=True, want16=want16, alpha=INV, eps=ln.eps)
+        gw, gb = self._direct(ln.weight), self._direct(ln.bias)
+        dest = None
+        if gw is not None and gb is not None and gb.data_ptr() == gw.data_ptr() + 4 * gw.numel():
+            dest = torch.as_strided(gw, (2, gw.numel()), (gw.numel(), 1))       # weight / bias gradients adjacent in the bucket
+        dx, dx16, dgb = ops.layernorm_bwd(dy, x, self._b(ln.weight), add=add, want32=True, want16=want16, alpha=INV, eps=ln.eps,
+                                          dgb=dest)
         grads[id(ln.weight)], grads[id(ln.bias)] = dgb[0], dgb[1]
         return (dx, dx16) if want16 else dx
 
@@ -342,8 +357,11 @@ class ComerEngine:
             self._wgrad(dc1_16, s["g16"], Mc, C, hid, grads, m.fc2.weight, m.fc2.bias)
             dx1_16 = torch.empty(Mc, hid, device=dev, dtype=F16)
             half = hid // 2
-            dw3, db3 = torch.empty(half, 9, device=dev, dtype=F32), torch.empty(half, device=dev, dtype=F32)
-            dw5, db5 = torch.empty(half, 25, device=dev, dtype=F32), torch.empty(half, device=dev, dtype=F32)
+            dst = [self._direct(q) for q in (m.dw3.weight, m.dw3.bias, m.dw5.weight, m.dw5.bias)]
+            dw3 = dst[0].view(half, 9) if dst[0] is not None else torch.empty(half, 9, device=dev, dtype=F32)
+            db3 = dst[1] if dst[1] is not None else torch.empty(half, device=dev, dtype=F32)
+            dw5 = dst[2].view(half, 25) if dst[2] is not None else torch.empty(half, 25, device=dev, dtype=F32)
+            db5 = dst[3] if dst[3] is not None else torch.empty(half, device=dev, dtype=F32)
             npart = ctypes.c_long(0)
             lib.wc_mrfp_dwconv_parts(hs3, len(shapes), B, hid, ctypes.byref(npart))
             part = torch.empty(npart.value * hid * 26, device=dev, dtype=F32)
@@ -400,5 +418,7 @@ class ComerFunction(torch.autograd.Function):
         out = []
         for p in eng.params():
             g = grads.get(id(p))
+            if g is not None and p.grad is not None and g.data_ptr() == p.grad.data_ptr():
+                g = None                                   # written straight into the caller's gradient buffer (see _direct)
             out.append(g.reshape(p.shape) if g is not None else None)
         return (None, None, None, dc0) + tuple(d.view(s) for d, s in zip(dvs, ctx.map_shapes)) + tuple(out)

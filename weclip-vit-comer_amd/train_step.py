@@ -86,6 +86,9 @@ class TrainStep:
             # the HIP head writes every adapter/decoder gradient straight into the bucket views
             # (the bucket is zeroed each step and each gradient is written exactly once per backward)
             eng.direct_grads = {n: p.grad for n, p in zip(eng.param_names(), eng.params()) if p.grad is not None}
+        comer = getattr(model, "comer", None)
+        if self.bucket is not None and comer is not None and os.environ.get("WECLIP_DIRECT_GRADS", "1") != "0":
+            comer.direct_grads = True          # the insert engine writes its parameter gradients into the bucket views too
 
     def mask(self, h, w, device):
         key = (h, w, str(device))
