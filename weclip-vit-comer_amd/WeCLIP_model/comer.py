@@ -265,8 +265,9 @@ class CoMerInteraction(nn.Module):
 
     def forward(self, img, adapter_maps, hw):
         """adapter_maps: list of (B, h*w, dim) adapter outputs, one per ViT block; hw = (h, w)."""
-        if img.is_cuda and len(self.stage_blocks) == 4 and os.environ.get("WECLIP_COMER_ENGINE", "1") != "0":
-            return self._forward_engine(img, adapter_maps, hw)
+        from .. import config
+        if img.is_cuda and len(self.stage_blocks) == 4 and not config.exact() and os.environ.get("WECLIP_COMER_ENGINE", "1") != "0":
+            return self._forward_engine(img, adapter_maps, hw)      # (`exact` precision: the module-by-module form, hi+lo operands)
         h, w = hw
         c, shapes = self.spm(img)
         outs = []
