@@ -20,6 +20,8 @@ Outputs (committed, data only -- no reference source):
                    the discrete layer selection is decided by the data, not by fp32 rounding;
                    every stage of the CAM chain recorded by wrapping (not editing) the reference's own
                    functions: class probabilities, CAM maps, affinity, T rows, refined CAMs, PAR rows, labels
+  vitb_512_train.npz  the benchmark-size forward once more followed by the reference's losses and `loss.backward()`: loss
+                   values, the norm of every adapter / decoder gradient, ten gradient tensors in full
   augment_ref.npz  the reference's train-time input chain (datasets/transforms.py: PIL BILINEAR rescale, flip, zero-pad
                    + crop, normalise) on six small uint8 images, up- and down-scaling, with every random draw recorded
 Inputs are regenerated from oracle/synth.py seeds; each fixture stores a checksum of the
@@ -314,6 +316,62 @@ def make_vitb_512(seg_trans, sink=None):
           "layer selection:", out["keep_ref"].astype(int), "A_l:", np.round(out["A64"], 3))
 
 
+def make_vitb_512_train():
+    """BASELINE configs[2] at the benchmark resolution, trainable half: the reference's `WeCLIP.forward` (ViT-B/16-sized
+    synthetic weights, image 3 of bench.py's batch, 512x512) followed by its losses (scripts/dist_clip_voc.py:250-260:
+    bilinear up-sampling, get_seg_loss, cams_to_affinity_label + get_aff_loss) and `loss.backward()`: both loss values, the
+    norm of every adapter / decoder gradient and a few gradient tensors in full."""
+    from PIL import Image
+    import WeCLIP_model.model_attn_aff_voc as ref_voc
+    from utils.camutils import cams_to_affinity_label
+    from utils.losses import get_aff_loss
+    get_seg_loss = _script_fn("get_seg_loss")
+    get_mask_by_radius = _script_fn("get_mask_by_radius")
+    H = W = 512
+    sd = synth.make_clip_state_dict(seed=0, with_text=True)
+    img = synth.make_images(16, H, W, seed=100)[BENCH_IMG:BENCH_IMG + 1].contiguous()
+    ids = synth.make_label_lists(16, 2, seed=7)[BENCH_IMG]
+    bg, fg = synth.make_text_features(20, 25, 512)
+    fuse_sd, dec_sd = synth.make_head_state_dicts()
+    with tempfile.TemporaryDirectory() as tmp:
+        ck = os.path.join(tmp, "clip_vitb.pt")
+        torch.save(sd, ck)
+        os.makedirs(os.path.join(tmp, "SegmentationClassAug"))
+        png = np.zeros((H, W), np.uint8)
+        for j, c in enumerate(ids):
+            png[32 + 64 * j: 96 + 64 * j, 32:160] = c + 1
+        png[-3:, -3:] = 255
+        Image.fromarray(png).save(os.path.join(tmp, "SegmentationClassAug", "im.png"))
+        model = ref_voc.WeCLIP(num_classes=21, clip_model=ck, embedding_dim=256, in_channels=[768] * 4, dataset_root_path=tmp,
+                               device="cpu")
+        model.bg_text_features, model.fg_text_features = bg, fg
+        model.decoder_fts_fuse.load_state_dict(fuse_sd)
+        model.decoder.load_state_dict(dec_sd)
+        model.eval()
+        seg, cam_labels, ap = model(img, ["im"])
+    segs = torch.nn.functional.interpolate(seg, size=cam_labels.shape[1:], mode="bilinear", align_corners=False)
+    mask = get_mask_by_radius(h=H // 16, w=W // 16, radius=8)
+    aff_label = cams_to_affinity_label(cam_labels.clone(), mask=torch.from_numpy(mask), ignore_index=255)
+    attn_loss, _, _ = get_aff_loss(ap, aff_label)
+    seg_loss = get_seg_loss(segs, cam_labels.type(torch.long), ignore_index=255)
+    (seg_loss + 0.1 * attn_loss).backward()
+    grads = {}
+    for n, p in list(model.decoder.named_parameters()) + list(model.decoder_fts_fuse.named_parameters()):
+        grads[n] = p.grad
+    keep = ["linear_pred.weight", "linear_pred.bias", "transformer.resblocks.2.attn.in_proj_bias",
+            "transformer.resblocks.0.ln_1.weight", "transformer.resblocks.0.mlp.c_fc.bias", "transformer.resblocks.1.attn.out_proj.weight",
+            "linears_modulelist.10.proj_2.bias", "linears_modulelist.0.proj.bias", "linears_modulelist.5.proj_2.weight", "linear_fuse.bias"]
+    out = dict(weights_ck=checksum([sd[k] for k in sorted(sd) if k.startswith("visual")]), img_ck=checksum([img]),
+               img_index=np.int64(BENCH_IMG), ids=np.array(ids), cam_labels=cam_labels[0].numpy().astype(np.uint8),
+               attn_loss=np.float32(attn_loss.item()), seg_loss=np.float32(seg_loss.item()),
+               n_pos=np.int64((aff_label == 1).sum()), n_neg=np.int64((aff_label == 0).sum()),
+               grad_norms=np.array([float(grads[n].norm()) for n in sorted(grads)], np.float64), grad_names=np.array(sorted(grads)))
+    for n in keep:
+        out["grad:" + n] = grads[n].numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "vitb_512_train.npz"), **out)
+    print("vitb_512_train.npz written; losses", out["seg_loss"], out["attn_loss"], "labels", np.unique(out["cam_labels"], return_counts=True))
+
+
 COCO_SIZES = [(80, 112), (96, 64), (71, 100)]      # synthetic "original" image sizes (the last one is odd on purpose)
 COCO_LONG = 96                                     # --resize_long
 
@@ -515,6 +573,9 @@ if __name__ == "__main__":
         make_vitb_512(True)
         make_vitb_512(True, synth.SINK_512)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "512train":
+        make_vitb_512_train()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "512sink":
         make_vitb_512(True, synth.SINK_512)
         sys.exit(0)
@@ -525,6 +586,7 @@ if __name__ == "__main__":
     make_vitb_512(False)
     make_vitb_512(True)
     make_vitb_512(True, synth.SINK_512)
+    make_vitb_512_train()
     make_tiny_coco_msc()
     make_tiny_coco_train(False)
     make_tiny_coco_train(True)

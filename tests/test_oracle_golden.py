@@ -215,3 +215,30 @@ def test_pil_bilinear_restatement_equals_pillow():
         rw, rh = max(int(s * W), 1), max(int(s * H), 1)
         ref = np.asarray(Image.fromarray(img).resize([rw, rh], resample=Image.BILINEAR))
         assert np.array_equal(O.pil_bilinear_u8(img, rw, rh), ref), (H, W, s)
+
+
+def test_vitb_512_train_losses_and_gradients_match_reference(golden):
+    """The oracle's trainable half at the benchmark resolution (adapters, decoder, attn_pred, losses, backward) against the
+    reference's own `loss.backward()` on image 3 of the benchmark batch."""
+    g = golden("vitb_512_train.npz")
+    sd = synth.make_clip_state_dict(seed=0, with_text=False)
+    if synth.checksum([sd[k] for k in sorted(sd) if k.startswith("visual")]) != g["weights_ck"]:
+        pytest.skip("synthetic RNG stream differs from fixture")
+    i = int(g["img_index"])
+    img = synth.make_images(16, 512, 512, seed=100)[i:i + 1].contiguous()
+    bg, fg = synth.make_text_features(20, 25, 512)
+    fuse, dec = synth.make_head_state_dicts()
+    fuse = {k: v.requires_grad_(True) for k, v in fuse.items()}
+    dec = {k: v.requires_grad_(True) for k, v in dec.items()}
+    seg, labels, ap = O.weclip_forward(img, [g["ids"].tolist()], sd, fuse, dec, bg, fg, heads=12)
+    assert (labels[0].numpy() != g["cam_labels"]).mean() <= 5e-4
+    ref_labels = torch.from_numpy(g["cam_labels"].astype(np.int64))[None]
+    loss, seg_loss, attn_loss = O.train_losses(seg, ref_labels, ap)
+    assert abs(seg_loss.item() - float(g["seg_loss"])) < 1e-4 and abs(attn_loss.item() - float(g["attn_loss"])) < 1e-5
+    loss.backward()
+    grads = {**{k: v.grad for k, v in dec.items()}, **{k: v.grad for k, v in fuse.items()}}
+    names = [str(n) for n in g["grad_names"]]
+    np.testing.assert_allclose(np.array([float(grads[n].norm()) for n in names]), g["grad_norms"], rtol=2e-3, atol=1e-7)
+    for k in g.files:
+        if k.startswith("grad:"):
+            np.testing.assert_allclose(grads[k[5:]].numpy().reshape(g[k].shape), g[k], rtol=2e-3, atol=1e-6 * np.abs(g[k]).max() + 1e-9)
