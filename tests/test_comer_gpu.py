@@ -285,3 +285,47 @@ def test_comer_direct_gradient_writes_equal_autograd_accumulation(monkeypatch):
         flats[direct] = step.bucket.flat.clone()
     assert flats["1"].abs().max().item() > 0
     assert torch.equal(flats["1"], flats["0"])
+
+
+def test_comer_engine_with_adapters_inside_matches_adapter_modules():
+    """`CoMerInteraction.forward_tokens` (the four stage adapters run inside the engine, fed by the encoder's f16 block
+    outputs) against the same engine fed by the adapter MODULES' outputs (segformer_head.MLP.tokens through
+    torch.ops.weclip.linear): output and the gradients of the adapters and of a few insert parameters."""
+    from types import SimpleNamespace
+    import torch.nn as nn
+    from weclip_vit_comer_amd.WeCLIP_model.comer import CoMerInteraction
+    from weclip_vit_comer_amd.WeCLIP_model.segformer_head import MLP
+    B, H, W, dim, Cin = 2, 64, 96, 256, 128
+    h, w = H // 16, W // 16
+    Lq = h * w + 1
+    torch.manual_seed(0)
+    net = CoMerInteraction(dim).cuda()
+    ads = nn.ModuleList([MLP(Cin, dim) for _ in range(11)]).cuda()
+    with torch.no_grad():
+        for t in net.cti:
+            t.gamma.fill_(0.4)
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(B, 3, H, W, generator=g).cuda()
+    xs = [torch.randn(B * Lq, Cin, generator=g).half().cuda() for _ in range(11)]
+    gy = torch.randn(B, dim, h, w, generator=g).cuda()
+    res = {}
+    for mode in ("modules", "engine"):
+        for p in list(net.parameters()) + list(ads.parameters()):
+            p.grad = None
+        if mode == "modules":
+            toks = [ads[i].tokens(xs[i].float().view(B, Lq, Cin)[:, 1:, :]) if i in net.stage_blocks else None for i in range(11)]
+            y = net(img, toks, (h, w))
+        else:
+            y = net.forward_tokens(img, [SimpleNamespace(hi=x) for x in xs], Lq, ads, (h, w))
+        y.backward(gy)
+        res[mode] = (y.detach().clone(), {n: p.grad.clone() for n, p in list(ads.named_parameters()) + list(net.named_parameters())
+                                          if p.grad is not None})
+    rel = lambda a, b: (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+    assert set(res["modules"][1]) == set(res["engine"][1])
+    assert any(n.startswith(f"{net.stage_blocks[0]}.proj") for n in res["engine"][1])
+    e_y = rel(res["engine"][0], res["modules"][0])
+    errs = {n: rel(res["engine"][1][n], v) for n, v in res["modules"][1].items()}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print(f"adapters inside the engine vs adapter modules: y {e_y:.1e}, worst gradients {worst}")
+    assert e_y < 2e-3
+    assert all(v < 3e-2 for n, v in errs.items() if "sampling_offsets" not in n), worst

@@ -257,10 +257,30 @@ class CoMerInteraction(nn.Module):
         from ..comer_engine import ComerEngine, ComerFunction
         if self._engine is None:
             self._engine = ComerEngine(self)
+        self._engine.adapters = None
         h, w = hw
         c0, shapes = self.spm(img)
         maps = [adapter_maps[b] for b in self.stage_blocks]
         y = ComerFunction.apply(self._engine, tuple(tuple(s) for s in shapes), (h, w), c0, *maps, *self._engine.params())
+        return y.view(img.shape[0], h * w, -1).transpose(1, 2).reshape(img.shape[0], -1, h, w)
+
+    def engine_ok(self, img):
+        from .. import config
+        return img.is_cuda and len(self.stage_blocks) == 4 and not config.exact() and os.environ.get("WECLIP_COMER_ENGINE", "1") != "0"
+
+    def forward_tokens(self, img, x16, Lq, adapters, hw):
+        """The engine path fed with the encoder's own f16 block outputs: x16[b] (B*Lq, Cin) f16 token rows (CLS first per
+        image) of ViT block b, adapters[b] the WeCLIP adapter MLP of that block.  The four adapters of `stage_blocks` run inside
+        the engine (two GEMMs each way instead of the module-by-module Linear ops)."""
+        from ..comer_engine import ComerEngine, ComerTokensFunction
+        if self._engine is None:
+            self._engine = ComerEngine(self)
+        eng = self._engine
+        eng.adapters = [adapters[b] for b in self.stage_blocks]
+        h, w = hw
+        c0, shapes = self.spm(img)
+        y = ComerTokensFunction.apply(eng, tuple(tuple(s) for s in shapes), (h, w), Lq, c0, *[x16[b].hi for b in self.stage_blocks],
+                                      *eng.params())
         return y.view(img.shape[0], h * w, -1).transpose(1, 2).reshape(img.shape[0], -1, h, w)
 
     def forward(self, img, adapter_maps, hw):

@@ -117,7 +117,8 @@ class WeCLIP(nn.Module):
         seg_trans = self.iter_num > self.seg_trans_after or mode == "val"
         img = img.cuda().float().contiguous()
         hip_head = self.head_impl == "hip" and self.comer is None
-        x16 = VE.X16Stack(self.encoder.visual.transformer.layers - 1) if hip_head else None
+        comer_tokens = self.comer is not None and self.head_impl == "hip" and self.comer.engine_ok(img)
+        x16 = VE.X16Stack(self.encoder.visual.transformer.layers - 1) if (hip_head or comer_tokens) else None
         with torch.no_grad():
             want_cam = not (mode == "val" and not self.val_runs_cam)
             xs, maps, _, Lq = self.encode(img, seg_trans, x16, want_maps=want_cam)
@@ -129,7 +130,10 @@ class WeCLIP(nn.Module):
                 drop = ((torch.rand(B, self.embedding_dim, device=img.device) >= p).float() / (1.0 - p)).contiguous()
             seg, attn_pred = HeadFunction.apply(self.head_engine, x16, B, Lq, h, w, drop, *self.head_engine.params())
         else:
-            if self.comer is not None:
+            if comer_tokens:       # adapters of the four stage blocks + inserts as one engine, fed by the encoder's f16 block outputs
+                fts = self.decoder_fts_fuse.dropout(self.comer.forward_tokens(img, x16, Lq, self.decoder_fts_fuse.linears_modulelist,
+                                                                              (h, w)))
+            elif self.comer is not None:
                 used = set(self.comer.stage_blocks)       # only these adapter outputs enter the inserts
                 toks = [mlp.tokens(r.view(B, Lq, -1)[:, 1:, :]) if i in used else None for i, (mlp, r) in
                         enumerate(zip(self.decoder_fts_fuse.linears_modulelist, xs))]

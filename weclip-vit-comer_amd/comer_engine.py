@@ -42,6 +42,7 @@ class ComerEngine:
         self.net = net
         self.wc = ops.WeightCache()
         self._ref = {}
+        self.adapters = None        # the 4 WeCLIP adapter MLPs (segformer_head.MLP) when the engine also runs them (forward_tokens)
 
     # ------------------------------------------------------------------------------------------ parameters
     def params(self):
@@ -57,6 +58,8 @@ class ComerEngine:
                 out += [a.sampling_offsets.weight, a.sampling_offsets.bias, a.attention_weights.weight, a.attention_weights.bias,
                         a.value_proj.weight, a.value_proj.bias, a.output_proj.weight, a.output_proj.bias]
         out += [net.fuse.weight, net.fuse.bias]
+        for a in (self.adapters or []):
+            out += [a.proj.weight, a.proj.bias, a.proj_2.weight, a.proj_2.bias]
         return out
 
     def _mats(self):
@@ -69,6 +72,8 @@ class ComerEngine:
                 out += [(f"{tag}{i}.vp", f(a.value_proj.weight)), (f"{tag}{i}.op", f(a.output_proj.weight)),
                         (f"{tag}{i}.ow", [f(a.sampling_offsets.weight), f(a.attention_weights.weight)])]
         out.append(("fuse", f(self.net.fuse.weight).flatten(1)))
+        for i, a in enumerate(self.adapters or []):
+            out += [(f"a{i}.p1", f(a.proj.weight)), (f"a{i}.p2", f(a.proj_2.weight))]
         return out
 
     def ref_points(self, shapes, dev):
@@ -139,9 +144,11 @@ class ComerEngine:
         return ops.colscale_split(x, cs, rows, want32=False, with_lo=False, alpha=alpha)[1].hi
 
     # ------------------------------------------------------------------------------------------ forward
-    def forward(self, c0, shapes, hw, maps):
-        """c0 (B, S, C) pyramid tokens of the stem; shapes [(H, W)] x 3; maps: the 4 adapter outputs (B, h*w, C).
-        -> (y rows (B*h*w, C) f32, ctx)."""
+    def forward(self, c0, shapes, hw, maps, x16=None, Lq=None):
+        """c0 (B, S, C) pyramid tokens of the stem; shapes [(H, W)] x 3; maps: the 4 adapter outputs (B, h*w, C) -- or, with
+        `self.adapters` set, x16: the 4 encoder block outputs (B*Lq, Cin) f16 (CLS row first per image, straight from the
+        encoder's epilogue) from which the engine computes the adapter outputs proj_2(relu(proj(tokens))) itself
+        (WeCLIP_model/segformer_head.py:13-28).  -> (y rows (B*h*w, C) f32, ctx)."""
         net = self.net
         B, S, C = c0.shape
         h, w = hw
@@ -167,7 +174,17 @@ class ComerEngine:
             m, t = net.mrfp[i], net.cti[i]
             hid = m.fc1.weight.shape[0]
             s = {}
-            v = maps[i].detach().float().contiguous().view(Mv, C)
+            if x16 is not None:        # the WeCLIP adapter of this stage's ViT block, on the patch rows of the f16 tokens
+                ad = self.adapters[i]
+                Cin = x16[i].shape[1]
+                t1 = torch.empty(Mv, C, device=dev, dtype=F16)
+                ops.gemm(x16[i].view(-1)[Cin:], W(f"a{i}.p1"), nhw, C, Cin, bias=self._b(ad.proj.bias), out16=t1, act=2, batch=B,
+                         sA=Lq * Cin, sW=0, sC=nhw * C)
+                v = torch.empty(Mv, C, device=dev, dtype=F32)
+                ops.gemm(t1, W(f"a{i}.p2"), Mv, C, C, bias=self._b(ad.proj_2.bias), out32=v)
+                s.update(t1=t1, x16=x16[i], Lq=Lq)
+            else:
+                v = maps[i].detach().float().contiguous().view(Mv, C)
             # ---- MRFP: c1 = c + fc2(gelu(dwconv(fc1(c))))
             x1 = torch.empty(Mc, hid, device=dev, dtype=F32)
             ops.gemm(c16, W(f"m{i}.fc1"), Mc, hid, C, bias=self._b(m.fc1.bias), out32=x1)
@@ -233,13 +250,13 @@ class ComerEngine:
         g = p.grad
         return g if (g is not None and g.is_contiguous() and g.dtype == F32 and g.data_ptr() % 16 == 0) else None
 
-    def _wgrad(self, dy16, x16, M, N, K, grads, pw, pb, lda=None):
+    def _wgrad(self, dy16, x16, M, N, K, grads, pw, pb, lda=None, xmap=None):
         """pw.grad / pb.grad (unscaled) of y = x W^T + b from the fp16 operands dy16 (M, lda >= N) [x GS] and x16 (M, K)."""
         tiles = ((N + 127) // 128) * ((K + 1 + 127) // 128)
         ns = 1
         while ns * 2 * tiles <= 512 and M // (ns * 2) >= 256:
             ns *= 2
-        part, ns = ops.wgrad_partials(dy16, x16, M, N, K, lda=lda, slices=ns, bias=True)
+        part, ns = ops.wgrad_partials(dy16, x16, M, N, K, lda=lda, slices=ns, bias=True, xmap=xmap)
         gw, gb = self._direct(pw), self._direct(pb)
         dw = gw.view(N, K) if gw is not None else torch.empty(N, K, device=dy16.device, dtype=F32)
         db = gb if gb is not None else torch.empty(N, device=dy16.device, dtype=F32)
@@ -347,6 +364,14 @@ class ComerEngine:
             ops.gemm(dow1, WT(f"v{i}.ow"), Mv, C, s["ld1"], out32=dq1)
             self._ow_grads(dow1, s["q1"], Mv, s["n1"], s["ld1"], t.to_v, grads)
             dvs[i] = self._ln_bwd(dq1, s["v"], t.nv_q, dv1, grads)
+            if "t1" in s:              # the adapter MLP behind v: v = t1 W2^T + b2, t1 = relu(x W1^T + b1); x is frozen
+                ad = self.adapters[i]
+                dv16 = self._f16(dvs[i])
+                self._wgrad(dv16, s["t1"], Mv, C, C, grads, ad.proj_2.weight, ad.proj_2.bias)
+                dt1 = torch.empty(Mv, C, device=dev, dtype=F16)
+                ops.gemm(dv16, WT(f"a{i}.p2"), Mv, C, C, out16=dt1, act=5, auxh=s["t1"], ldaux=C)
+                self._wgrad(dt1, s["x16"], Mv, C, s["x16"].shape[1], grads, ad.proj.weight, ad.proj.bias, xmap=(nhw, s["Lq"], 1))
+                dvs[i] = None
             df1 = torch.empty(Mc, C, device=dev, dtype=F32)
             ops.gemm(dval1_16, WT(f"v{i}.vp"), Mc, C, C, out32=df1)
             self._wgrad(dval1_16, s["f1"], Mc, C, C, grads, t.to_v.value_proj.weight, t.to_v.value_proj.bias)
@@ -398,7 +423,7 @@ class ComerEngine:
             grads[id(t.gamma)] = (Wop * G).sum(1) + bop * gsum
         self._ow_jobs, self._gamma_jobs = None, None
         B, S, C = ctx["B"], ctx["S"], ctx["C"]
-        return (dc0 * INV).view(B, S, C), [d * INV for d in dvs], grads
+        return (dc0 * INV).view(B, S, C), [d * INV if d is not None else None for d in dvs], grads
 
 
 class ComerFunction(torch.autograd.Function):
@@ -422,3 +447,26 @@ class ComerFunction(torch.autograd.Function):
                 g = None                                   # written straight into the caller's gradient buffer (see _direct)
             out.append(g.reshape(p.shape) if g is not None else None)
         return (None, None, None, dc0) + tuple(d.view(s) for d, s in zip(dvs, ctx.map_shapes)) + tuple(out)
+
+
+class ComerTokensFunction(torch.autograd.Function):
+    """The same with the four WeCLIP adapters inside the engine: (c0, 4 frozen f16 token tensors, params...) -> fused rows."""
+
+    @staticmethod
+    def forward(ctx, engine, shapes, hw, Lq, c0, x0, x1, x2, x3, *params):
+        y, c = engine.forward(c0, shapes, hw, None, x16=[x0, x1, x2, x3], Lq=Lq)
+        ctx.engine, ctx.c = engine, c
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        eng = ctx.engine
+        dc0, _, grads = eng.run_backward(ctx.c, dy.contiguous())
+        ctx.c = None
+        out = []
+        for p in eng.params():
+            g = grads.get(id(p))
+            if g is not None and p.grad is not None and g.data_ptr() == p.grad.data_ptr():
+                g = None
+            out.append(g.reshape(p.shape) if g is not None else None)
+        return (None, None, None, None, dc0, None, None, None, None) + tuple(out)
