@@ -15,27 +15,55 @@
 //                        fixed order), then dx; per-channel dgamma / dbeta partials per (n, row block), summed in order.
 #include "common.h"
 
+// One thread = 8 consecutive columns of one row (Kp % 8 == 0): the row is decoded once, the eight values leave as ONE 16-byte
+// store per output (round 2 wrote 2 bytes per thread: 1.2 TB/s on the 134 MB of the first layer); with C % 8 == 0 the eight
+// columns share a tap and come from two 16-byte loads.
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, __half* __restrict__ hi,
                                                       __half* __restrict__ lo, int N, int H, int W, int C, int Ho, int Wo,
                                                       int stride, int Kp, long total) {
-    const int K = 9 * C;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int col = (int)(i % Kp);
-        const long row = i / Kp;
-        float v = 0.f;
-        if (col < K) {
-            const int tap = col / C, c = col - tap * C;
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const int ox = (int)(row % Wo);
-            const long r2 = row / Wo;
-            const int oy = (int)(r2 % Ho);
-            const long n = r2 / Ho;
-            const int iy = oy * stride - 1 + ky, ix = ox * stride - 1 + kx;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((n * H + iy) * W + ix) * C + c];
+    const int K = 9 * C, K8 = Kp >> 3;
+    const bool vec = (C & 7) == 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (total >> 3); i += (long)gridDim.x * 256) {
+        const int col0 = (int)(i % K8) * 8;
+        const long row = i / K8;
+        const int ox = (int)(row % Wo);
+        const long r2 = row / Wo;
+        const int oy = (int)(r2 % Ho);
+        const long n = r2 / Ho;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (vec) {
+            if (col0 < K) {
+                const int tap = col0 / C, c = col0 - tap * C;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const int iy = oy * stride - 1 + ky, ix = ox * stride - 1 + kx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                    const float4* p = reinterpret_cast<const float4*>(x + ((n * H + iy) * W + ix) * C + c);
+                    const float4 a4 = p[0], b4 = p[1];
+                    v[0] = a4.x; v[1] = a4.y; v[2] = a4.z; v[3] = a4.w; v[4] = b4.x; v[5] = b4.y; v[6] = b4.z; v[7] = b4.w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int col = col0 + j;
+                if (col < K) {
+                    const int tap = col / C, c = col - tap * C;
+                    const int ky = tap / 3, kx = tap - ky * 3;
+                    const int iy = oy * stride - 1 + ky, ix = ox * stride - 1 + kx;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v[j] = x[((n * H + iy) * W + ix) * C + c];
+                }
+            }
         }
-        const __half h = __float2half(v);
-        hi[i] = h;
-        if (lo) lo[i] = __float2half(v - __half2float(h));
+        __half h[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            h[j] = __float2half(v[j]);
+            l[j] = __float2half(v[j] - __half2float(h[j]));
+        }
+        *reinterpret_cast<u32x4*>(hi + i * 8) = *reinterpret_cast<const u32x4*>(h);
+        if (lo) *reinterpret_cast<u32x4*>(lo + i * 8) = *reinterpret_cast<const u32x4*>(l);
     }
 }
 
@@ -69,46 +97,63 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
 }
 
 // ---- GroupNorm + ReLU on rows (n, HW, C), G groups of Cg = C / G channels --------------------------------------
-#define GN_ROWS 64      // rows of one partial block
+// Round 3: a thread owns ONE channel and a row lane (consecutive lanes = consecutive channels: coalesced NHWC rows, no
+// per-element division), the row lanes meet in LDS in a fixed order, group sums are formed from the channel sums.  The
+// round-2 kernels walked the block once per group with two block reductions each and the backward a second time with one
+// thread per channel (126 us per launch at 16 x 256 x 256 x 32).  Needs 256 % C == 0 (C = 32, 64, 128 in the stem).
+#define GN_ROWS 256      // rows of one partial block (the callers size their buffers for 64: more than enough)
 
 // part[(n*nblk + blk)*G + g] = (sum, sumsq) of rows [blk*GN_ROWS, ...) of image n, group g       (grid: nblk, N)
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, float2* __restrict__ part, int HW,
                                                           int C, int G) {
-    __shared__ float red[16];
+    __shared__ float2 red[256];
     const int blk = blockIdx.x, n = blockIdx.y, nblk = gridDim.x;
-    const int Cg = C / G;
+    const int Cg = C / G, c = threadIdx.x % C, rl = threadIdx.x / C, nrl = 256 / C;
     const int r0 = blk * GN_ROWS, r1 = min(r0 + GN_ROWS, HW);
-    for (int g = 0; g < G; ++g) {
-        float s = 0.f, q = 0.f;
-        const int cnt = (r1 - r0) * Cg;
-        for (int e = threadIdx.x; e < cnt; e += 256) {
-            const int r = r0 + e / Cg, c = g * Cg + e % Cg;
-            const float v = x[((long)n * HW + r) * C + c];
-            s += v;
-            q += v * v;
-        }
-        s = block_sum(s, red);
-        q = block_sum(q, red);
-        if (threadIdx.x == 0) part[((long)n * nblk + blk) * G + g] = make_float2(s, q);
+    float s = 0.f, q = 0.f;
+    const float* xp = x + (long)n * HW * C + c;
+    for (int r = r0 + rl; r < r1; r += nrl) {
+        const float v = xp[(long)r * C];
+        s += v;
+        q += v * v;
+    }
+    red[threadIdx.x] = make_float2(s, q);
+    __syncthreads();
+    if (threadIdx.x < C) {                    // channel sums: the row lanes in a fixed order
+        float2 t = red[threadIdx.x];
+        for (int k = 1; k < nrl; ++k) { t.x += red[k * C + threadIdx.x].x; t.y += red[k * C + threadIdx.x].y; }
+        red[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float2 t = make_float2(0.f, 0.f);
+        for (int k = 0; k < Cg; ++k) { t.x += red[threadIdx.x * Cg + k].x; t.y += red[threadIdx.x * Cg + k].y; }
+        part[((long)n * nblk + blk) * G + threadIdx.x] = t;
     }
 }
 
-// stats[n*G + g] = (mean, rstd): serial, fixed-order sum of the partials                       (grid: N*G threads)
-__global__ void gn_finish_kernel(const float2* __restrict__ part, float2* __restrict__ stats, int nblk, int G, int N,
-                                 float count, float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * G) return;
-    const int n = i / G, g = i - n * G;
+// stats[n*G + g] = (mean, rstd): fixed-order sum of the partials, one 64-thread workgroup per (n, g)      (grid: N*G)
+__global__ __launch_bounds__(64) void gn_finish_kernel(const float2* __restrict__ part, float2* __restrict__ stats, int nblk, int G,
+                                                        int N, float count, float eps) {
+    __shared__ double sh[2][64];
+    const int i = blockIdx.x, n = i / G, g = i - n * G;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = threadIdx.x; b < nblk; b += 64) {
         const float2 p = part[((long)n * nblk + b) * G + g];
         s += p.x;
         q += p.y;
     }
-    const double mean = s / count;
-    double var = q / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[i] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = 0.0; q = 0.0;
+        for (int k = 0; k < 64; ++k) { s += sh[0][k]; q += sh[1][k]; }
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[i] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+    }
 }
 
 __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restrict__ x, const float2* __restrict__ stats,
@@ -124,41 +169,39 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restric
     }
 }
 
-// backward partials: per (n, blk): group sums (sum g, sum g*xhat) with g = dy*mask*gamma, and per channel
-// (sum dy*mask*xhat, sum dy*mask)                                                                (grid: nblk, N)
+// backward partials: per (n, blk): per channel (sum d*xhat, sum d) with d = dy*mask, and from them the group sums
+// (sum g, sum g*xhat) with g = d*gamma: sum_rows g = gamma_c * sum d, sum_rows g*xhat = gamma_c * sum d*xhat     (grid: nblk, N)
 __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                               const float* __restrict__ dy, const float2* __restrict__ stats,
                                                               const float* __restrict__ gamma, float2* __restrict__ gpart,
                                                               float2* __restrict__ cpart, int HW, int C, int G) {
-    __shared__ float red[16];
+    __shared__ float2 red[256];
     const int blk = blockIdx.x, n = blockIdx.y, nblk = gridDim.x;
-    const int Cg = C / G;
+    const int Cg = C / G, c = threadIdx.x % C, rl = threadIdx.x / C, nrl = 256 / C;
     const int r0 = blk * GN_ROWS, r1 = min(r0 + GN_ROWS, HW);
-    for (int g = 0; g < G; ++g) {
-        const float2 st = stats[n * G + g];
-        float s = 0.f, q = 0.f;
-        const int cnt = (r1 - r0) * Cg;
-        for (int e = threadIdx.x; e < cnt; e += 256) {
-            const int r = r0 + e / Cg, c = g * Cg + e % Cg;
-            const long o = ((long)n * HW + r) * C + c;
-            const float gg = (y[o] > 0.f ? dy[o] : 0.f) * gamma[c];
-            s += gg;
-            q += gg * (x[o] - st.x) * st.y;
-        }
-        s = block_sum(s, red);
-        q = block_sum(q, red);
-        if (threadIdx.x == 0) gpart[((long)n * nblk + blk) * G + g] = make_float2(s, q);
+    const float2 st = stats[n * G + c / Cg];
+    float a = 0.f, b = 0.f;
+    const long base = (long)n * HW * C + c;
+    for (int r = r0 + rl; r < r1; r += nrl) {
+        const long o = base + (long)r * C;
+        const float d = y[o] > 0.f ? dy[o] : 0.f;
+        a += d * (x[o] - st.x) * st.y;
+        b += d;
     }
-    for (int c = threadIdx.x; c < C; c += 256) {           // channel sums over this block's rows, serial per channel
-        const float2 st = stats[n * G + c / Cg];
-        float a = 0.f, b = 0.f;
-        for (int r = r0; r < r1; ++r) {
-            const long o = ((long)n * HW + r) * C + c;
-            const float d = y[o] > 0.f ? dy[o] : 0.f;
-            a += d * (x[o] - st.x) * st.y;
-            b += d;
-        }
-        cpart[((long)n * nblk + blk) * C + c] = make_float2(a, b);
+    red[threadIdx.x] = make_float2(a, b);
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float2 t = red[threadIdx.x];
+        for (int k = 1; k < nrl; ++k) { t.x += red[k * C + threadIdx.x].x; t.y += red[k * C + threadIdx.x].y; }
+        cpart[((long)n * nblk + blk) * C + threadIdx.x] = t;
+        const float gm = gamma[threadIdx.x];
+        red[threadIdx.x] = make_float2(gm * t.y, gm * t.x);          // (sum g, sum g*xhat) of this channel
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float2 t = make_float2(0.f, 0.f);
+        for (int k = 0; k < Cg; ++k) { t.x += red[threadIdx.x * Cg + k].x; t.y += red[threadIdx.x * Cg + k].y; }
+        gpart[((long)n * nblk + blk) * G + threadIdx.x] = t;
     }
 }
 
@@ -223,8 +266,9 @@ extern "C" int wc_im2col3x3(const float* x, void* cols_hi, void* cols_lo, int N,
                  "wc_im2col3x3: bad argument (stride 1 or 2, Kp >= 9 C and a multiple of 64)");
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const long total = (long)N * Ho * Wo * Kp;
-    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (__half*)cols_hi, (__half*)cols_lo,
-                       N, H, W, C, Ho, Wo, stride, Kp, total);
+    WC_CHECK_ARG(((uintptr_t)cols_hi | (uintptr_t)cols_lo | (uintptr_t)x) % 16 == 0, "wc_im2col3x3: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total >> 3)), dim3(256), 0, (hipStream_t)stream, x, (__half*)cols_hi,
+                       (__half*)cols_lo, N, H, W, C, Ho, Wo, stride, Kp, total);
     WC_LAUNCH_CHECK("im2col_kernel");
     return WC_OK;
 }
@@ -242,13 +286,13 @@ extern "C" int wc_col2im3x3(const float* dcols, float* dx, int N, int H, int W, 
 
 extern "C" int wc_groupnorm_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
                                      float* part, int N, int HW, int C, int G, float eps, void* stream) {
-    WC_CHECK_ARG(x && gamma && beta && y && stats && part && N > 0 && N <= 65535 && HW > 0 && C > 0 && G > 0 && C % G == 0,
-                 "wc_groupnorm_relu_fwd: bad argument");
+    WC_CHECK_ARG(x && gamma && beta && y && stats && part && N > 0 && N <= 65535 && HW > 0 && C > 0 && G > 0 && C % G == 0 &&
+                 C <= 256 && 256 % C == 0, "wc_groupnorm_relu_fwd: bad argument (C must divide 256)");
     hipStream_t st = (hipStream_t)stream;
     const int nblk = wc_cdiv(HW, GN_ROWS);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, N), dim3(256), 0, st, x, (float2*)part, HW, C, G);
     WC_LAUNCH_CHECK("gn_partial_kernel");
-    hipLaunchKernelGGL(gn_finish_kernel, dim3(wc_cdiv(N * G, 64)), dim3(64), 0, st, (const float2*)part, (float2*)stats, nblk, G, N,
+    hipLaunchKernelGGL(gn_finish_kernel, dim3(N * G), dim3(64), 0, st, (const float2*)part, (float2*)stats, nblk, G, N,
                        (float)((double)HW * (C / G)), eps);
     WC_LAUNCH_CHECK("gn_finish_kernel");
     const long total = (long)N * HW * C;
@@ -262,7 +306,7 @@ extern "C" int wc_groupnorm_relu_bwd(const float* x, const float* y, const float
                                      float* dx, float* dgamma, float* dbeta, float* gpart, float* cpart, float* gsum, int N,
                                      int HW, int C, int G, void* stream) {
     WC_CHECK_ARG(x && y && dy && stats && gamma && dx && dgamma && dbeta && gpart && cpart && gsum && N > 0 && N <= 65535 &&
-                 HW > 0 && C > 0 && G > 0 && C % G == 0, "wc_groupnorm_relu_bwd: bad argument");
+                 HW > 0 && C > 0 && G > 0 && C % G == 0 && C <= 256 && 256 % C == 0, "wc_groupnorm_relu_bwd: bad argument (C must divide 256)");
     hipStream_t st = (hipStream_t)stream;
     const int nblk = wc_cdiv(HW, GN_ROWS);
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nblk, N), dim3(256), 0, st, x, y, dy, (const float2*)stats, gamma,

@@ -1248,9 +1248,16 @@ __global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict
                                                           int nslices, long n, float alpha) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < nslices; ++k) s += part[(long)k * n + i];
-    out[i] = s * alpha;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // 4 slice loads in flight (a serial chain ran at one load latency per slice)
+    int k = 0;
+    for (; k + 4 <= nslices; k += 4) {
+        s0 += part[(long)k * n + i];
+        s1 += part[(long)(k + 1) * n + i];
+        s2 += part[(long)(k + 2) * n + i];
+        s3 += part[(long)(k + 3) * n + i];
+    }
+    for (; k < nslices; ++k) s0 += part[(long)k * n + i];
+    out[i] = ((s0 + s1) + (s2 + s3)) * alpha;
 }
 
 // Same reduction for a weight-gradient GEMM whose operand carried a ones row: part is (slices, rows, cols+1),
