@@ -67,16 +67,21 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
     }
 }
 
+// one thread = 4 consecutive channels of one input pixel (C % 4 == 0: 16-byte loads / store), else one channel
+template <int V>
 __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcols, float* __restrict__ dx, int N, int H,
                                                       int W, int C, int Ho, int Wo, int stride, int Kp, long total) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const long p = i / C;
+    const int CV = C / V;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total / V; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % CV) * V;
+        const long p = i / CV;
         const int ix = (int)(p % W);
         const long p2 = p / W;
         const int iy = (int)(p2 % H);
         const long n = p2 / H;
-        float acc = 0.f;
+        float acc[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] = 0.f;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int ty = iy + 1 - ky;
@@ -89,10 +94,17 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
                 if (tx < 0 || tx % stride) continue;
                 const int ox = tx / stride;
                 if (ox >= Wo) continue;
-                acc += dcols[((n * Ho + oy) * Wo + ox) * Kp + (ky * 3 + kx) * C + c];
+                const float* src = dcols + ((n * Ho + oy) * Wo + ox) * Kp + (ky * 3 + kx) * C + c;
+                if constexpr (V == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(src);
+                    acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
+                } else {
+                    acc[0] += src[0];
+                }
             }
         }
-        dx[i] = acc;
+        if constexpr (V == 4) *reinterpret_cast<float4*>(dx + i * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        else dx[i] = acc[0];
     }
 }
 
@@ -156,10 +168,28 @@ __global__ __launch_bounds__(64) void gn_finish_kernel(const float2* __restrict_
     }
 }
 
+// four consecutive channels per thread (C % 4 == 0 and Cg % 4 == 0 in the stem: 32 / 8 = 4 channels per group at least)
 __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restrict__ x, const float2* __restrict__ stats,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ y, int HW, int C, int G, long total) {
     const int Cg = C / G;
+    if ((C & 3) == 0 && (Cg & 3) == 0) {
+        const long per = (long)HW * C;
+        for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long)gridDim.x * 1024) {
+            const int c = (int)(i % C);
+            const long n = i / per;
+            const float2 st = stats[n * G + c / Cg];
+            const float4 xv = *reinterpret_cast<const float4*>(x + i), gm = *reinterpret_cast<const float4*>(gamma + c),
+                         bt = *reinterpret_cast<const float4*>(beta + c);
+            float4 o;
+            o.x = fmaxf((xv.x - st.x) * st.y * gm.x + bt.x, 0.f);
+            o.y = fmaxf((xv.y - st.x) * st.y * gm.y + bt.y, 0.f);
+            o.z = fmaxf((xv.z - st.x) * st.y * gm.z + bt.z, 0.f);
+            o.w = fmaxf((xv.w - st.x) * st.y * gm.w + bt.w, 0.f);
+            *reinterpret_cast<float4*>(y + i) = o;
+        }
+        return;
+    }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c = (int)(i % C);
         const long n = i / ((long)HW * C);
@@ -244,6 +274,26 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict_
                                                          float* __restrict__ dx, int HW, int C, int G, float count,
                                                          long total) {
     const int Cg = C / G;
+    if ((C & 3) == 0 && (Cg & 3) == 0) {
+        const long per = (long)HW * C;
+        const float ic = 1.f / count;
+        for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long)gridDim.x * 1024) {
+            const int c = (int)(i % C);
+            const long n = i / per;
+            const int g = c / Cg;
+            const float2 st = stats[n * G + g], gs = gsum[n * G + g];
+            const float4 xv = *reinterpret_cast<const float4*>(x + i), yv = *reinterpret_cast<const float4*>(y + i),
+                         dv = *reinterpret_cast<const float4*>(dy + i), gm = *reinterpret_cast<const float4*>(gamma + c);
+            float4 o;
+            o.x = st.y * ((yv.x > 0.f ? dv.x : 0.f) * gm.x - (gs.x + (xv.x - st.x) * st.y * gs.y) / count);
+            o.y = st.y * ((yv.y > 0.f ? dv.y : 0.f) * gm.y - (gs.x + (xv.y - st.x) * st.y * gs.y) / count);
+            o.z = st.y * ((yv.z > 0.f ? dv.z : 0.f) * gm.z - (gs.x + (xv.z - st.x) * st.y * gs.y) / count);
+            o.w = st.y * ((yv.w > 0.f ? dv.w : 0.f) * gm.w - (gs.x + (xv.w - st.x) * st.y * gs.y) / count);
+            (void)ic;
+            *reinterpret_cast<float4*>(dx + i) = o;
+        }
+        return;
+    }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c = (int)(i % C);
         const long n = i / ((long)HW * C);
@@ -278,8 +328,12 @@ extern "C" int wc_col2im3x3(const float* dcols, float* dx, int N, int H, int W, 
                  "wc_col2im3x3: bad argument");
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const long total = (long)N * H * W * C;
-    hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dcols, dx, N, H, W, C, Ho, Wo,
-                       stride, Kp, total);
+    if (C % 4 == 0 && Kp % 4 == 0 && ((uintptr_t)dcols | (uintptr_t)dx) % 16 == 0)
+        hipLaunchKernelGGL(col2im_kernel<4>, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream, dcols, dx, N, H, W, C, Ho, Wo,
+                           stride, Kp, total);
+    else
+        hipLaunchKernelGGL(col2im_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dcols, dx, N, H, W, C, Ho, Wo,
+                           stride, Kp, total);
     WC_LAUNCH_CHECK("col2im_kernel");
     return WC_OK;
 }
