@@ -2,7 +2,7 @@
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import synth
+from weclip_vit_comer_amd import synth
 from weclip_vit_comer_amd import config
 from weclip_vit_comer_amd.WeCLIP_model.model_attn_aff_voc import WeCLIP
 g = np.load("tests/golden/vitb_512.npz")
