@@ -8,12 +8,17 @@ bidirectional CTI exchanges features with the ViT branch through multi-scale def
   CTI-toC:  c <- c + MSDeformAttn(LN(c), LN(v));  c <- c + FFN(LN(c))
 Per the brief the ViT stays frozen and the *WeCLIP adapter outputs* (256-d maps of those blocks) are
 the ViT-side features; the 8 CTI outputs (4 toV maps + 4 toC 1/16 maps) are channel-concatenated and
-fused by a 1x1 conv into the decoder input.  Everything here is trainable.  The deformable-attention
-core runs on the HIP kernels of csrc/msdeform.hip (forward gather + backward scatter); every Linear / 1x1
-conv / LayerNorm around it goes through hip_functional.py (MFMA GEMM forward, input / weight / bias gradients,
-LayerNorm forward / backward); the depth-wise convs are csrc/dwconv.hip and the 3x3 stride-2 stem convs +
-GroupNorm + ReLU are csrc/convstem.hip.  Parity is pinned only against oracle/comer_oracle.py and stock torch
-modules (no reference exists).
+fused by a 1x1 conv into the decoder input.  Everything here is trainable.
+
+Two implementations of the same arithmetic:
+  * the ENGINE (comer_engine.py; the CUDA path in `fast` precision): everything behind the conv stem as one explicit
+    forward / backward on fused HIP launches (csrc/comer.hip, msdeform.hip, gemm.hip), optionally including the four
+    stage adapters (`forward_tokens`);
+  * the MODULE-BY-MODULE form below (the CPU path, `exact` precision, `WECLIP_COMER_ENGINE=0`): the deformable-attention
+    core on csrc/msdeform.hip, every Linear / 1x1 conv / LayerNorm through hip_functional.py (registered custom ops with
+    autograd: MFMA GEMM forward, input / weight / bias gradients), depth-wise convs on csrc/dwconv.hip.
+The 3x3 stride-2 stem convs + GroupNorm + ReLU (csrc/convstem.hip) are shared.  Parity is pinned only against
+oracle/comer_oracle.py, stock torch modules and an fp64 evaluation of this network (no reference code exists).
 """
 import math
 import os

@@ -18,8 +18,11 @@ and element-wise glue; this engine runs the same arithmetic on token rows end to
     (gemm_km), their reductions collected into one launch, gradients carried multiplied by GRAD_SCALE like the head's.
 
 The conv stem (`SpatialPrior`) stays on its autograd Functions (hip_functional.conv3x3_rows / groupnorm_relu_rows); the
-engine starts from its output and hands its gradient back.  Parity: against the module-by-module form
-(tests/test_comer_gpu.py), which is itself pinned only to oracle/comer_oracle.py and stock torch ("parity unpinned").
+engine starts from its output and hands its gradient back.  With `adapters` set (`CoMerInteraction.forward_tokens`) the four
+WeCLIP adapter MLPs of the stage blocks run inside the engine on the encoder's f16 block outputs, and with
+`CoMerInteraction.direct_grads` (set by train_step.TrainStep) every parameter gradient is written straight into the views of
+the flat all-reduce bucket.  Parity: against an fp64 CPU evaluation of the same network and the module-by-module form
+(tests/test_comer_gpu.py); no reference code exists ("parity unpinned").  Runs in `fast` precision (single fp16 operands).
 """
 import ctypes
 
