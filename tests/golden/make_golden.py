@@ -20,6 +20,9 @@ Outputs (committed, data only -- no reference source):
                    the discrete layer selection is decided by the data, not by fp32 rounding;
                    every stage of the CAM chain recorded by wrapping (not editing) the reference's own
                    functions: class probabilities, CAM maps, affinity, T rows, refined CAMs, PAR rows, labels
+  vitb_320.npz     the same whole forward at the REFERENCE'S OWN default geometry (crop 320, batch 4: scripts/dist_clip_voc.py:34,
+                   configs/voc_attn_reg.yaml:5): image 1 of a 4 x 320 x 320 batch (L = 401 tokens: neither a multiple of the
+                   attention tiles nor the CLS-only remainder of 512 x 512)
   vitb_512_train.npz  the benchmark-size forward once more followed by the reference's losses and `loss.backward()`: loss
                    values, the norm of every adapter / decoder gradient, ten gradient tensors in full
   augment_ref.npz  the reference's train-time input chain (datasets/transforms.py: PIL BILINEAR rescale, flip, zero-pad
@@ -222,7 +225,7 @@ def make_vitb_224():
 BENCH_IMG = 3          # image of bench.py's batch (synth.make_images(16, 512, 512, seed=100)) the 512x512 fixture is made of
 
 
-def make_vitb_512(seg_trans, sink=None):
+def make_vitb_512(seg_trans, sink=None, size=512, batch=16, index=None, seed=100, label_seed=7, fn_override=None):
     """Whole reference `WeCLIP.forward` at the benchmark size on ONE image of the benchmark batch.  The
     intermediate stages are recorded by wrapping the reference's own callables at generation time
     (GradCAM.__call__, compute_trans_mat, perform_single_voc_cam, PAR.forward); nothing is edited."""
@@ -231,10 +234,11 @@ def make_vitb_512(seg_trans, sink=None):
     import WeCLIP_model.model_attn_aff_voc as ref_voc
     from pytorch_grad_cam.base_cam import BaseCAM
 
-    H = W = 512
+    H = W = size
+    IDX = BENCH_IMG if index is None else index
     sd = synth.make_clip_state_dict(seed=0, with_text=True, cls_sink=sink)
-    img = synth.make_images(16, H, W, seed=100)[BENCH_IMG:BENCH_IMG + 1].contiguous()
-    ids = synth.make_label_lists(16, 2, seed=7)[BENCH_IMG]
+    img = synth.make_images(batch, H, W, seed=seed)[IDX:IDX + 1].contiguous()
+    ids = synth.make_label_lists(batch, 2, seed=label_seed)[IDX]
     bg, fg = synth.make_text_features(20, 25, 512)
     fuse_sd, dec_sd = synth.make_head_state_dicts()
     rec = {"cam": [], "probs": [], "attn_last": [], "trans_in": [], "trans_out": [], "refined": [], "par_in": [], "par_out": []}
@@ -293,7 +297,7 @@ def make_vitb_512(seg_trans, sink=None):
     keep_ref = attn_diff <= torch.mean(attn_diff)
     A64 = aw.double().flatten(1).sum(1)
     out = dict(keep_ref=keep_ref.numpy(), diff_ref=attn_diff.numpy(), A64=A64.numpy(), weights_ck=checksum([sd[k] for k in sorted(sd) if k.startswith("visual")]), img_ck=checksum([img]),
-               img_index=np.int64(BENCH_IMG), ids=np.array(ids),
+               img_index=np.int64(IDX), ids=np.array(ids),
                fts_last_rows=fts[-1][::64, 0].numpy().astype(np.float32),       # (17, 768): every 64th token of block 11
                fts5_rows=fts[5][::128, 0].numpy().astype(np.float32),
                attn10_rows=attns[10][0, ::128].numpy(), attn_last_rows=rec["attn_last"][0][::128],
@@ -311,6 +315,9 @@ def make_vitb_512(seg_trans, sink=None):
         assert seg_trans
         fn = "vitb_512_seg_sink.npz"
         out["cls_sink"] = np.array(sink, np.float64)
+    if fn_override:
+        fn = fn_override
+        out.update(size=np.int64(size), batch=np.int64(batch), seed=np.int64(seed), label_seed=np.int64(label_seed))
     np.savez_compressed(os.path.join(OUT, fn), **out)
     print(fn, "written; probs:", out["probs"][:, :2], "labels:", np.unique(out["cam_labels"], return_counts=True),
           "layer selection:", out["keep_ref"].astype(int), "A_l:", np.round(out["A64"], 3))
@@ -362,7 +369,7 @@ def make_vitb_512_train():
             "transformer.resblocks.0.ln_1.weight", "transformer.resblocks.0.mlp.c_fc.bias", "transformer.resblocks.1.attn.out_proj.weight",
             "linears_modulelist.10.proj_2.bias", "linears_modulelist.0.proj.bias", "linears_modulelist.5.proj_2.weight", "linear_fuse.bias"]
     out = dict(weights_ck=checksum([sd[k] for k in sorted(sd) if k.startswith("visual")]), img_ck=checksum([img]),
-               img_index=np.int64(BENCH_IMG), ids=np.array(ids), cam_labels=cam_labels[0].numpy().astype(np.uint8),
+               img_index=np.int64(IDX), ids=np.array(ids), cam_labels=cam_labels[0].numpy().astype(np.uint8),
                attn_loss=np.float32(attn_loss.item()), seg_loss=np.float32(seg_loss.item()),
                n_pos=np.int64((aff_label == 1).sum()), n_neg=np.int64((aff_label == 0).sum()),
                grad_norms=np.array([float(grads[n].norm()) for n in sorted(grads)], np.float64), grad_names=np.array(sorted(grads)))
@@ -573,6 +580,9 @@ if __name__ == "__main__":
         make_vitb_512(True)
         make_vitb_512(True, synth.SINK_512)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "320":
+        make_vitb_512(False, size=320, batch=4, index=1, seed=320, label_seed=9, fn_override="vitb_320.npz")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "512train":
         make_vitb_512_train()
         sys.exit(0)
@@ -587,6 +597,7 @@ if __name__ == "__main__":
     make_vitb_512(True)
     make_vitb_512(True, synth.SINK_512)
     make_vitb_512_train()
+    make_vitb_512(False, size=320, batch=4, index=1, seed=320, label_seed=9, fn_override="vitb_320.npz")
     make_tiny_coco_msc()
     make_tiny_coco_train(False)
     make_tiny_coco_train(True)

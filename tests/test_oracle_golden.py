@@ -242,3 +242,23 @@ def test_vitb_512_train_losses_and_gradients_match_reference(golden):
     for k in g.files:
         if k.startswith("grad:"):
             np.testing.assert_allclose(grads[k[5:]].numpy().reshape(g[k].shape), g[k], rtol=2e-3, atol=1e-6 * np.abs(g[k]).max() + 1e-9)
+
+
+def test_vitb_320_reference_default_crop(golden):
+    """The oracle's whole forward at the reference's own default geometry (320 x 320) against the reference's."""
+    g = golden("vitb_320.npz")
+    sd = synth.make_clip_state_dict(seed=0, with_text=False)
+    if synth.checksum([sd[k] for k in sorted(sd) if k.startswith("visual")]) != g["weights_ck"]:
+        pytest.skip("synthetic RNG stream differs from fixture")
+    i, S3, B3 = int(g["img_index"]), int(g["size"]), int(g["batch"])
+    img = synth.make_images(B3, S3, S3, seed=int(g["seed"]))[i:i + 1].contiguous()
+    ids = synth.make_label_lists(B3, 2, seed=int(g["label_seed"]))[i]
+    assert ids == g["ids"].tolist()
+    bg, fg = synth.make_text_features(20, 25, 512)
+    fuse, dec = synth.make_head_state_dicts()
+    with torch.no_grad():
+        seg, labels, ap, aux = O.weclip_forward(img, [ids], sd, fuse, dec, bg, fg, heads=12, return_aux=True)
+    np.testing.assert_allclose(aux[0]["probs"][0], g["probs"][0], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(aux[0]["refined"], g["refined"], rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(seg[0].numpy(), g["seg"], rtol=0, atol=2e-4)
+    assert (labels[0].numpy() != g["cam_labels"]).mean() <= 5e-4
