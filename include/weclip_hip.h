@@ -166,6 +166,13 @@ int wc_gemm_plan(int M, int N, int K, int nseg, int batch);
  * Process-wide; for benchmarks and tests (the environment variables WECLIP_GEMM_P192 / WECLIP_GEMM_P192_COST set the
  * initial values). */
 void wc_gemm_set_p192(int mode, float cost);
+/* MFMA shape of the 256x256 kernel: 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16 (same schedule, operand bytes and
+ * accumulator registers; fp32 sums of 32 instead of 16 products per instruction, so results differ in the last fp32 bits).
+ * Process-wide; initial value from WECLIP_GEMM_M16. */
+void wc_gemm_set_m16(int on);
+/* 256x256 tiles on the 4-wave kernel (128x128 wave tiles, operands through registers: global_load -> ds_write) instead of the
+ * 8-wave LDS-DMA ping-pong kernel.  Process-wide; initial value from WECLIP_GEMM_W4. */
+void wc_gemm_set_w4(int on);
 /* out[i] = alpha * sum_s part[s*n + i]: reduction of split-K partial products (the slices are a
  * batched wc_gemm_f16 over K ranges: sA = sW = K/slices, sC = M*N). */
 int wc_sum_slices(const float* part, float* out, int nslices, long n, float alpha, void* stream);

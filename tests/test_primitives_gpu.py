@@ -172,6 +172,70 @@ def test_gemm_tall_192_column_tile(ops, M, N, K, nseg):
     assert _rel(o2["z"].float().cpu().double(), ref * torch.sigmoid(1.702 * ref)) < 1e-3
 
 
+@pytest.mark.parametrize("variant", ["m16", "w4"])
+@pytest.mark.parametrize("M,N,K,nseg", [(16400, 768, 768, 1), (16640, 2304, 768, 1), (16400, 1024, 128, 1), (16400, 768, 128, 3)])
+def test_gemm_tall_kernel_variants(ops, variant, M, N, K, nseg):
+    """The two opt-in builds of the 256x256 tile (round 3): `m16` = the LDS-DMA kernel on v_mfma_f32_16x16x32_f16 (another
+    accumulator layout through every epilogue path), `w4` = four waves of 128x128, operands through registers.  Each epilogue
+    path against the fp64 product and, to fp32 accumulation-order accuracy, against the default kernel: wide fp16 (hi + lo,
+    bias, column scale), narrow fp32 + residual (forced-fp16 rounding; fp32 + fp16), QuickGELU + saved pre-activation, ReLU' aux;
+    two K-tiles (K = 128), three segments, ragged and whole row counts."""
+    import ctypes
+    from weclip_vit_comer_amd import _lib as L
+    cd = L.lib().cdll
+    for f in (cd.wc_gemm_set_m16, cd.wc_gemm_set_w4):
+        f.argtypes, f.restype = [ctypes.c_int], None
+    _set_p192(0)
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    a = ops.Split(torch.randn(M, K, generator=g).half().cuda(), (torch.randn(M, K, generator=g) * 1e-3).half().cuda() if nseg > 1 else None)
+    w = ops.Split((torch.randn(N, K, generator=g) * 0.05).half().cuda(), (torch.randn(N, K, generator=g) * 5e-5).half().cuda() if nseg > 2 else None)
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    saved = torch.randn(M, N, generator=g).half().cuda()
+    ref = a.hi.double() @ w.hi.double().t()
+    if nseg > 1:
+        ref += a.lo.double() @ w.hi.double().t()
+    if nseg > 2:
+        ref += a.hi.double() @ w.lo.double().t()
+    ref = (ref + bias.double()).cpu()
+
+    def run(on):
+        cd.wc_gemm_set_m16(1 if on and variant == "m16" else 0)
+        cd.wc_gemm_set_w4(1 if on and variant == "w4" else 0)
+        o = {}
+        o["h"], o["l"] = torch.zeros(M, N, device="cuda", dtype=torch.float16), torch.zeros(M, N, device="cuda", dtype=torch.float16)
+        ops.gemm(a, w, M, N, K, bias=bias, out16=o["h"], out16lo=o["l"], scale=0.18, scale_cols=N // 3)
+        o["x1"] = torch.zeros(M, N, device="cuda")
+        ops.gemm(a, w, M, N, K, bias=bias, resid=res, out32=o["x1"], round16=True)
+        o["x2"], o["x2h"] = torch.zeros(M, N, device="cuda"), torch.zeros(M, N, device="cuda", dtype=torch.float16)
+        ops.gemm(a, w, M, N, K, bias=bias, resid=res, out32=o["x2"], out16=o["x2h"])
+        o["z"], o["u"] = torch.zeros(M, N, device="cuda", dtype=torch.float16), torch.zeros(M, N, device="cuda")
+        ops.gemm(a, w, M, N, K, bias=bias, out16=o["z"], act=1, pre32=o["u"])
+        o["r"] = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+        ops.gemm(a, w, M, N, K, out16=o["r"], act=5, auxh=saved, ldaux=N)
+        torch.cuda.synchronize()
+        return o
+
+    try:
+        assert cd.wc_gemm_plan(M, N, K, nseg, 1) in (1, 2)
+        o0 = run(False)
+        o1 = run(True)
+    finally:
+        cd.wc_gemm_set_m16(0)
+        cd.wc_gemm_set_w4(0)
+        _set_p192(1)
+    for k in o0:      # same products, another fp32 summation order: a few fp32 ulps of the sum, one fp16 ulp on the fp16 outputs
+        d = (o0[k].float() - o1[k].float()).abs().max().item()
+        assert d <= 2e-3 * max(1.0, o0[k].float().abs().max().item()), (k, d)
+    sc = torch.ones(N, dtype=torch.float64)
+    sc[:N // 3] = 0.18
+    assert _rel((o1["h"].float() + o1["l"].float()).cpu().double(), ref * sc) < 2e-6
+    assert _rel(o1["x2"].cpu().double(), ref + res.cpu().double()) < 2e-6
+    assert _rel(o1["u"].cpu().double(), ref) < 2e-6
+    assert _rel(o1["z"].float().cpu().double(), ref * torch.sigmoid(1.702 * ref)) < 1e-3
+    assert _rel(o1["r"].float().cpu().double(), (ref - bias.cpu().double()) * (saved.cpu().double() > 0)) < 1e-3
+
+
 def test_gemm_ragged_rows_split(ops):
     """65 x 4 tiles of 256x256 on 256 CUs: the 16 ragged rows go to a second launch (128x128 kernel);
     residual / fp16 hi+lo outputs / saved pre-activation must line up across the seam."""

@@ -21,6 +21,7 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define BM 128
 #define BN 128
@@ -96,12 +97,38 @@ __device__ __forceinline__ void gemm_colvals(const GemmArgs& g, int n0, int wc, 
     }
 }
 
+// The same for the 16x16 MFMA layout (L16 below): a lane owns FOUR columns of the 64-wide block, 16 apart.
+__device__ __forceinline__ void gemm_colvals16(const GemmArgs& g, int n0, int wc, int lane, float (&bv)[4], float (&sc)[4]) {
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+        const int col = n0 + wc * 64 + ci * 16 + (lane & 15);
+        const int colc = col < g.N ? col : g.N - 1;
+        bv[ci] = g.bias ? g.bias[colc] : 0.f;
+        sc[ci] = (col < g.scale_cols) ? g.scale : 1.0f;
+        if (g.cscale) sc[ci] *= g.cscale[colc];
+    }
+}
+
 // NI = column tiles (of 32) of the wave's block: 2 (64 x 64) or 1 (64 x 32: the third column tile of the 256x192 kernel).
-template <bool AUX, int NI = 2>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][NI], int m0, int n0, int wr, int wc,
-                                              int lane, long zb, char* scratch, const float (&bv)[2],
-                                              const float (&sc)[2], long cb, long xb = 0) {
+// L16: the accumulators come from v_mfma_f32_16x16x32_f16.  A 32x32 block is then FOUR 16x16 tiles (tr, tc) packed into the
+// same 16 registers, r = (tr*2 + tc)*4 + i, holding row tr*16 + (lane>>4)*4 + i, column tc*16 + (lane&15); registers 8c'..8c'+7
+// still cover the rows [16c', 16c'+16) of the block, so the chunking of the wide path is unchanged, and a lane's per-column
+// constants are bv / sc[ni*2 + tc] (gemm_colvals16).
+template <int NI>
+__device__ __forceinline__ float epi_acc(const f32x16 (&acc)[2][NI], int mi, int ni, int r) { return acc[mi][ni][r]; }
+template <int NI>
+__device__ __forceinline__ float epi_acc(const f32x4 (&acc)[2][NI][4], int mi, int ni, int r) { return acc[mi][ni][r >> 2][r & 3]; }
+
+template <bool AUX, int NI = 2, bool L16 = false, class ACC>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, ACC& acc, int m0, int n0, int wr, int wc,
+                                              int lane, long zb, char* scratch, const float (&bv)[L16 ? 2 * NI : 2],
+                                              const float (&sc)[L16 ? 2 * NI : 2], long cb, long xb = 0) {
     const int act = g.act;
+    // layout of accumulator register r (0..15) of block (mi, ni): row inside the 32-row block, column inside the 64-wide block,
+    // index of the lane's per-column constants
+#define EPI_ROW(r_) (L16 ? ((((r_) >> 3) << 4) + ((lane >> 4) << 2) + ((r_) & 3)) : (((r_) & 3) + 8 * (((r_) >> 2) & 3) + 4 * (lane >> 5)))
+#define EPI_COL(ni_, r_) (L16 ? ((ni_) * 32 + ((((r_) >> 2) & 1) << 4) + (lane & 15)) : ((ni_) * 32 + (lane & 31)))
+#define EPI_CI(ni_, r_) (L16 ? ((ni_) * 2 + (((r_) >> 2) & 1)) : (ni_))
     const bool has_res = g.resid != nullptr;
     const bool r16 = g.round16 != 0;
     if (g.vec && !g.P32 && g.C16 && !g.C32) {   // fp32 outputs are already 128-B coalesced per half-wave: measured slower there
@@ -149,21 +176,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int rr = 0; rr < 8; ++rr) v[ni * 8 + rr] = acc[mi][ni][rq0 + rr] + bv[ni];
+                for (int rr = 0; rr < 8; ++rr) v[ni * 8 + rr] = epi_acc<NI>(acc, mi, ni, rq0 + rr) + bv[EPI_CI(ni, rr)];
             if (r16) {
 #pragma unroll
                 for (int e = 0; e < NI * 8; ++e) v[e] = __half2float(__float2half(v[e]));
             }
             if (has_sc) {
 #pragma unroll
-                for (int e = 0; e < NI * 8; ++e) v[e] *= sc[e >> 3];
+                for (int e = 0; e < NI * 8; ++e) v[e] *= sc[EPI_CI(e >> 3, e & 7)];
             }
             if constexpr (!AUX) { WC_EPI_ACT(v, NI * 8) }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int rr = 0; rr < 8; ++rr)
-                    tile[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * 64 + ni * 32 + (lane & 31)] = v[ni * 8 + rr];
+                    tile[EPI_ROW(rr) * 64 + EPI_COL(ni, rr)] = v[ni * 8 + rr];      // (rr < 8: rows 0..15 of the chunk)
             // same wave reads what it wrote: LDS ops of a wave complete in order, no barrier needed
             float f[4][4];
             bool ok[4];
@@ -250,12 +277,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                const int col = n0 + wc * 64 + ni * 32 + (lane & 31);
-                const int colc = col < g.N ? col : g.N - 1;
-                const int rbase = m0 + wr * 64 + mi * 32 + 4 * (lane >> 5);
+                const int rbase = m0 + wr * 64 + mi * 32;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    int row = rbase + (r & 3) + 8 * (r >> 2);
+                    const int col = n0 + wc * 64 + EPI_COL(ni, r);
+                    const int colc = col < g.N ? col : g.N - 1;
+                    int row = rbase + EPI_ROW(r);
                     if (row > g.M - 1) row = g.M - 1;
                     rva[AUX ? 0 : mi][AUX ? 0 : ni][r] = g.resid[zb * g.sR + (long)row * g.ldr + colc];
                 }
@@ -265,27 +292,35 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            const int col = n0 + wc * 64 + ni * 32 + (lane & 31);
-            const bool colok = col < g.N;
-            const int colc = colok ? col : g.N - 1;
-            const int rbase = m0 + wr * 64 + mi * 32 + 4 * (lane >> 5);
+            // a lane's columns of this block: one (32x32 layout) or two, 16 apart (L16)
+            int colv[2], colcv[2];
+            bool colokv[2];
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc) {
+                colv[tc] = n0 + wc * 64 + EPI_COL(ni, tc * 4);
+                colokv[tc] = colv[tc] < g.N;
+                colcv[tc] = colokv[tc] ? colv[tc] : g.N - 1;
+            }
+#define EPI_TC(r_) (L16 ? (((r_) >> 2) & 1) : 0)
+            const int rbase = m0 + wr * 64 + mi * 32;
             float uv[16], v[16], pre[16];
             float (&rv)[16] = rva[AUX ? 0 : mi][AUX ? 0 : ni];
             if constexpr (AUX) {      // the aux variants are register-bound: residual per block
                 if (has_res) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        int row = rbase + (r & 3) + 8 * (r >> 2);
+                        int row = rbase + EPI_ROW(r);
                         if (row > g.M - 1) row = g.M - 1;
-                        rv[r] = g.resid[zb * g.sR + (long)row * g.ldr + colc];
+                        rv[r] = g.resid[zb * g.sR + (long)row * g.ldr + colcv[EPI_TC(r)]];
                     }
                 }
             }
             if constexpr (AUX) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    int row = rbase + (r & 3) + 8 * (r >> 2);
+                    int row = rbase + EPI_ROW(r);
                     if (row > g.M - 1) row = g.M - 1;
+                    const int colc = colcv[EPI_TC(r)];
                     if (act == 4) {
                         const long arow = g.rowmap ? (long)g.rowmap[(row + g.row0) / g.rpg] * g.rpg + (row + g.row0) % g.rpg : row;
                         const float u = g.aux[arow * g.ldaux + colc];
@@ -301,13 +336,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = acc[mi][ni][r] + bv[ni];
+            for (int r = 0; r < 16; ++r) v[r] = epi_acc<NI>(acc, mi, ni, r) + bv[EPI_CI(ni, r)];
             if (r16) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = __half2float(__float2half(v[r]));
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { v[r] *= sc[ni]; pre[r] = v[r]; }
+            for (int r = 0; r < 16; ++r) { v[r] *= sc[EPI_CI(ni, r)]; pre[r] = v[r]; }
             if constexpr (AUX) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] *= uv[r];
@@ -318,39 +353,40 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] += rv[r];
             }
-            const long o0 = cb + (long)rbase * g.ldc + col;
+            // element r lives at o0 + drow(r) * ldc + (its column - the lane's first column)
+            const long o0 = cb + (long)rbase * g.ldc + colv[0];
+#define EPI_OFF(r_) ((long)EPI_ROW(r_) * g.ldc + (EPI_TC(r_) ? 16 : 0))
+#define EPI_OK(r_) (colokv[EPI_TC(r_)] && rbase + EPI_ROW(r_) < g.M)
             if (g.P32) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dr = (r & 3) + 8 * (r >> 2);
-                    if (colok && rbase + dr < g.M) g.P32[o0 + (long)dr * g.ldc] = pre[r];
-                }
+                for (int r = 0; r < 16; ++r)
+                    if (EPI_OK(r)) g.P32[o0 + EPI_OFF(r)] = pre[r];
             }
             if (g.C32) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int dr = (r & 3) + 8 * (r >> 2);
                     // (non-temporal here was measured on the step and is slightly slower: the fp32 outputs are the
                     // residual stream, re-read at once by the LayerNorm that follows)
-                    if (colok && rbase + dr < g.M) g.C32[o0 + (long)dr * g.ldc] = v[r];
+                    if (EPI_OK(r)) g.C32[o0 + EPI_OFF(r)] = v[r];
                 }
             }
             if (g.C16) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dr = (r & 3) + 8 * (r >> 2);
-                    if (colok && rbase + dr < g.M) g.C16[o0 + (long)dr * g.ldc] = __float2half(v[r]);
-                }
+                for (int r = 0; r < 16; ++r)
+                    if (EPI_OK(r)) g.C16[o0 + EPI_OFF(r)] = __float2half(v[r]);
                 if (g.C16lo) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int dr = (r & 3) + 8 * (r >> 2);
-                        if (colok && rbase + dr < g.M)
-                            g.C16lo[o0 + (long)dr * g.ldc] = __float2half(v[r] - __half2float(__float2half(v[r])));
-                    }
+                    for (int r = 0; r < 16; ++r)
+                        if (EPI_OK(r)) g.C16lo[o0 + EPI_OFF(r)] = __float2half(v[r] - __half2float(__float2half(v[r])));
                 }
             }
         }
+#undef EPI_OFF
+#undef EPI_OK
+#undef EPI_TC
+#undef EPI_ROW
+#undef EPI_COL
+#undef EPI_CI
 }
 
 // Main kernel.  Operand tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging and no
@@ -600,8 +636,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
 // the LDS-DMA of half-tile p+6 between its MFMAs; a slot is re-staged at least two phases after its last read.
 // The two row groups run one barrier apart: while the waves of one group multiply (and issue DMA), the other
 // group's waves (their SIMD neighbours) read fragments, so LDS reads, DMA and MFMA overlap.
+//
+// M16 (round 3): the same schedule on v_mfma_f32_16x16x32_f16 -- per phase 16 MFMAs of 16 cycles instead of 8 of 32, the same
+// fragment bytes (a 16-B fragment is now 16 rows x 8 of the 32 k of an MFMA: lane l reads row l & 15, 16-B chunk l >> 4; the
+// XOR swizzle is conflict-free for that pattern as well) and the same 128 accumulator registers.  The matrix pipe takes the
+// same cycles either way; what differs is the clock the chip holds under the load (MI355X_MICROARCH.md, DVFS item 7).
 #define PP_SLOT 16384
-template <bool AUX>
+template <bool AUX, bool M16>
 __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 8 half-tile slots [128 rows][64 halfs], XOR-swizzled
     const int tid = threadIdx.x, lane = tid & 63;
@@ -622,7 +663,9 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
     const int m0 = ty * 256, n0 = tx * 256;
 
     // per-thread DMA sources of the four half-tile kinds (two 16-B chunks each)
-    long offA0[2], offA1[2], offB0[2], offB1[2];
+    // (32-bit BYTE offsets from the operand's base: the launcher keeps operands of 4 GiB and more off this kernel; with a
+    // uniform 64-bit base the LDS-DMA takes them as its 32-bit VGPR offset, no 64-bit vector add per instruction)
+    unsigned offA0[2], offA1[2], offB0[2], offB1[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int q = i * 512 + tid;                 // chunk index inside the half-tile image
@@ -632,8 +675,8 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
         int b0 = n0 + (row >> 5) * 64 + (row & 31), b1 = b0 + 32;
         a0 = a0 < g.M ? a0 : g.M - 1; a1 = a1 < g.M ? a1 : g.M - 1;
         b0 = b0 < g.N ? b0 : g.N - 1; b1 = b1 < g.N ? b1 : g.N - 1;
-        offA0[i] = (long)a0 * g.lda + c * 8; offA1[i] = (long)a1 * g.lda + c * 8;
-        offB0[i] = (long)b0 * g.ldw + c * 8; offB1[i] = (long)b1 * g.ldw + c * 8;
+        offA0[i] = (unsigned)(((long)a0 * g.lda + c * 8) * 2); offA1[i] = (unsigned)(((long)a1 * g.lda + c * 8) * 2);
+        offB0[i] = (unsigned)(((long)b0 * g.ldw + c * 8) * 2); offB1[i] = (unsigned)(((long)b1 * g.ldw + c * 8) * 2);
     }
     const int ktiles = g.K / BK;
     const int nt = ktiles * g.nseg;
@@ -647,11 +690,12 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
         const long k0__ = (long)((t_) - seg__ * ktiles) * BK;                                                 \
         const __half* P__ = ((q_) == 0 || (q_) == 3) ? (seg__ == 0 ? g.A[0] : (seg__ == 1 ? g.A[1] : g.A[2])) \
                                                      : (seg__ == 0 ? g.W[0] : (seg__ == 1 ? g.W[1] : g.W[2])); \
-        const long o0__ = (q_) == 0 ? offA0[0] : (q_) == 1 ? offB0[0] : (q_) == 2 ? offB1[0] : offA1[0];      \
-        const long o1__ = (q_) == 0 ? offA0[1] : (q_) == 1 ? offB0[1] : (q_) == 2 ? offB1[1] : offA1[1];      \
+        const unsigned o0__ = (q_) == 0 ? offA0[0] : (q_) == 1 ? offB0[0] : (q_) == 2 ? offB1[0] : offA1[0];  \
+        const unsigned o1__ = (q_) == 0 ? offA0[1] : (q_) == 1 ? offB0[1] : (q_) == 2 ? offB1[1] : offA1[1];  \
         char* d__ = smem + (slot_) * PP_SLOT + wave * 1024;                                                   \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(P__ + o0__ + k0__), (lds_ptr)d__, 16, 0, 0);               \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(P__ + o1__ + k0__), (lds_ptr)(d__ + 8192), 16, 0, 0);      \
+        const char* B__ = reinterpret_cast<const char*>(P__ + k0__);                                          \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(B__ + o0__), (lds_ptr)d__, 16, 0, 0);                      \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(B__ + o1__), (lds_ptr)(d__ + 8192), 16, 0, 0);             \
     }
     // leave the n_ newest half-tiles (2 DMA instructions each) in flight
 #define PP_WAIT(n_)                                                                 \
@@ -664,29 +708,45 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       \
     }
     // fragment read addresses (bytes inside a slot): A rows wr*64 + mi*32 + l31, B rows wc*32 + l31
-    const int hh = lane >> 5, l31 = lane & 31;
+    // M16: fragment x of a 32-row block is (row tile tr = x >> 1, k half x & 1): rows tr*16 + (lane & 15), chunk (x & 1)*4 + (lane >> 4)
+    const int hh = lane >> 5, l31 = lane & 31, q16 = lane >> 4, l15 = lane & 15;
     int aaddr[2][4], baddr[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-            const int ra = wr * 64 + mi * 32 + l31;
-            aaddr[mi][ks] = ra * 128 + (((2 * ks + hh) ^ ((ra >> 1) & 7)) << 4);
+            const int ra = M16 ? wr * 64 + mi * 32 + (ks >> 1) * 16 + l15 : wr * 64 + mi * 32 + l31;
+            const int ch = M16 ? (ks & 1) * 4 + q16 : 2 * ks + hh;
+            aaddr[mi][ks] = ra * 128 + ((ch ^ ((ra >> 1) & 7)) << 4);
         }
-        const int rb = wc * 32 + l31;
-        baddr[ks] = rb * 128 + (((2 * ks + hh) ^ ((rb >> 1) & 7)) << 4);
+        const int rb = M16 ? wc * 32 + (ks >> 1) * 16 + l15 : wc * 32 + l31;
+        const int ch = M16 ? (ks & 1) * 4 + q16 : 2 * ks + hh;
+        baddr[ks] = rb * 128 + ((ch ^ ((rb >> 1) & 7)) << 4);
     }
-    f32x16 acc[2][2][2];      // [row half a][mi][column half b]
+    f32x16 acc[M16 ? 1 : 2][2][2];      // [row half a][mi][column half b]
+    f32x4 acc4[M16 ? 2 : 1][2][2][4];   // M16: [a][mi][b][tr*2 + tc]
+    if constexpr (M16) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
-    float bv[2], sc[2];
-    gemm_colvals(g, n0, wc, lane, 0, bv, sc);
+                    for (int r = 0; r < 4; ++r) acc4[a][i][j][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
+    }
+    float bv[M16 ? 4 : 2], sc[M16 ? 4 : 2];
+    if constexpr (M16) gemm_colvals16(g, n0, wc, lane, bv, sc);
+    else gemm_colvals(g, n0, wc, lane, 0, bv, sc);
 
     // prologue: half-tiles 0..5 (nt >= 2 is guaranteed by the launcher), the first two landed
     PP_STAGE(0, 0, 0); PP_STAGE(0, 1, 1); PP_STAGE(0, 2, 2); PP_STAGE(0, 3, 3); PP_STAGE(1, 0, 4); PP_STAGE(1, 1, 5);
@@ -703,12 +763,26 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
 #define PP_READ_B(fb_, slot_)                                                                                 \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                          \
         fb_[ks] = *reinterpret_cast<const f16x8*>(smem + (slot_) * PP_SLOT + baddr[ks]);
+    // M16: MFMA (k2, mi, tr, tc) multiplies fragment fa[mi][tr*2 + k2] with fb[tc*2 + k2] into acc4[a][mi][b][tr*2 + tc]; the
+    // quarter q_ (0..3) of a phase is k half k2 = q_ >> 1, mi = q_ & 1: four MFMAs on four different accumulators
+#define PP_MMA16_Q(a_, fb_, b_, q_)                                                                           \
+    _Pragma("unroll") for (int tt = 0; tt < 4; ++tt)                                                          \
+        acc4[a_][(q_) & 1][b_][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                  \
+            fa[(q_) & 1][(tt >> 1) * 2 + ((q_) >> 1)], fb_[(tt & 1) * 2 + ((q_) >> 1)], acc4[a_][(q_) & 1][b_][tt], 0, 0, 0);
+#define PP_PIN16(a_, b_)                                                                                      \
+    asm volatile("" : "+v"(acc4[a_][0][b_][0]), "+v"(acc4[a_][0][b_][1]), "+v"(acc4[a_][0][b_][2]), "+v"(acc4[a_][0][b_][3]),  \
+                      "+v"(acc4[a_][1][b_][0]), "+v"(acc4[a_][1][b_][1]), "+v"(acc4[a_][1][b_][2]), "+v"(acc4[a_][1][b_][3]));
 #define PP_MMA(a_, fb_, b_)                                                                                   \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                        \
-        acc[a_][0][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][ks], fb_[ks], acc[a_][0][b_], 0, 0, 0); \
-        acc[a_][1][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][ks], fb_[ks], acc[a_][1][b_], 0, 0, 0); \
-    }                                                                                                         \
-    asm volatile("" : "+v"(acc[a_][0][b_]), "+v"(acc[a_][1][b_]));   /* keeps the MFMAs inside their phase */
+    if constexpr (M16) {                                                                                      \
+        PP_MMA16_Q(a_, fb_, b_, 0) PP_MMA16_Q(a_, fb_, b_, 1) PP_MMA16_Q(a_, fb_, b_, 2) PP_MMA16_Q(a_, fb_, b_, 3) \
+        PP_PIN16(a_, b_)                                                                                      \
+    } else {                                                                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                    \
+            acc[a_][0][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][ks], fb_[ks], acc[a_][0][b_], 0, 0, 0); \
+            acc[a_][1][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][ks], fb_[ks], acc[a_][1][b_], 0, 0, 0); \
+        }                                                                                                     \
+        asm volatile("" : "+v"(acc[a_][0][b_]), "+v"(acc[a_][1][b_]));   /* keeps the MFMAs inside their phase */ \
+    }
     // one phase of the guarded form (last K-tiles): [fragment reads] -> DMA of half-tile phi+6 -> counted wait ->
     // barrier -> 8 MFMAs -> barrier
 #define PP_PHASE(phi_, READS_, tj_, qj_, slotj_, MMA_)                                                        \
@@ -740,10 +814,12 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
         const long k0__ = (long)((t_) - seg__ * ktiles) * BK;                                                 \
         const __half* P__ = ((q_) == 0 || (q_) == 3) ? (seg__ == 0 ? g.A[0] : (seg__ == 1 ? g.A[1] : g.A[2])) \
                                                      : (seg__ == 0 ? g.W[0] : (seg__ == 1 ? g.W[1] : g.W[2])); \
-        const long o__ = (q_) == 0 ? offA0[h_] : (q_) == 1 ? offB0[h_] : (q_) == 2 ? offB1[h_] : offA1[h_];   \
+        unsigned o__ = (q_) == 0 ? offA0[h_] : (q_) == 1 ? offB0[h_] : (q_) == 2 ? offB1[h_] : offA1[h_];     \
+        asm volatile("" : "+v"(o__));      /* keeps the 32-bit offset a 32-bit register (no hoisted 64-bit copy) */ \
         char* d__ = smem + (slot_) * PP_SLOT + wave * 1024 + (h_) * 8192;                                     \
+        const char* B__ = reinterpret_cast<const char*>(P__ + k0__);                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(P__ + o__ + k0__), (lds_ptr)d__, 16, 0, 0);                \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(B__ + o__), (lds_ptr)d__, 16, 0, 0);                       \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     }
 #define PP_PHASE_S(READS_, tj_, qj_, slotj_, a_, fb_, b_)                                                     \
@@ -755,13 +831,22 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         __builtin_amdgcn_s_setprio(1);                                                                        \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                    \
-            acc[a_][0][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][ks], fb_[ks], acc[a_][0][b_], 0, 0, 0); \
-            acc[a_][1][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][ks], fb_[ks], acc[a_][1][b_], 0, 0, 0); \
-            if (ks == 0) PP_STAGE_H(tj_, qj_, slotj_, 0)                                                      \
-            if (ks == 2) PP_STAGE_H(tj_, qj_, slotj_, 1)                                                      \
+        if constexpr (M16) {                                                                                  \
+            PP_MMA16_Q(a_, fb_, b_, 0)                                                                        \
+            PP_STAGE_H(tj_, qj_, slotj_, 0)                                                                   \
+            PP_MMA16_Q(a_, fb_, b_, 1) PP_MMA16_Q(a_, fb_, b_, 2)                                             \
+            PP_STAGE_H(tj_, qj_, slotj_, 1)                                                                   \
+            PP_MMA16_Q(a_, fb_, b_, 3)                                                                        \
+            PP_PIN16(a_, b_)                                                                                  \
+        } else {                                                                                              \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                \
+                acc[a_][0][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][ks], fb_[ks], acc[a_][0][b_], 0, 0, 0); \
+                acc[a_][1][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][ks], fb_[ks], acc[a_][1][b_], 0, 0, 0); \
+                if (ks == 0) PP_STAGE_H(tj_, qj_, slotj_, 0)                                                  \
+                if (ks == 2) PP_STAGE_H(tj_, qj_, slotj_, 1)                                                  \
+            }                                                                                                 \
+            asm volatile("" : "+v"(acc[a_][0][b_]), "+v"(acc[a_][1][b_]));                                    \
         }                                                                                                     \
-        asm volatile("" : "+v"(acc[a_][0][b_]), "+v"(acc[a_][1][b_]));                                        \
         __builtin_amdgcn_s_setprio(0);                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         __builtin_amdgcn_s_barrier();                                                                         \
@@ -797,14 +882,216 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
     }
 #undef PP_PHASE
 #undef PP_MMA
+#undef PP_MMA16_Q
+#undef PP_PIN16
 #undef PP_READ_A
 #undef PP_READ_B
 #undef PP_WAIT
 #undef PP_STAGE
     if (wr == 0) __builtin_amdgcn_s_barrier();       // re-align the two row groups
     __syncthreads();                                 // every wave is done with the operand slots: epilogue scratch
-    gemm_epilogue<AUX>(g, acc[0], m0 + wr * 128, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc, 0);
-    gemm_epilogue<AUX>(g, acc[1], m0 + wr * 128 + 64, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc, 0);
+    if constexpr (M16) {      // (the epilogue reads the 16x16 tiles as register r = (tr*2 + tc)*4 + i of a 32x32 block)
+        gemm_epilogue<AUX, 2, true>(g, acc4[0], m0 + wr * 128, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc, 0);
+        gemm_epilogue<AUX, 2, true>(g, acc4[1], m0 + wr * 128 + 64, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc, 0);
+    } else {
+        gemm_epilogue<AUX, 2, false>(g, acc[0], m0 + wr * 128, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc, 0);
+        gemm_epilogue<AUX, 2, false>(g, acc[1], m0 + wr * 128 + 64, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 256x256x64 kernel with FOUR waves (round 3): one wave per SIMD, wave (wr, wc) = (wave >> 1, wave & 1) owns a 128x128 block
+// (4 x 4 MFMA tiles, 256 accumulator registers: one wave per SIMD may use all 512 registers of a lane).
+//
+// Why: the ping-pong kernel above brings its operands in by LDS-DMA, and the CU's address path takes ~38 cycles per 1-KiB
+// DMA piece (in-kernel stamps, round 2): 64 pieces per 64-deep K-tile = ~2400 cycles against the 2048 cycles the K-tile's
+// MFMAs take -- its K loop is bound by the DMA issue path (1.26 us per K-tile with 24 CUs busy), which is why its time follows
+// the bytes staged and not the number of busy CUs.  Here the operands take the ordinary vector-memory path instead:
+// global_load_dwordx4 (1 KiB per wave-instruction at the L1's 64 B/clk = 16 cycles) into 64 staging registers, ds_write_b128
+// into a double-buffered LDS image (~13 cycles each), ds_read_b128 fragments.  Per K-tile and CU: 1024 cycles of L1 path,
+// ~830 + 512 cycles of LDS writes + reads (the 128x128 wave tile reads a third fewer fragment bytes than 128x64), 2048 of MFMA.
+// One workgroup barrier per K-tile: K-tile t+1 is loaded during the first half of K-tile t's MFMAs, written to the other LDS
+// image during the second half, and the barrier sits in the middle of the last k-step, with MFMAs queued on both sides.
+#define W4_IMG 65536      // one LDS image: A rows 0..255 (32 KiB) then W rows 0..255 (32 KiB), 128-B rows, XOR-swizzled chunks
+template <bool AUX, int EXP = 0>      // EXP: timing experiments (wrong results): 1 no global loads, 2 no LDS writes, 4 no barrier, 8 no fragment reads
+__global__ __launch_bounds__(256) void gemm_f16_w4_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int gx = g.gx, gy = g.gy;
+    const int lin = blockIdx.x;
+    int tx, ty;
+    if (gy >= 16) {          // XCD-aware order, as in the kernels above
+        const int slot = lin >> 3;
+        ty = (slot / gx) * 8 + (lin & 7);
+        tx = slot - (slot / gx) * gx;
+    } else {
+        ty = lin / gx;
+        tx = lin - ty * gx;
+    }
+    if (ty >= gy) return;
+    const int m0 = ty * 256, n0 = tx * 256;
+
+    // staging: wave w fetches rows [64w, 64w + 64) of the A and of the W tile, 8 rows x 128 B per wave-instruction
+    const int r8 = lane >> 3, c8 = lane & 7;
+    unsigned offA[8], offB[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = wave * 64 + i * 8 + r8;
+        const int ra = m0 + row < g.M ? m0 + row : g.M - 1, rb = n0 + row < g.N ? n0 + row : g.N - 1;
+        offA[i] = (unsigned)(((long)ra * g.lda + c8 * 8) * 2);
+        offB[i] = (unsigned)(((long)rb * g.ldw + c8 * 8) * 2);
+    }
+    // LDS write address of staging register i: row 64w + 8i + r8, physical chunk c8 ^ ((row >> 1) & 7); (row >> 1) & 7 =
+    // (r8 >> 1) ^ 4 (i & 1): two bases, + (i >> 1) * 2048
+    int wbase[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int row = wave * 64 + par * 8 + r8;
+        wbase[par] = row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4);
+    }
+    // fragment reads: A rows wr*128 + mt*32 + l31 (+ mt * 4096 B), W rows wc*128 + nt*32 + l31 in the second half of the image
+    const int hh = lane >> 5, l31 = lane & 31;
+    int aaddr[4], baddr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int ra = wr * 128 + l31, rb = wc * 128 + l31;
+        aaddr[ks] = ra * 128 + (((2 * ks + hh) ^ ((ra >> 1) & 7)) << 4);
+        baddr[ks] = 32768 + rb * 128 + (((2 * ks + hh) ^ ((rb >> 1) & 7)) << 4);
+    }
+    f32x16 acc[2][2][2][2];      // [row block rb][column block cb][mi][ni]: MFMA tile (mt, nt) = (2 rb + mi, 2 cb + ni)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][i][j][r] = 0.f;
+
+    const int ktiles = g.K / BK;
+    const int nt = ktiles * g.nseg;
+    f16x8 G[16];                 // staging registers: 0..7 A, 8..15 W
+    f16x8 fa[2][4], fb[2][4];    // fragments of two k-steps
+    // K-tile t_ -> uniform byte bases of its A / W columns
+#define W4_BASES(t_)                                                                                          \
+    const int seg__ = (t_) / ktiles;                                                                          \
+    const long k0__ = (long)((t_) - seg__ * ktiles) * BK;                                                     \
+    const char* PA__ = reinterpret_cast<const char*>((seg__ == 0 ? g.A[0] : (seg__ == 1 ? g.A[1] : g.A[2])) + k0__); \
+    const char* PW__ = reinterpret_cast<const char*>((seg__ == 0 ? g.W[0] : (seg__ == 1 ? g.W[1] : g.W[2])) + k0__);
+    // (the empty asm keeps the 32-bit offset a 32-bit register: uniform base + VGPR offset form of the load, no 64-bit vector add)
+#define W4_LOAD_A(i_) { unsigned o__ = offA[i_]; asm volatile("" : "+v"(o__)); G[i_] = *reinterpret_cast<const f16x8*>(PA__ + o__); }
+#define W4_LOAD_B(i_) { unsigned o__ = offB[i_]; asm volatile("" : "+v"(o__)); G[8 + (i_)] = *reinterpret_cast<const f16x8*>(PW__ + o__); }
+#define W4_WRITE_A(i_) *reinterpret_cast<f16x8*>(smem + wbase[(i_) & 1] + ((i_) >> 1) * 2048) = G[i_];
+#define W4_WRITE_B(i_) *reinterpret_cast<f16x8*>(smem + 32768 + wbase[(i_) & 1] + ((i_) >> 1) * 2048) = G[8 + (i_)];
+#define W4_READ(buf_, ks_, j_)                                                                                \
+    if ((j_) < 4) fa[buf_][(j_) & 3] = *reinterpret_cast<const f16x8*>(smem + aaddr[ks_] + ((j_) & 3) * 4096); \
+    else fb[buf_][(j_) & 3] = *reinterpret_cast<const f16x8*>(smem + baddr[ks_] + ((j_) & 3) * 4096);
+#define W4_SB __builtin_amdgcn_sched_barrier(0);
+    // MFMA j of a k-step: tile (mt, nt) in snake order over the 4 x 4 tiles
+#define W4_MMA(buf_, j_)                                                                                      \
+    {                                                                                                         \
+        constexpr int mt__ = (j_) >> 2, nt__ = (mt__ & 1) ? 3 - ((j_) & 3) : (j_) & 3;                        \
+        acc[mt__ >> 1][nt__ >> 1][mt__ & 1][nt__ & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                \
+            fa[buf_][mt__], fb[buf_][nt__], acc[mt__ >> 1][nt__ >> 1][mt__ & 1][nt__ & 1], 0, 0, 0);           \
+    }
+#define W4_REP16(X_) X_(0) X_(1) X_(2) X_(3) X_(4) X_(5) X_(6) X_(7) X_(8) X_(9) X_(10) X_(11) X_(12) X_(13) X_(14) X_(15)
+
+    // prologue: K-tile 0 -> image 0, K-tile 1 requested into the staging registers, fragments of k-step 0 of K-tile 0.  The
+    // images alternate by toggling bit 16 of the addresses: wbase points into the image being WRITTEN (the next K-tile's),
+    // aaddr / baddr into the one being read.
+    {
+        W4_BASES(0)
+#define W4_P0(j_) if ((j_) < 8) { W4_LOAD_A((j_) & 7) } else { W4_LOAD_B((j_) & 7) }
+        W4_REP16(W4_P0)
+#define W4_P1(j_) if ((j_) < 8) { W4_WRITE_A((j_) & 7) } else { W4_WRITE_B((j_) & 7) }
+        W4_REP16(W4_P1)
+#undef W4_P1
+    }
+    if (nt > 1) {
+        W4_BASES(1)
+        W4_REP16(W4_P0)
+    }
+#undef W4_P0
+    wbase[0] ^= W4_IMG; wbase[1] ^= W4_IMG;
+    __syncthreads();
+#define W4_P2(j_) if ((j_) < 8) { W4_READ(0, 0, (j_) & 7) }
+    W4_REP16(W4_P2)
+#undef W4_P2
+
+    // One K-tile t.  WR: K-tile t+1 exists (its rows wait in the staging registers: write them to the other image, barrier,
+    // pre-read its k-step 0); LD: K-tile t+2 exists (a staging register is re-loaded with its K-tile t+2 data two slots after
+    // it has been written out, so a load has a whole K-tile of MFMAs, ~1.4 us, to arrive).
+    // ONE memory instruction per MFMA slot, the three kinds spread evenly over the K-tile: the four waves run in lockstep
+    // (barrier), so 8 loads (writes) in 8 consecutive slots of every wave ask the CU's L1 (LDS store path) for 128 (~100) B/clk
+    // against 64 (79) it delivers, and the waves stall at ISSUE, matrix pipe idle (tools/gemm_w4_exp.py: bunched, the loads cost
+    // 0.29 us and the writes 0.13 us of a 1.9-us K-tile).
+    //   slot j of k-steps 0..2: j even: fragment j/2 of the next k-step (order: A0 B0 B1 B2 B3 A1 A2 A3, the order of first use)
+    //                           j = 4q+1: write staging register 4s+q;  j = 4q+3: load it again
+    //   k-step 3: j < 8: write (even) / load (odd) staging register 12 + j/2; barrier after MFMA 7; j >= 8: fragments of
+    //             k-step 0 of K-tile t+1
+#define W4_FR(r_) ((r_) == 0 ? 0 : (r_) <= 4 ? (r_) + 3 : (r_) - 4)      /* read order -> fragment index (0..3 A, 4..7 B) */
+#define W4_WRITE(gi_) if ((gi_) < 8) { W4_WRITE_A((gi_) & 7) } else { W4_WRITE_B((gi_) & 7) }
+#define W4_LOAD(gi_) if ((gi_) < 8) { W4_LOAD_A((gi_) & 7) } else { W4_LOAD_B((gi_) & 7) }
+#define W4_SLOT(s_, buf_, j_)                                                                                 \
+    if (((j_) & 1) == 0) { if (!(EXP & 8)) { W4_READ((buf_) ^ 1, (s_) + 1, W4_FR((j_) >> 1)) } }              \
+    else if (((j_) & 3) == 1) { if (WR && !(EXP & 2)) { W4_WRITE((s_) * 4 + ((j_) >> 2)) } }                  \
+    else { if (LD && !(EXP & 1)) { W4_LOAD((s_) * 4 + ((j_) >> 2)) } }                                        \
+    W4_SB W4_MMA(buf_, j_) W4_SB
+#define W4_S0(j_) W4_SLOT(0, 0, j_)
+#define W4_S1(j_) W4_SLOT(1, 1, j_)
+#define W4_S2(j_) W4_SLOT(2, 0, j_)
+#define W4_S3(j_)                                                                                             \
+    if ((j_) < 8) {                                                                                           \
+        if (((j_) & 1) == 0) { if (WR && !(EXP & 2)) { W4_WRITE(12 + (((j_) & 7) >> 1)) } }                   \
+        else { if (LD && !(EXP & 1)) { W4_LOAD(12 + (((j_) & 7) >> 1)) } }                                    \
+    } else if (WR && !(EXP & 8)) { W4_READ(0, 0, W4_FR((j_) & 7)) }                                           \
+    W4_SB W4_MMA(1, j_) W4_SB                                                                                 \
+    if (WR && (j_) == 7 && !(EXP & 4)) { __syncthreads(); W4_SB }
+#define W4_TILE(t_)                                                                                           \
+    {                                                                                                         \
+        W4_BASES((t_) + 2)                                                                                    \
+        W4_SB                                                                                                 \
+        W4_REP16(W4_S0) W4_REP16(W4_S1) W4_REP16(W4_S2)                                                       \
+        if (WR) {      /* every read of this image has been issued: the read addresses move to the other one */ \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) { aaddr[ks] ^= W4_IMG; baddr[ks] ^= W4_IMG; }    \
+        }                                                                                                     \
+        W4_REP16(W4_S3)                                                                                       \
+        wbase[0] ^= W4_IMG; wbase[1] ^= W4_IMG;                                                               \
+    }
+    int t = 0;
+    for (; t + 2 < nt; ++t) { constexpr bool WR = true, LD = true; W4_TILE(t) }
+    if (t + 1 < nt) { constexpr bool WR = true, LD = false; W4_TILE(t) ++t; }
+    { constexpr bool WR = false, LD = false; W4_TILE(t) }
+#undef W4_TILE
+#undef W4_SLOT
+#undef W4_WRITE
+#undef W4_LOAD
+#undef W4_FR
+#undef W4_S0
+#undef W4_S1
+#undef W4_S2
+#undef W4_S3
+#undef W4_REP16
+#undef W4_MMA
+#undef W4_READ
+#undef W4_WRITE_A
+#undef W4_WRITE_B
+#undef W4_LOAD_A
+#undef W4_LOAD_B
+#undef W4_BASES
+#undef W4_SB
+    __syncthreads();                                 // every wave is done with the operand images: epilogue scratch
+    float bv0[2], sc0[2], bv1[2], sc1[2];
+    gemm_colvals(g, n0, wc * 2, lane, 0, bv0, sc0);
+    gemm_colvals(g, n0, wc * 2 + 1, lane, 0, bv1, sc1);
+    gemm_epilogue<AUX, 2, false>(g, acc[0][0], m0 + wr * 128, n0, 0, wc * 2, lane, 0, smem + wave * 8192, bv0, sc0, 0);
+    gemm_epilogue<AUX, 2, false>(g, acc[0][1], m0 + wr * 128, n0, 0, wc * 2 + 1, lane, 0, smem + wave * 8192, bv1, sc1, 0);
+    gemm_epilogue<AUX, 2, false>(g, acc[1][0], m0 + wr * 128 + 64, n0, 0, wc * 2, lane, 0, smem + wave * 8192, bv0, sc0, 0);
+    gemm_epilogue<AUX, 2, false>(g, acc[1][1], m0 + wr * 128 + 64, n0, 0, wc * 2 + 1, lane, 0, smem + wave * 8192, bv1, sc1, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1390,6 +1677,10 @@ extern "C" int wc_sum_slices(const float* part, float* out, int nslices, long n,
 // (per CU the LDS-DMA path, 1.26 us per K-tile with 24 CUs active; contention between CUs adds to it: 1.66 us at 192 CUs),
 // so filling the idle quarter of the chip only raises the contention.  The 192-column tile is therefore taken only where it
 // stages FEWER bytes (N = 192, 384, 576: the 256-column tile would carry dead columns), never in the training step.
+static int g_w4 = -1;                    // 256x256 tiles on the 4-wave register-staged kernel (WECLIP_GEMM_W4 / wc_gemm_set_w4)
+extern "C" void wc_gemm_set_w4(int on) { g_w4 = on; }
+static int g_pp_m16 = -1;                // 256x256 kernel on 16x16x32 MFMAs (WECLIP_GEMM_M16 / wc_gemm_set_m16)
+extern "C" void wc_gemm_set_m16(int on) { g_pp_m16 = on ? 1 : 0; }
 static int g_p192_mode = -1;             // 0: never, 1: by staged bytes, 2: whenever the shape allows
 static float g_p192_cost = 1.0f;         // relative cost of a byte staged by the 192-column kernel
 extern "C" void wc_gemm_set_p192(int mode, float cost) {
@@ -1397,7 +1688,9 @@ extern "C" void wc_gemm_set_p192(int mode, float cost) {
     if (cost > 0.f) g_p192_cost = cost;
 }
 
-static int gemm_plan(int M, int N, int K, int nseg, int batch, bool row_mapped_aux) {
+static int gemm_plan(int M, int N, int K, int nseg, int batch, bool row_mapped_aux, long lda = 0, long ldw = 0) {
+    if (lda <= 0) lda = K;
+    if (ldw <= 0) ldw = K;
     static const int pp_mode = getenv("WECLIP_GEMM_PP") ? atoi(getenv("WECLIP_GEMM_PP")) : 1;
     static const int pp_min_tiles = getenv("WECLIP_GEMM_PP_MIN_TILES") ? atoi(getenv("WECLIP_GEMM_PP_MIN_TILES")) : 160;
     if (g_p192_mode < 0) {
@@ -1406,6 +1699,7 @@ static int gemm_plan(int M, int N, int K, int nseg, int batch, bool row_mapped_a
     }
     const long gx = wc_cdiv(N, 256), gy = wc_cdiv(M, 256);
     if (!pp_mode || batch != 1 || (long)K * nseg < 2 * BK || gx * gy < pp_min_tiles) return 0;
+    if ((long)M * lda * 2 >= (1L << 32) || (long)N * ldw * 2 >= (1L << 32)) return 0;      // the tall kernels carry 32-bit byte offsets
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
@@ -1488,7 +1782,7 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
                 ? 1 : 0;
     g.auxvec = (act == 5 && ldaux % 4 == 0 && sX2 % 4 == 0 && (uintptr_t)auxh % 8 == 0) ? 1 : 0;
     g.gx = wc_cdiv(N, BN);
-    const int plan = gemm_plan(M, N, K, nseg, batch, false);
+    const int plan = gemm_plan(M, N, K, nseg, batch, false, lda, ldw);
     if (plan) {   // tall GEMM: 256x256 / 256x192 ping-pong kernel
         const bool p192 = plan >= 3;
         const int tn = p192 ? 192 : 256;
@@ -1497,8 +1791,12 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
         dim3 gridp((unsigned)(g.gx * (g.gy >= 16 ? (g.gy + 7) / 8 * 8 : g.gy)), 1, 1);
         static bool lds_attr_set = false;
         if (!lds_attr_set) {      // 128 / 112 KiB of dynamic LDS are above the default per-kernel limit
-            WC_CHECK_ARG(hipFuncSetAttribute((const void*)gemm_f16_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PP_SLOT) == hipSuccess &&
-                         hipFuncSetAttribute((const void*)gemm_f16_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PP_SLOT) == hipSuccess &&
+            WC_CHECK_ARG(hipFuncSetAttribute((const void*)gemm_f16_pp_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PP_SLOT) == hipSuccess &&
+                         hipFuncSetAttribute((const void*)gemm_f16_pp_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PP_SLOT) == hipSuccess &&
+                         hipFuncSetAttribute((const void*)gemm_f16_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W4_IMG) == hipSuccess &&
+                         hipFuncSetAttribute((const void*)gemm_f16_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W4_IMG) == hipSuccess &&
+                         hipFuncSetAttribute((const void*)gemm_f16_pp_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PP_SLOT) == hipSuccess &&
+                         hipFuncSetAttribute((const void*)gemm_f16_pp_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PP_SLOT) == hipSuccess &&
                          hipFuncSetAttribute((const void*)gemm_f16_p192_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 14 * P192_UNIT) == hipSuccess &&
                          hipFuncSetAttribute((const void*)gemm_f16_p192_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 14 * P192_UNIT) == hipSuccess,
                          "wc_gemm_f16: cannot reserve 128 KiB of LDS");
@@ -1523,11 +1821,36 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
             wc_prof_end(pr, use_aux ? "gemm_f16_p192_kernel<true>" : "gemm_f16_p192_kernel<false>", 2.0 * g.M * N * K, stream);
             WC_LAUNCH_CHECK("gemm_f16_p192_kernel");
         } else {
-            if (use_aux)
-                hipLaunchKernelGGL(gemm_f16_pp_kernel<true>, gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
-            else
-                hipLaunchKernelGGL(gemm_f16_pp_kernel<false>, gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
-            wc_prof_end(pr, use_aux ? "gemm_f16_pp_kernel<true>" : "gemm_f16_pp_kernel<false>", 2.0 * g.M * N * K, stream);
+            if (g_pp_m16 < 0) g_pp_m16 = getenv("WECLIP_GEMM_M16") ? atoi(getenv("WECLIP_GEMM_M16")) : 0;
+            if (g_w4 < 0) g_w4 = getenv("WECLIP_GEMM_W4") ? atoi(getenv("WECLIP_GEMM_W4")) : 0;
+            if (g_w4) {
+                if (use_aux)
+                    hipLaunchKernelGGL(gemm_f16_w4_kernel<true>, gridp, dim3(256), 2 * W4_IMG, (hipStream_t)stream, g);
+#ifdef W4_EXPERIMENTS
+                else if (g_w4 > 1) {
+                    static bool exp_attr = false;
+#define W4_EXP_CASE(e_) case e_: if (!exp_attr) hipFuncSetAttribute((const void*)gemm_f16_w4_kernel<false, e_>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W4_IMG); \
+                    hipLaunchKernelGGL((gemm_f16_w4_kernel<false, e_>), gridp, dim3(256), 2 * W4_IMG, (hipStream_t)stream, g); break;
+                    switch (g_w4 - 1) { W4_EXP_CASE(1) W4_EXP_CASE(3) W4_EXP_CASE(4) W4_EXP_CASE(7) W4_EXP_CASE(15) W4_EXP_CASE(8) default: break; }
+                }
+#endif
+                else
+                    hipLaunchKernelGGL(gemm_f16_w4_kernel<false>, gridp, dim3(256), 2 * W4_IMG, (hipStream_t)stream, g);
+                wc_prof_end(pr, use_aux ? "gemm_f16_w4_kernel<true>" : "gemm_f16_w4_kernel<false>", 2.0 * g.M * N * K, stream);
+                WC_LAUNCH_CHECK("gemm_f16_w4_kernel");
+            } else if (g_pp_m16) {
+                if (use_aux)
+                    hipLaunchKernelGGL((gemm_f16_pp_kernel<true, true>), gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
+                else
+                    hipLaunchKernelGGL((gemm_f16_pp_kernel<false, true>), gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
+            } else {
+                if (use_aux)
+                    hipLaunchKernelGGL((gemm_f16_pp_kernel<true, false>), gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
+                else
+                    hipLaunchKernelGGL((gemm_f16_pp_kernel<false, false>), gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
+            }
+            wc_prof_end(pr, g_pp_m16 ? (use_aux ? "gemm_f16_pp_kernel<true, true>" : "gemm_f16_pp_kernel<false, true>")
+                                     : (use_aux ? "gemm_f16_pp_kernel<true, false>" : "gemm_f16_pp_kernel<false, false>"), 2.0 * g.M * N * K, stream);
             WC_LAUNCH_CHECK("gemm_f16_pp_kernel");
         }
         if (!split) return WC_OK;
