@@ -170,6 +170,9 @@ void wc_gemm_set_p192(int mode, float cost);
  * accumulator registers; fp32 sums of 32 instead of 16 products per instruction, so results differ in the last fp32 bits).
  * Process-wide; initial value from WECLIP_GEMM_M16. */
 void wc_gemm_set_m16(int on);
+/* Per-shape timing of the GEMM entry points when WECLIP_GEMM_LOG=1 (an event pair around every call): writes
+ * "entry M= N= K= seg= batch= plan= act=\tcalls\tms\tflop" lines into buf, clears the log, returns the number of lines. */
+int wc_gemm_log_report(char* buf, int cap);
 /* 256x256 tiles on the 4-wave kernel (128x128 wave tiles, operands through registers: global_load -> ds_write) instead of the
  * 8-wave LDS-DMA ping-pong kernel.  Process-wide; initial value from WECLIP_GEMM_W4. */
 void wc_gemm_set_w4(int on);

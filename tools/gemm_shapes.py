@@ -1,44 +1,39 @@
-"""List the GEMM shapes of one training step with their event-timed durations (sorted by total time)."""
-import os, sys, collections
+"""Which GEMM shapes the training step launches and what each costs: WECLIP_GEMM_LOG=1 puts an event pair around every call of the
+GEMM entry points; eager steps (no graph) are aggregated per (entry, M, N, K, segments, batch, kernel plan).
+    python tools/gemm_shapes.py [comer]"""
+import ctypes, os, sys
+os.environ["WECLIP_GEMM_LOG"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from weclip_vit_comer_amd import synth, ops
-from weclip_vit_comer_amd.WeCLIP_model.model_attn_aff_voc import WeCLIP
+import bench
+from weclip_vit_comer_amd import _lib as L
+from weclip_vit_comer_amd.data import SyntheticVOCLoader
 from weclip_vit_comer_amd.train_step import TrainStep
 
+comer = len(sys.argv) > 1 and sys.argv[1] == "comer"
 dev = torch.device("cuda", 0)
-sd = synth.make_clip_state_dict(seed=0, with_text=False)
-bg, fg = synth.make_text_features(20, 25, 512)
-fuse, dec = synth.make_head_state_dicts()
-model = WeCLIP(num_classes=21, clip_model=sd, embedding_dim=256, in_channels=[768] * 4, dataset_root_path=None,
-               device=dev, text_features=(bg.to(dev), fg.to(dev)))
-model.decoder_fts_fuse.load_state_dict(fuse); model.decoder.load_state_dict(dec); model.train()
-step = TrainStep(model)
-img = synth.make_images(16, 512, 512, seed=100).to(dev)
-labels = synth.make_label_lists(16, 2, seed=7)
-for _ in range(3):
+model = bench.make_model(dev, comer=comer)
+step = TrainStep(model, graph=False)
+loader = SyntheticVOCLoader(16, 512, 2, rank=0, world=1, device=dev, source="uint8")
+cd = L.lib().cdll
+cd.wc_gemm_log_report.argtypes = [ctypes.c_char_p, ctypes.c_int]
+cd.wc_gemm_log_report.restype = ctypes.c_int
+buf = ctypes.create_string_buffer(1 << 20)
+for _ in range(2):
+    img, labels = loader.next()
     step(img, labels=labels)
-torch.cuda.synchronize()
-rec = []
-orig = ops.gemm
-def traced(a, w, M, N, K, **kw):
-    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record(); orig(a, w, M, N, K, **kw); e1.record()
-    nseg = 1 + (getattr(a, "lo", None) is not None) + (getattr(w, "lo", None) is not None)
-    rec.append(((M, N, K, nseg, kw.get("batch", 1), kw.get("act", 0), "res" if kw.get("resid") is not None else "",
-                 "o32" if kw.get("out32") is not None else "o16"), e0, e1))
-ops.gemm = traced
-import weclip_vit_comer_amd.head_engine as he, weclip_vit_comer_amd.clip.vit_engine as ve, weclip_vit_comer_amd.gradcam_engine as ge
-for m in (he, ve, ge):
-    m.ops.gemm = traced
-step(img, labels=labels)
-torch.cuda.synchronize()
-agg = collections.defaultdict(lambda: [0, 0.0])
-for k, e0, e1 in rec:
-    agg[k][0] += 1; agg[k][1] += e0.elapsed_time(e1) * 1e3
-tot = sum(v[1] for v in agg.values())
-print(f"{len(rec)} GEMM calls, {tot/1e3:.2f} ms")
-for k, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    M, N, K, nseg, batch = k[:5]
-    tf = 2.0 * M * N * K * batch * n / us / 1e6
-    print(f"{str(k):60s} x{n:3d} {us/n:8.1f} us each {us/1e3:7.3f} ms  {tf:7.1f} TF/s")
+cd.wc_gemm_log_report(buf, len(buf))      # drop the warm-up steps
+n = 3
+for _ in range(n):
+    img, labels = loader.next()
+    step(img, labels=labels)
+cd.wc_gemm_log_report(buf, len(buf))
+rows = []
+for line in buf.value.decode().splitlines():
+    key, calls, ms, flop = line.split("\t")
+    rows.append((float(ms) / n, int(calls) / n, float(flop) / n, key))
+rows.sort(reverse=True)
+tot = sum(r[0] for r in rows)
+print(f"GEMM entry points, per step (eager, event pair around every call: each adds a few us of fencing): {tot:.3f} ms in {sum(r[1] for r in rows):.0f} calls")
+for ms, calls, flop, key in rows:
+    print(f"{ms:8.3f} ms {calls:5.1f} calls {ms / calls * 1e3:8.1f} us each {flop / ms / 1e9:8.1f} TF/s   {key}")

@@ -19,6 +19,56 @@
 #include <cstring>
 #include <stdlib.h>
 
+#include <map>
+#include <string>
+#include <vector>
+
+// Per-shape timing of the GEMM entry points (WECLIP_GEMM_LOG=1, tools/gemm_shapes.py): an event pair around every call,
+// aggregated by (entry, M, N, K, segments, batch, kernel plan).  Off by default: one branch per call.
+struct GemmShapeRec { char key[96]; hipEvent_t e0, e1; double flop; };
+static int g_shape_log = -1;
+static std::vector<GemmShapeRec> g_shape_recs;
+static int shape_log_begin(void* stream) {
+    if (g_shape_log < 0) g_shape_log = getenv("WECLIP_GEMM_LOG") ? atoi(getenv("WECLIP_GEMM_LOG")) : 0;
+    if (!g_shape_log) return -1;
+    GemmShapeRec r;
+    r.key[0] = 0; r.flop = 0;
+    hipEventCreate(&r.e0); hipEventCreate(&r.e1);
+    hipEventRecord(r.e0, (hipStream_t)stream);
+    g_shape_recs.push_back(r);
+    return (int)g_shape_recs.size() - 1;
+}
+static void shape_log_end(int idx, const char* kind, int M, int N, int K, int nseg, int batch, int plan, int act, void* stream) {
+    if (idx < 0) return;
+    GemmShapeRec& r = g_shape_recs[idx];
+    snprintf(r.key, sizeof(r.key), "%s M=%d N=%d K=%d seg=%d batch=%d plan=%d act=%d", kind, M, N, K, nseg, batch, plan, act);
+    r.flop = 2.0 * M * N * K * nseg * batch;
+    hipEventRecord(r.e1, (hipStream_t)stream);
+}
+// "key\tcalls\tms\tflop" lines, cleared afterwards
+extern "C" int wc_gemm_log_report(char* buf, int cap) {
+    hipDeviceSynchronize();
+    std::map<std::string, std::pair<double, std::pair<double, long>>> agg;
+    for (auto& r : g_shape_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            auto& a = agg[r.key];
+            a.first += ms; a.second.first += r.flop; a.second.second += 1;
+        }
+        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    }
+    g_shape_recs.clear();
+    int off = 0;
+    if (cap > 0) buf[0] = 0;
+    for (auto& kv : agg) {
+        const int n = snprintf(buf + off, off < cap ? cap - off : 0, "%s\t%ld\t%.6f\t%.6e\n", kv.first.c_str(), kv.second.second.second,
+                               kv.second.first, kv.second.second.first);
+        if (n < 0 || off + n >= cap) break;
+        off += n;
+    }
+    return (int)agg.size();
+}
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -78,7 +128,7 @@ struct GemmArgs {
         _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_) (v_)[e_] = fmaxf((v_)[e_], 0.f);      \
     } else if (act == 3) {                                                                        \
         _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_) (v_)[e_] = __builtin_amdgcn_rcpf(1.0f + __expf(-(v_)[e_])); \
-    } else if (act == 6) {                                                                        \
+    } else if (ERF && act == 6) {      /* (erff costs registers: only in the builds that serve act 6 / 7) */ \
         _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_)                                       \
             (v_)[e_] = 0.5f * (v_)[e_] * (1.0f + erff((v_)[e_] * 0.70710678118654752f));          \
     }
@@ -119,14 +169,21 @@ __device__ __forceinline__ float epi_acc(const f32x16 (&acc)[2][NI], int mi, int
 template <int NI>
 __device__ __forceinline__ float epi_acc(const f32x4 (&acc)[2][NI][4], int mi, int ni, int r) { return acc[mi][ni][r >> 2][r & 3]; }
 
-template <bool AUX, int NI = 2, bool L16 = false, class ACC>
+// EK = epilogue kind of the build: 0 plain (act 0..3), 1 side input (act 4 QuickGELU', act 5 ReLU'), 2 erf GELU (act 6),
+// 3 erf GELU' with side input (act 7).  The erf forms live in builds of their own: carried by every build they cost the
+// 128x128 kernel its second workgroup per CU (244 -> 260 registers: 65 -> 95 us on the decoder shapes, round 3).
+template <int EK, int NI = 2, bool L16 = false, class ACC>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, ACC& acc, int m0, int n0, int wr, int wc,
                                               int lane, long zb, char* scratch, const float (&bv)[L16 ? 2 * NI : 2],
                                               const float (&sc)[L16 ? 2 * NI : 2], long cb, long xb = 0) {
+    constexpr bool AUX = (EK & 1) != 0, ERF = EK >= 2;
     const int act = g.act;
     // layout of accumulator register r (0..15) of block (mi, ni): row inside the 32-row block, column inside the 64-wide block,
     // index of the lane's per-column constants
-#define EPI_ROW(r_) (L16 ? ((((r_) >> 3) << 4) + ((lane >> 4) << 2) + ((r_) & 3)) : (((r_) & 3) + 8 * (((r_) >> 2) & 3) + 4 * (lane >> 5)))
+    // (row = lane part + compile-time part: kept apart so that row * ldc stays one lane-dependent base + scalar multiples of ldc)
+    const int rowl = L16 ? ((lane >> 4) << 2) : 4 * (lane >> 5);
+#define EPI_ROWC(r_) (L16 ? ((((r_) >> 3) << 4) + ((r_) & 3)) : (((r_) & 3) + 8 * (((r_) >> 2) & 3)))
+#define EPI_ROW(r_) (rowl + EPI_ROWC(r_))
 #define EPI_COL(ni_, r_) (L16 ? ((ni_) * 32 + ((((r_) >> 2) & 1) << 4) + (lane & 15)) : ((ni_) * 32 + (lane & 31)))
 #define EPI_CI(ni_, r_) (L16 ? ((ni_) * 2 + (((r_) >> 2) & 1)) : (ni_))
     const bool has_res = g.resid != nullptr;
@@ -163,7 +220,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, ACC& acc, int m
             }
         };
         if constexpr (AUX) {
-            if (act == 4 || act == 7) aux_load(0, ua[0]);
+            if (ERF ? act == 7 : act == 4) aux_load(0, ua[0]);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {            // rows [16c, 16c+16) of the wave's 64x64 sub-tile
@@ -171,7 +228,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, ACC& acc, int m
             float* tile = tile0 + (c & 1) * 1024;
             float v[NI * 8];
             if constexpr (AUX) {
-                if ((act == 4 || act == 7) && c + 1 < 4) aux_load(c + 1, ua[(c + 1) & 1]);
+                if ((ERF ? act == 7 : act == 4) && c + 1 < 4) aux_load(c + 1, ua[(c + 1) & 1]);
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
@@ -209,19 +266,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, ACC& acc, int m
                 for (int it = 0; it < 4; ++it) {
                     if (!ok[it]) continue;
                     const int grow = m0 + wr * 64 + c * 16 + it * 4 + (lane >> 4);
-                    if (act == 4) {
+                    if (!ERF && act == 4) {
                         const float (&u)[4] = ua[c & 1][it];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u[k]));
                             f[it][k] *= sg * (1.0f + 1.702f * u[k] * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
                         }
-                    } else if (act == 7) {
+                    } else if (ERF && act == 7) {
                         const float (&u)[4] = ua[c & 1][it];
 #pragma unroll
                         for (int k = 0; k < 4; ++k)      // d/du [u * Phi(u)] = Phi(u) + u * phi(u)
                             f[it][k] *= 0.5f * (1.0f + erff(u[k] * 0.70710678118654752f)) + u[k] * 0.3989422804014327f * __expf(-0.5f * u[k] * u[k]);
-                    } else {
+                    } else if (!ERF) {
                         const __half* hp = g.auxh + xb + (long)grow * g.ldaux + gcol;
                         if (full && g.auxvec) {          // one 8-byte load of the four saved activations
                             typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
@@ -277,12 +334,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, ACC& acc, int m
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                const int rbase = m0 + wr * 64 + mi * 32;
+                const int rbase = m0 + wr * 64 + mi * 32 + rowl;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int col = n0 + wc * 64 + EPI_COL(ni, r);
                     const int colc = col < g.N ? col : g.N - 1;
-                    int row = rbase + EPI_ROW(r);
+                    int row = rbase + EPI_ROWC(r);
                     if (row > g.M - 1) row = g.M - 1;
                     rva[AUX ? 0 : mi][AUX ? 0 : ni][r] = g.resid[zb * g.sR + (long)row * g.ldr + colc];
                 }
@@ -302,14 +359,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, ACC& acc, int m
                 colcv[tc] = colokv[tc] ? colv[tc] : g.N - 1;
             }
 #define EPI_TC(r_) (L16 ? (((r_) >> 2) & 1) : 0)
-            const int rbase = m0 + wr * 64 + mi * 32;
+            const int rbase = m0 + wr * 64 + mi * 32 + rowl;
             float uv[16], v[16], pre[16];
             float (&rv)[16] = rva[AUX ? 0 : mi][AUX ? 0 : ni];
             if constexpr (AUX) {      // the aux variants are register-bound: residual per block
                 if (has_res) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        int row = rbase + EPI_ROW(r);
+                        int row = rbase + EPI_ROWC(r);
                         if (row > g.M - 1) row = g.M - 1;
                         rv[r] = g.resid[zb * g.sR + (long)row * g.ldr + colcv[EPI_TC(r)]];
                     }
@@ -318,19 +375,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, ACC& acc, int m
             if constexpr (AUX) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    int row = rbase + EPI_ROW(r);
+                    int row = rbase + EPI_ROWC(r);
                     if (row > g.M - 1) row = g.M - 1;
                     const int colc = colcv[EPI_TC(r)];
-                    if (act == 4) {
+                    if (!ERF && act == 4) {
                         const long arow = g.rowmap ? (long)g.rowmap[(row + g.row0) / g.rpg] * g.rpg + (row + g.row0) % g.rpg : row;
                         const float u = g.aux[arow * g.ldaux + colc];
                         const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u));
                         uv[r] = sg * (1.0f + 1.702f * u * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
-                    } else if (act == 7) {
+                    } else if (ERF && act == 7) {
                         const long arow = g.rowmap ? (long)g.rowmap[(row + g.row0) / g.rpg] * g.rpg + (row + g.row0) % g.rpg : row;
                         const float u = g.aux[arow * g.ldaux + colc];
                         uv[r] = 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
-                    } else {
+                    } else if (!ERF) {
                         uv[r] = __half2float(g.auxh[xb + (long)row * g.ldaux + colc]) > 0.f ? 1.f : 0.f;   // ReLU'
                     }
                 }
@@ -355,8 +412,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, ACC& acc, int m
             }
             // element r lives at o0 + drow(r) * ldc + (its column - the lane's first column)
             const long o0 = cb + (long)rbase * g.ldc + colv[0];
-#define EPI_OFF(r_) ((long)EPI_ROW(r_) * g.ldc + (EPI_TC(r_) ? 16 : 0))
-#define EPI_OK(r_) (colokv[EPI_TC(r_)] && rbase + EPI_ROW(r_) < g.M)
+#define EPI_OFF(r_) ((long)EPI_ROWC(r_) * g.ldc + (EPI_TC(r_) ? 16 : 0))
+#define EPI_OK(r_) (colokv[EPI_TC(r_)] && rbase + EPI_ROWC(r_) < g.M)
             if (g.P32) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -385,6 +442,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, ACC& acc, int m
 #undef EPI_OK
 #undef EPI_TC
 #undef EPI_ROW
+#undef EPI_ROWC
 #undef EPI_COL
 #undef EPI_CI
 }
@@ -398,8 +456,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, ACC& acc, int m
 // NST = 2: two stages, one in flight, two workgroups per CU hide each other's load latency (grids of many tiles).
 // NST = 4: a ring of four stages, three in flight behind counted vmcnt waits and raw s_barriers, 128 KiB: for grids of
 // at most one workgroup per CU, where the 2-stage loop runs at one global-memory latency per 64-deep K-tile.
-template <bool AUX, int NST>
-__global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
+template <int EK, int NST>
+__global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_f16_kernel(GemmArgs g) {      // NST = 2: two workgroups per CU (<= 256 registers)
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [NST stages][A tile 16 KiB | W tile 16 KiB]
     constexpr int TILE = BM * BK * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -542,7 +600,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
 #undef FRAG_LOAD
 #undef FRAG_MMA
 #undef GLDS
-    gemm_epilogue<AUX>(g, acc, m0, n0, wr, wc, lane, zb, smem + wave * 8192, bv, sc, z1 * g.sC + z2 * g.sC2, z2 * g.sX2);
+    gemm_epilogue<EK>(g, acc, m0, n0, wr, wc, lane, zb, smem + wave * 8192, bv, sc, z1 * g.sC + z2 * g.sC2, z2 * g.sX2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -551,7 +609,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
 // 17.8 us for 16 x 3072 x 768).  Here a workgroup owns 64 output columns, its four waves split K, operands go straight
 // from global memory to MFMA fragments (no LDS: nothing is shared between waves), all loads of a chunk of 12 k-steps in
 // flight at once; the four partial tiles meet in LDS and wave 0 runs the shared epilogue.
-template <bool AUX>
+template <int EK>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float red[3 * 32 * 64];      // partial tiles of waves 1..3: [wave-1][reg][lane]
     __shared__ __attribute__((aligned(16))) char scr[8192];              // epilogue scratch of wave 0
@@ -620,7 +678,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][j][r] += red[(w * 32 + j * 16 + r) * 64 + lane];
-    gemm_epilogue<AUX>(g, acc, 0, n0, 0, 0, lane, 0, scr, bv, sc, 0);
+    gemm_epilogue<EK>(g, acc, 0, n0, 0, 0, lane, 0, scr, bv, sc, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -642,7 +700,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
 // XOR swizzle is conflict-free for that pattern as well) and the same 128 accumulator registers.  The matrix pipe takes the
 // same cycles either way; what differs is the clock the chip holds under the load (MI355X_MICROARCH.md, DVFS item 7).
 #define PP_SLOT 16384
-template <bool AUX, bool M16>
+template <int EK, bool M16>
 __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 8 half-tile slots [128 rows][64 halfs], XOR-swizzled
     const int tid = threadIdx.x, lane = tid & 63;
@@ -891,11 +949,11 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
     if (wr == 0) __builtin_amdgcn_s_barrier();       // re-align the two row groups
     __syncthreads();                                 // every wave is done with the operand slots: epilogue scratch
     if constexpr (M16) {      // (the epilogue reads the 16x16 tiles as register r = (tr*2 + tc)*4 + i of a 32x32 block)
-        gemm_epilogue<AUX, 2, true>(g, acc4[0], m0 + wr * 128, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc, 0);
-        gemm_epilogue<AUX, 2, true>(g, acc4[1], m0 + wr * 128 + 64, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc, 0);
+        gemm_epilogue<EK, 2, true>(g, acc4[0], m0 + wr * 128, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc, 0);
+        gemm_epilogue<EK, 2, true>(g, acc4[1], m0 + wr * 128 + 64, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc, 0);
     } else {
-        gemm_epilogue<AUX, 2, false>(g, acc[0], m0 + wr * 128, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc, 0);
-        gemm_epilogue<AUX, 2, false>(g, acc[1], m0 + wr * 128 + 64, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc, 0);
+        gemm_epilogue<EK, 2, false>(g, acc[0], m0 + wr * 128, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc, 0);
+        gemm_epilogue<EK, 2, false>(g, acc[1], m0 + wr * 128 + 64, n0, 0, wc, lane, 0, smem + wave * 8192, bv, sc, 0);
     }
 }
 
@@ -913,7 +971,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
 // One workgroup barrier per K-tile: K-tile t+1 is loaded during the first half of K-tile t's MFMAs, written to the other LDS
 // image during the second half, and the barrier sits in the middle of the last k-step, with MFMAs queued on both sides.
 #define W4_IMG 65536      // one LDS image: A rows 0..255 (32 KiB) then W rows 0..255 (32 KiB), 128-B rows, XOR-swizzled chunks
-template <bool AUX, int EXP = 0>      // EXP: timing experiments (wrong results): 1 no global loads, 2 no LDS writes, 4 no barrier, 8 no fragment reads
+template <int EK, int EXP = 0>      // EXP: timing experiments (wrong results): 1 no global loads, 2 no LDS writes, 4 no barrier, 8 no fragment reads
 __global__ __launch_bounds__(256) void gemm_f16_w4_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1088,10 +1146,10 @@ __global__ __launch_bounds__(256) void gemm_f16_w4_kernel(GemmArgs g) {
     float bv0[2], sc0[2], bv1[2], sc1[2];
     gemm_colvals(g, n0, wc * 2, lane, 0, bv0, sc0);
     gemm_colvals(g, n0, wc * 2 + 1, lane, 0, bv1, sc1);
-    gemm_epilogue<AUX, 2, false>(g, acc[0][0], m0 + wr * 128, n0, 0, wc * 2, lane, 0, smem + wave * 8192, bv0, sc0, 0);
-    gemm_epilogue<AUX, 2, false>(g, acc[0][1], m0 + wr * 128, n0, 0, wc * 2 + 1, lane, 0, smem + wave * 8192, bv1, sc1, 0);
-    gemm_epilogue<AUX, 2, false>(g, acc[1][0], m0 + wr * 128 + 64, n0, 0, wc * 2, lane, 0, smem + wave * 8192, bv0, sc0, 0);
-    gemm_epilogue<AUX, 2, false>(g, acc[1][1], m0 + wr * 128 + 64, n0, 0, wc * 2 + 1, lane, 0, smem + wave * 8192, bv1, sc1, 0);
+    gemm_epilogue<EK, 2, false>(g, acc[0][0], m0 + wr * 128, n0, 0, wc * 2, lane, 0, smem + wave * 8192, bv0, sc0, 0);
+    gemm_epilogue<EK, 2, false>(g, acc[0][1], m0 + wr * 128, n0, 0, wc * 2 + 1, lane, 0, smem + wave * 8192, bv1, sc1, 0);
+    gemm_epilogue<EK, 2, false>(g, acc[1][0], m0 + wr * 128 + 64, n0, 0, wc * 2, lane, 0, smem + wave * 8192, bv0, sc0, 0);
+    gemm_epilogue<EK, 2, false>(g, acc[1][1], m0 + wr * 128 + 64, n0, 0, wc * 2 + 1, lane, 0, smem + wave * 8192, bv1, sc1, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1113,7 +1171,7 @@ __global__ __launch_bounds__(256) void gemm_f16_w4_kernel(GemmArgs g) {
 // barriers (`s_waitcnt vmcnt(5)` at every wait), and a slot is re-staged only after both halves have passed the
 // `lgkmcnt(0)` behind its last fragment read.
 #define P192_UNIT 8192
-template <bool AUX>
+template <int EK>
 __global__ __launch_bounds__(512) void gemm_f16_p192_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 14 units [64 rows][64 halfs], XOR-swizzled
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1277,8 +1335,8 @@ __global__ __launch_bounds__(512) void gemm_f16_p192_kernel(GemmArgs g) {
 #undef P192_W0
     if (grp == 0) __builtin_amdgcn_s_barrier();      // re-align the two halves
     __syncthreads();                                 // every wave is done with the ring: epilogue scratch
-    gemm_epilogue<AUX, 2>(g, accP, m0 + wr * 64, n0 + wc * 96, 0, 0, lane, 0, smem + wave * 8192, bvP, scP, 0);
-    gemm_epilogue<AUX, 1>(g, accQ, m0 + wr * 64, n0 + wc * 96 + 64, 0, 0, lane, 0, smem + wave * 8192, bvQ, scQ, 0);
+    gemm_epilogue<EK, 2>(g, accP, m0 + wr * 64, n0 + wc * 96, 0, 0, lane, 0, smem + wave * 8192, bvP, scP, 0);
+    gemm_epilogue<EK, 1>(g, accQ, m0 + wr * 64, n0 + wc * 96 + 64, 0, 0, lane, 0, smem + wave * 8192, bvQ, scQ, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1524,7 +1582,9 @@ extern "C" int wc_gemm_km_f16_grouped(const void* dY, long lda, const void* X, l
     WC_CHECK_ARG((long)g.tiles * g.units < (1L << 31), "wc_gemm_km_f16: grid too large");
     dim3 grid((unsigned)(g.tiles * g.units));
     const int pr = wc_prof_begin(stream);
+    const int sl = shape_log_begin(stream);
     hipLaunchKernelGGL(gemm_km_kernel, grid, dim3(256), 4 * 64 * 256, (hipStream_t)stream, g);
+    shape_log_end(sl, "km", M, N, K1, 1, groups, ns, 0, stream);
     wc_prof_end(pr, "gemm_km_kernel", 2.0 * M * N * K1 * groups, stream);
     WC_LAUNCH_CHECK("gemm_km_kernel");
     return WC_OK;
@@ -1744,7 +1804,30 @@ extern "C" int wc_gemm_f16(const void* A0, const void* A1, const void* A2, const
                                cscale, sCS, batch, 0, 0, 0, 0, 0, stream);
 }
 
+static int gemm_f16_grouped_impl(const void* A0, const void* A1, const void* A2, const void* W0,
+                                   const void* W1, const void* W2, int nseg, int M, int N, int K, long lda,
+                                   long ldw, int batch, long sA, long sW, long sC, const float* bias,
+                                   const float* resid, long ldr, long sR, float* C32, void* C16, void* C16lo, long ldc,
+                                   int act, int round16, float scale, int scale_cols, float* P32, const float* aux,
+                                   const int* rowmap, int rpg, long ldaux, const void* auxh, const float* cscale,
+                                   long sCS, int zdiv, long sA2, long sW2, long sC2, long sB2, long sX2, void* stream);
+
 extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A2, const void* W0,
+                                   const void* W1, const void* W2, int nseg, int M, int N, int K, long lda,
+                                   long ldw, int batch, long sA, long sW, long sC, const float* bias,
+                                   const float* resid, long ldr, long sR, float* C32, void* C16, void* C16lo, long ldc,
+                                   int act, int round16, float scale, int scale_cols, float* P32, const float* aux,
+                                   const int* rowmap, int rpg, long ldaux, const void* auxh, const float* cscale,
+                                   long sCS, int zdiv, long sA2, long sW2, long sC2, long sB2, long sX2, void* stream) {
+    const int sl = shape_log_begin(stream);
+    const int rc = gemm_f16_grouped_impl(A0, A1, A2, W0, W1, W2, nseg, M, N, K, lda, ldw, batch, sA, sW, sC, bias, resid, ldr, sR, C32, C16,
+                                         C16lo, ldc, act, round16, scale, scale_cols, P32, aux, rowmap, rpg, ldaux, auxh, cscale, sCS, zdiv,
+                                         sA2, sW2, sC2, sB2, sX2, stream);
+    if (sl >= 0) shape_log_end(sl, C32 ? (C16 ? "f16+f32" : "f32") : "f16", M, N, K, nseg, batch, gemm_plan(M, N, K, nseg, batch, false, lda, ldw), act, stream);
+    return rc;
+}
+
+static int gemm_f16_grouped_impl(const void* A0, const void* A1, const void* A2, const void* W0,
                                    const void* W1, const void* W2, int nseg, int M, int N, int K, long lda,
                                    long ldw, int batch, long sA, long sW, long sC, const float* bias,
                                    const float* resid, long ldr, long sR, float* C32, void* C16, void* C16lo, long ldc,
@@ -1765,6 +1848,7 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
     WC_CHECK_ARG(act != 5 || (auxh && ldaux >= N), "wc_gemm_f16: act 5 needs auxh, ldaux");
     WC_CHECK_ARG((act != 4 && act != 7) || (aux && rpg > 0 && ldaux >= N), "wc_gemm_f16: act 4 / 7 need aux, rpg, ldaux");
     const bool use_aux = act == 4 || act == 5 || act == 7;      // the epilogue variant that reads a side input
+    const bool erf = act == 6 || act == 7;                      // the erf-GELU builds (gemm_epilogue EK 2 / 3)
     GemmArgs g;
     g.A[0] = (const __half*)A0; g.A[1] = (const __half*)A1; g.A[2] = (const __half*)A2;
     g.W[0] = (const __half*)W0; g.W[1] = (const __half*)W1; g.W[2] = (const __half*)W2;
@@ -1782,7 +1866,8 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
                 ? 1 : 0;
     g.auxvec = (act == 5 && ldaux % 4 == 0 && sX2 % 4 == 0 && (uintptr_t)auxh % 8 == 0) ? 1 : 0;
     g.gx = wc_cdiv(N, BN);
-    const int plan = gemm_plan(M, N, K, nseg, batch, false, lda, ldw);
+    int plan = gemm_plan(M, N, K, nseg, batch, false, lda, ldw);
+    if (erf && plan >= 3) plan -= 2;      // the erf epilogues exist for the 256x256 tile only
     if (plan) {   // tall GEMM: 256x256 / 256x192 ping-pong kernel
         const bool p192 = plan >= 3;
         const int tn = p192 ? 192 : 256;
@@ -1818,12 +1903,26 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
                 hipLaunchKernelGGL(gemm_f16_p192_kernel<true>, gridp, dim3(512), 14 * P192_UNIT, (hipStream_t)stream, g);
             else
                 hipLaunchKernelGGL(gemm_f16_p192_kernel<false>, gridp, dim3(512), 14 * P192_UNIT, (hipStream_t)stream, g);
-            wc_prof_end(pr, use_aux ? "gemm_f16_p192_kernel<true>" : "gemm_f16_p192_kernel<false>", 2.0 * g.M * N * K, stream);
+            wc_prof_end(pr, use_aux ? "gemm_f16_p192_kernel<1>" : "gemm_f16_p192_kernel<0>", 2.0 * g.M * N * K, stream);
             WC_LAUNCH_CHECK("gemm_f16_p192_kernel");
         } else {
             if (g_pp_m16 < 0) g_pp_m16 = getenv("WECLIP_GEMM_M16") ? atoi(getenv("WECLIP_GEMM_M16")) : 0;
             if (g_w4 < 0) g_w4 = getenv("WECLIP_GEMM_W4") ? atoi(getenv("WECLIP_GEMM_W4")) : 0;
-            if (g_w4) {
+            if (erf) {
+                static bool erf_attr = false;
+                if (!erf_attr) {
+                    WC_CHECK_ARG(hipFuncSetAttribute((const void*)gemm_f16_pp_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PP_SLOT) == hipSuccess &&
+                                 hipFuncSetAttribute((const void*)gemm_f16_pp_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PP_SLOT) == hipSuccess,
+                                 "wc_gemm_f16: cannot reserve 128 KiB of LDS");
+                    erf_attr = true;
+                }
+                if (use_aux)
+                    hipLaunchKernelGGL((gemm_f16_pp_kernel<3, false>), gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
+                else
+                    hipLaunchKernelGGL((gemm_f16_pp_kernel<2, false>), gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
+                wc_prof_end(pr, use_aux ? "gemm_f16_pp_kernel<3, false>" : "gemm_f16_pp_kernel<2, false>", 2.0 * g.M * N * K, stream);
+                WC_LAUNCH_CHECK("gemm_f16_pp_kernel");
+            } else if (g_w4) {
                 if (use_aux)
                     hipLaunchKernelGGL(gemm_f16_w4_kernel<true>, gridp, dim3(256), 2 * W4_IMG, (hipStream_t)stream, g);
 #ifdef W4_EXPERIMENTS
@@ -1836,7 +1935,7 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
 #endif
                 else
                     hipLaunchKernelGGL(gemm_f16_w4_kernel<false>, gridp, dim3(256), 2 * W4_IMG, (hipStream_t)stream, g);
-                wc_prof_end(pr, use_aux ? "gemm_f16_w4_kernel<true>" : "gemm_f16_w4_kernel<false>", 2.0 * g.M * N * K, stream);
+                wc_prof_end(pr, use_aux ? "gemm_f16_w4_kernel<1, 0>" : "gemm_f16_w4_kernel<0, 0>", 2.0 * g.M * N * K, stream);
                 WC_LAUNCH_CHECK("gemm_f16_w4_kernel");
             } else if (g_pp_m16) {
                 if (use_aux)
@@ -1849,8 +1948,8 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
                 else
                     hipLaunchKernelGGL((gemm_f16_pp_kernel<false, false>), gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
             }
-            wc_prof_end(pr, g_pp_m16 ? (use_aux ? "gemm_f16_pp_kernel<true, true>" : "gemm_f16_pp_kernel<false, true>")
-                                     : (use_aux ? "gemm_f16_pp_kernel<true, false>" : "gemm_f16_pp_kernel<false, false>"), 2.0 * g.M * N * K, stream);
+            wc_prof_end(pr, g_pp_m16 ? (use_aux ? "gemm_f16_pp_kernel<1, true>" : "gemm_f16_pp_kernel<0, true>")
+                                     : (use_aux ? "gemm_f16_pp_kernel<1, false>" : "gemm_f16_pp_kernel<0, false>"), 2.0 * g.M * N * K, stream);
             WC_LAUNCH_CHECK("gemm_f16_pp_kernel");
         }
         if (!split) return WC_OK;
@@ -1869,11 +1968,15 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
     static const int skinny_env = getenv("WECLIP_GEMM_SKINNY") ? atoi(getenv("WECLIP_GEMM_SKINNY")) : 1;
     if (skinny_env && M <= 32 && batch == 1 && N >= 256) {      // a few rows against many weight rows
         const int prs = wc_prof_begin(stream);
-        if (use_aux)
+        if (erf && use_aux)
+            hipLaunchKernelGGL(gemm_skinny_kernel<3>, dim3(wc_cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, g);
+        else if (erf)
+            hipLaunchKernelGGL(gemm_skinny_kernel<2>, dim3(wc_cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, g);
+        else if (use_aux)
             hipLaunchKernelGGL(gemm_skinny_kernel<true>, dim3(wc_cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, g);
         else
             hipLaunchKernelGGL(gemm_skinny_kernel<false>, dim3(wc_cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, g);
-        wc_prof_end(prs, use_aux ? "gemm_skinny_kernel<true>" : "gemm_skinny_kernel<false>", 2.0 * M * N * K, stream);
+        wc_prof_end(prs, erf ? "gemm_skinny_kernel<erf>" : use_aux ? "gemm_skinny_kernel<1>" : "gemm_skinny_kernel<0>", 2.0 * M * N * K, stream);
         WC_LAUNCH_CHECK("gemm_skinny_kernel");
         return WC_OK;
     }
@@ -1887,6 +1990,8 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
             hipDeviceGetAttribute(&n_cu128, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu128 <= 0)
             n_cu128 = 256;
         WC_CHECK_ARG(hipFuncSetAttribute((const void*)gemm_f16_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * BM * BK * 2) == hipSuccess &&
+                     hipFuncSetAttribute((const void*)gemm_f16_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * BM * BK * 2) == hipSuccess &&
+                     hipFuncSetAttribute((const void*)gemm_f16_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * BM * BK * 2) == hipSuccess &&
                      hipFuncSetAttribute((const void*)gemm_f16_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * BM * BK * 2) == hipSuccess,
                      "wc_gemm_f16: cannot reserve 128 KiB of LDS");
     }
@@ -1894,15 +1999,24 @@ extern "C" int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A
     const bool ring = ring_env && (long)g.gx * g.gy * batch <= n_cu128 && K / BK * nseg >= 3;
     const size_t lds = (ring ? 4 : 2) * 2 * BM * BK * 2;
     const int pr = wc_prof_begin(stream);
-    if (use_aux) {
+    if (erf) {
+        if (use_aux) {
+            if (ring) hipLaunchKernelGGL((gemm_f16_kernel<3, 4>), grid, dim3(256), lds, (hipStream_t)stream, g);
+            else hipLaunchKernelGGL((gemm_f16_kernel<3, 2>), grid, dim3(256), lds, (hipStream_t)stream, g);
+        } else {
+            if (ring) hipLaunchKernelGGL((gemm_f16_kernel<2, 4>), grid, dim3(256), lds, (hipStream_t)stream, g);
+            else hipLaunchKernelGGL((gemm_f16_kernel<2, 2>), grid, dim3(256), lds, (hipStream_t)stream, g);
+        }
+    } else if (use_aux) {
         if (ring) hipLaunchKernelGGL((gemm_f16_kernel<true, 4>), grid, dim3(256), lds, (hipStream_t)stream, g);
         else hipLaunchKernelGGL((gemm_f16_kernel<true, 2>), grid, dim3(256), lds, (hipStream_t)stream, g);
     } else {
         if (ring) hipLaunchKernelGGL((gemm_f16_kernel<false, 4>), grid, dim3(256), lds, (hipStream_t)stream, g);
         else hipLaunchKernelGGL((gemm_f16_kernel<false, 2>), grid, dim3(256), lds, (hipStream_t)stream, g);
     }
-    wc_prof_end(pr, use_aux ? (ring ? "gemm_f16_kernel<true, 4>" : "gemm_f16_kernel<true, 2>")
-                             : (ring ? "gemm_f16_kernel<false, 4>" : "gemm_f16_kernel<false, 2>"), 2.0 * g.M * N * K * batch, stream);
+    wc_prof_end(pr, erf ? (ring ? "gemm_f16_kernel<erf, 4>" : "gemm_f16_kernel<erf, 2>")
+                    : use_aux ? (ring ? "gemm_f16_kernel<1, 4>" : "gemm_f16_kernel<1, 2>")
+                              : (ring ? "gemm_f16_kernel<0, 4>" : "gemm_f16_kernel<0, 2>"), 2.0 * g.M * N * K * batch, stream);
     WC_LAUNCH_CHECK("gemm_f16_kernel");
     return WC_OK;
 }
