@@ -63,6 +63,8 @@ class WeCLIP(nn.Module):
         # blocks [2,5,8,11]; their fusion replaces `linear_fuse` as the decoder input.  Extra keys
         # `comer.*` in the state dict; absent (and the reference contract untouched) by default.
         self.comer = CoMerInteraction(embedding_dim) if comer else None
+        self.fork_head = os.environ.get("WECLIP_FORK_HEAD", "1") != "0"      # head forward beside the CAM chain (second stream)
+        self._side = None
         self.to(device)
 
     def get_param_groups(self):
@@ -128,31 +130,71 @@ class WeCLIP(nn.Module):
             if self.training:
                 p = self.decoder_fts_fuse.dropout.p
                 drop = ((torch.rand(B, self.embedding_dim, device=img.device) >= p).float() / (1.0 - p)).contiguous()
+            # Outside the seg-trans branch the CAM -> affinity -> PAR chain reads nothing the head produces (clip_tool.py:146-176
+            # takes attn_pred only after iteration 15000): the head's forward runs on a second stream beside it (the HBM-bound
+            # PAR sweeps and the small MFMA launches of the decoder fill each other's gaps) and joins before the losses.
+            fork = self.fork_head and want_cam and not seg_trans and img.is_cuda
+            if fork:
+                main = torch.cuda.current_stream()
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=img.device)
+                self.head_engine.fwd_stream = self._side
+                try:
+                    seg, attn_pred = HeadFunction.apply(self.head_engine, x16, B, Lq, h, w, drop, *self.head_engine.params())
+                finally:
+                    self.head_engine.fwd_stream = None
+                with torch.no_grad():
+                    cam_labels = self.cam_labels(img, xs[-1], maps, None, img_names, labels, mode, seg_trans, h, w, plan=plan)
+                main.wait_stream(self._side)
+                return seg, cam_labels, attn_pred
             seg, attn_pred = HeadFunction.apply(self.head_engine, x16, B, Lq, h, w, drop, *self.head_engine.params())
         else:
-            if comer_tokens:       # adapters of the four stage blocks + inserts as one engine, fed by the encoder's f16 block outputs
-                fts = self.decoder_fts_fuse.dropout(self.comer.forward_tokens(img, x16, Lq, self.decoder_fts_fuse.linears_modulelist,
-                                                                              (h, w)))
-            elif self.comer is not None:
-                used = set(self.comer.stage_blocks)       # only these adapter outputs enter the inserts
-                toks = [mlp.tokens(r.view(B, Lq, -1)[:, 1:, :]) if i in used else None for i, (mlp, r) in
-                        enumerate(zip(self.decoder_fts_fuse.linears_modulelist, xs))]
-                fts = self.decoder_fts_fuse.dropout(self.comer(img, toks, (h, w)))
-            else:
-                fts = self.decoder_fts_fuse.forward_rows(xs, B, Lq, h, w)
-            if self.head_impl == "hip":      # decoder + linear_pred + attn_pred on the HIP path, from the fused features
-                rows = fts.permute(0, 2, 3, 1).reshape(B * h * w, fts.shape[1])
-                seg, attn_pred = DecoderFunction.apply(self.head_engine, rows, B, h, w, *self.head_engine.dec_params())
-            else:
-                seg, _ = self.decoder(fts, need_weights=False)
-                f = fts.reshape(B, fts.shape[1], h * w)
-                attn_pred = torch.sigmoid(f.transpose(2, 1).bmm(f))
+            # (same fork for the module-by-module head: its autograd nodes then belong to the side stream, their backward runs
+            #  there, and TrainStep joins `side_streams()` after loss.backward())
+            fork = self.fork_head and want_cam and not seg_trans and img.is_cuda and self.head_impl == "hip" and self.training
+            if fork:
+                main = torch.cuda.current_stream()
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=img.device)
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    seg, attn_pred = self._module_head(img, xs, x16, comer_tokens, B, Lq, h, w)
+                with torch.no_grad():
+                    cam_labels = self.cam_labels(img, xs[-1], maps, None, img_names, labels, mode, seg_trans, h, w, plan=plan)
+                main.wait_stream(self._side)
+                return seg, cam_labels, attn_pred
+            seg, attn_pred = self._module_head(img, xs, x16, comer_tokens, B, Lq, h, w)
         if mode == "val" and not self.val_runs_cam:
             return seg, None, attn_pred
         with torch.no_grad():
             cam_labels = self.cam_labels(img, xs[-1], maps, attn_pred.detach(), img_names, labels, mode,
                                          seg_trans, h, w, plan=plan)
         return seg, cam_labels, attn_pred
+
+    def side_streams(self):
+        """Streams (besides the caller's) that forward / backward work of this model may run on."""
+        return [self._side] if self._side is not None else []
+
+    def _module_head(self, img, xs, x16, comer_tokens, B, Lq, h, w):
+        """Adapters [+ ViT-CoMer inserts] -> decoder -> attn_pred through autograd nodes (every head form but the fused engine)."""
+        if comer_tokens:       # adapters of the four stage blocks + inserts as one engine, fed by the encoder's f16 block outputs
+            fts = self.decoder_fts_fuse.dropout(self.comer.forward_tokens(img, x16, Lq, self.decoder_fts_fuse.linears_modulelist,
+                                                                          (h, w)))
+        elif self.comer is not None:
+            used = set(self.comer.stage_blocks)       # only these adapter outputs enter the inserts
+            toks = [mlp.tokens(r.view(B, Lq, -1)[:, 1:, :]) if i in used else None for i, (mlp, r) in
+                    enumerate(zip(self.decoder_fts_fuse.linears_modulelist, xs))]
+            fts = self.decoder_fts_fuse.dropout(self.comer(img, toks, (h, w)))
+        else:
+            fts = self.decoder_fts_fuse.forward_rows(xs, B, Lq, h, w)
+        if self.head_impl == "hip":      # decoder + linear_pred + attn_pred on the HIP path, from the fused features
+            rows = fts.permute(0, 2, 3, 1).reshape(B * h * w, fts.shape[1])
+            seg, attn_pred = DecoderFunction.apply(self.head_engine, rows, B, h, w, *self.head_engine.dec_params())
+        else:
+            seg, _ = self.decoder(fts, need_weights=False)
+            f = fts.reshape(B, fts.shape[1], h * w)
+            attn_pred = torch.sigmoid(f.transpose(2, 1).bmm(f))
+        return seg, attn_pred
 
     def cam_labels(self, img, last_rows, maps, attn_pred, img_names, labels, mode, seg_trans, h, w, plan=None):
         if self.bg_text_features is None or self.fg_text_features is None:

@@ -1,6 +1,8 @@
 """Per-image CAM driver API of reference clip/clip_tool.py, executed by the batched device
 pipeline (gradcam_engine + cam_pipeline): nothing leaves the GPU between GradCAM, the affinity
 refinement and the label map."""
+import os
+
 import numpy as np
 import torch
 
@@ -153,14 +155,36 @@ def batch_refined_cams(clip_model, last_rows, maps11, seg_attn, plan, text_hat, 
     Returns (R (B, hw, K) refined CAMs, cams (P, hw), probs (P, Tmax), state)."""
     B, Lq = plan.B, h * w + 1
     st = last_layer_forward(clip_model, last_rows, B, Lq)
-    cams, probs, _ = st.grad_cam(text_hat, plan.text_idx, plan.n_text, plan.pair_img, plan.pair_cls, plan.Tmax)
     maps = list(maps11) + [st.mean]
     need = maps[-n_last:] if seg_trans else maps[-8:]
     if any(m is None for m in need):
         raise RuntimeError("attention maps needed by the affinity were not computed")
-    W, c1 = CP.affinity_weight(maps, seg_attn, seg_trans, n_last, keep=keep, return_c1=True)
+    if _FORK_AFFINITY and last_rows.is_cuda:
+        # the affinity weight (HBM-bound sums over the head-mean maps + Sinkhorn sweeps) needs nothing of the GradCAM chain
+        # (MFMA-bound GEMMs through the last block): side by side on two streams, joined before the refinement
+        main = torch.cuda.current_stream()
+        side = _side_stream(last_rows.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            W, c1 = CP.affinity_weight(maps, seg_attn, seg_trans, n_last, keep=keep, return_c1=True)
+        cams, probs, _ = st.grad_cam(text_hat, plan.text_idx, plan.n_text, plan.pair_img, plan.pair_cls, plan.Tmax)
+        main.wait_stream(side)
+    else:
+        cams, probs, _ = st.grad_cam(text_hat, plan.text_idx, plan.n_text, plan.pair_img, plan.pair_cls, plan.Tmax)
+        W, c1 = CP.affinity_weight(maps, seg_attn, seg_trans, n_last, keep=keep, return_c1=True)
     R = CP.refine(W, cams, plan.pair_img, plan.pair_slot, plan.K, h, w, thr, c1=c1)
     return R, cams, probs, st
+
+
+_FORK_AFFINITY = os.environ.get("WECLIP_FORK_AFFINITY", "0") != "0"      # measured neutral to slightly slower (12.84-12.96 vs 12.75-12.84 ms): off
+_SIDE = {}
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
 
 
 def _single(img_path, image, image_features, attn_weight_list, seg_attn, bg_text_features, fg_text_features,

@@ -50,6 +50,7 @@ class HeadEngine:
         # name -> fp32 buffer the gradient of that parameter is written INTO (not accumulated) by backward();
         # set by TrainStep to views of its flat all-reduce bucket so no per-parameter copy/add kernels run
         self.direct_grads = None
+        self.fwd_stream = None          # set by WeCLIP.forward while the head forward runs beside the CAM chain
         self.wcache = ops.WeightCache()     # fp16 (row-major + transposed) copies of every weight matrix, one launch per step
 
     def params(self):
@@ -199,12 +200,39 @@ class HeadEngine:
         The split-K reductions of all weight gradients are collected and run as ONE launch at the end
         (wc_sum_slices_wb_multi; 16 launches of 5-7 us at the launch floor otherwise)."""
         self._pending = []
+        # the weight-gradient GEMMs (few 128x128 output tiles, long contraction: low occupancy) and their reduction depend on
+        # nothing downstream: they run on a second stream beside the data-gradient chain and join at the end
+        side = None
+        if _FORK_WGRAD and (dseg if dseg is not None else dap).is_cuda:
+            dev = (dseg if dseg is not None else dap).device
+            side = _WG_STREAMS.get(dev.index)
+            if side is None:
+                side = _WG_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+        self._wg_side, self._keep = side, []
         try:
             grads = self._backward_impl(ctx, dseg, dap)
-            self._flush_reductions()
+            if side is not None:
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._flush_reductions()
+                main.wait_stream(side)
+            else:
+                self._flush_reductions()
         finally:
             self._pending = None
+            self._wg_side, self._keep = None, None
         return grads
+
+    def _partials(self, *a, **kw):
+        """ops.wgrad_partials on the weight-gradient stream (operands kept alive until the join)."""
+        side = getattr(self, "_wg_side", None)
+        if side is None:
+            return ops.wgrad_partials(*a, **kw)
+        side.wait_stream(torch.cuda.current_stream())
+        self._keep.extend(t for t in a if isinstance(t, torch.Tensor))
+        with torch.cuda.stream(side):
+            return ops.wgrad_partials(*a, **kw)
 
     def _reduce(self, part, gw, gb, ns, N_, K_, alpha, groups=1, sw=0, sb=0):
         """dW / db = alpha * sum of the `ns` split-K slices of `part`: queued while a backward pass is collecting,
@@ -348,7 +376,7 @@ class HeadEngine:
         def run(dy, lda, gA, x, ldx, gX, N_, K_, xmap, gw, gb, sw, sb):
             tiles = ((N_ + 127) // 128) * ((K_ + 1 + 127) // 128) * n
             ns = max(1, min(_WGRAD_WGS // tiles, M // 256))       # one round of workgroups (2 per CU), few partials
-            part, ns = ops.wgrad_partials(dy, x, M, N_, K_, lda=lda, ldx=ldx, slices=ns, bias=True, xmap=xmap, groups=n, gA=gA, gX=gX)
+            part, ns = self._partials(dy, x, M, N_, K_, lda=lda, ldx=ldx, slices=ns, bias=True, xmap=xmap, groups=n, gA=gA, gX=gX)
             self._reduce(part, gw, gb, ns, N_, K_, inv, groups=n, sw=sw, sb=sb)
 
         # proj_2: dY = dcat[:, l*E:(l+1)*E], X = t1[l];   proj: dY = dt1[l], X = patch rows of block output l
@@ -377,7 +405,7 @@ class HeadEngine:
         ns = 1
         while ns * 2 * tiles <= _WGRAD_WGS and M // (ns * 2) >= 256:
             ns *= 2
-        part, ns = ops.wgrad_partials(dy16, x16, M, N_, K_, lda=lda, ldx=ldx, slices=ns, bias=True, xmap=xmap)
+        part, ns = self._partials(dy16, x16, M, N_, K_, lda=lda, ldx=ldx, slices=ns, bias=True, xmap=xmap)
         gw, gb = self._dest(wname, (N_, K_)), self._dest(bname, (N_,))
         self._reduce(part, gw, gb, ns, N_, K_, inv)
         grads[wname], grads[bname] = gw, gb
@@ -416,12 +444,24 @@ class HeadEngine:
         return dx
 
 
+_FORK_WGRAD = os.environ.get("WECLIP_FORK_WGRAD", "0") != "0"      # measured neutral (12.74-12.80 vs 12.75-12.84 ms per step): off
+_WG_STREAMS = {}
+
+
 class HeadFunction(torch.autograd.Function):
     """autograd bridge: (params...) -> (seg, attn_pred); backward = HeadEngine.backward."""
 
     @staticmethod
     def forward(ctx, engine, xs, B, Lq, h, w, drop_scale, *params):
-        seg, ap, c = engine.forward(xs, B, Lq, h, w, drop_scale)
+        side = engine.fwd_stream
+        if side is not None:
+            # forward on a second stream (WeCLIP.forward joins it after the CAM chain); the node itself was created on the
+            # caller's stream, so the backward -- and the direct gradient writes the optimizer waits for -- run there
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                seg, ap, c = engine.forward(xs, B, Lq, h, w, drop_scale)
+        else:
+            seg, ap, c = engine.forward(xs, B, Lq, h, w, drop_scale)
         ctx.engine, ctx.c = engine, c
         return seg, ap
 

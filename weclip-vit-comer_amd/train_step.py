@@ -130,6 +130,10 @@ class TrainStep:
         else:
             self.opt.zero_grad()
         loss.backward()
+        if img.is_cuda:      # backward nodes of a head that ran beside the CAM chain execute on the model's side stream
+            cur = torch.cuda.current_stream()
+            for s in getattr(self.model, "side_streams", lambda: [])():
+                cur.wait_stream(s)
         return loss.detach(), seg_loss.detach(), attn_loss.detach()
 
     def __call__(self, img, names=None, labels=None):
