@@ -209,6 +209,10 @@ def roofline_leg(args, step, loader, dev):
     from weclip_vit_comer_amd import ops
     B, S, K = args.batch, args.size, args.classes_per_image
     step.graph = False
+    # one stream for these steps: an event pair around a launch must time THAT kernel, not its share of the GPU beside the
+    # head forward that the timed (graph) steps run on a second stream
+    fork_was = getattr(step.model, "fork_head", False)
+    step.model.fork_head = False
     for _ in range(2):
         img, labels = loader.next()
         step(img, labels=labels)
@@ -223,6 +227,7 @@ def roofline_leg(args, step, loader, dev):
     dt = time.perf_counter() - t0
     summ = ops.KernelTimer.summary()
     ops.KernelTimer.enable(0)
+    step.model.fork_head = fork_was
     stride = max(args.timer_stride, 1)
 
     # peaks from guides/MI355X_MICROARCH.md: dense fp16 MFMA 2.5 PFLOP/s, HBM3E 8 TB/s
