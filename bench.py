@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--timer-stride", type=int, default=7,
                     help="HIP-event pair around 1 of every n instrumented kernel launches (0: none, roofline = null)")
     ap.add_argument("--roof-steps", type=int, default=8, help="eager instrumented steps for the roofline leg")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="head forward on the step's own stream instead of beside the CAM chain (profiling passes: a kernel trace "
+                         "then times every kernel alone)")
     ap.add_argument("--cpu-images", type=int, default=2, help="images in the bounded CPU-oracle sample")
     ap.add_argument("--cpu-images-1thread", type=int, default=1, help="images in the single-thread CPU-oracle sample (0: skip)")
     return ap.parse_args()
@@ -164,6 +167,8 @@ def run_leg(args, dev, rank, world, *, comer=False, seg_trans=False, steps=None,
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     model = make_model(dev, comer=comer, seg_trans=seg_trans)
+    if args.single_stream:
+        model.fork_head = model.fork_mean = False
     use_graph = graph and (not comer or os.environ.get("WECLIP_COMER_GRAPH", "1") != "0")
     step = TrainStep(model, graph=use_graph)
     loader = SyntheticVOCLoader(args.batch, args.size, args.classes_per_image, rank=rank, world=world, device=dev,
@@ -211,8 +216,8 @@ def roofline_leg(args, step, loader, dev):
     step.graph = False
     # one stream for these steps: an event pair around a launch must time THAT kernel, not its share of the GPU beside the
     # head forward that the timed (graph) steps run on a second stream
-    fork_was = getattr(step.model, "fork_head", False)
-    step.model.fork_head = False
+    fork_was = (getattr(step.model, "fork_head", False), getattr(step.model, "fork_mean", False))
+    step.model.fork_head = step.model.fork_mean = False
     for _ in range(2):
         img, labels = loader.next()
         step(img, labels=labels)
@@ -227,7 +232,7 @@ def roofline_leg(args, step, loader, dev):
     dt = time.perf_counter() - t0
     summ = ops.KernelTimer.summary()
     ops.KernelTimer.enable(0)
-    step.model.fork_head = fork_was
+    step.model.fork_head, step.model.fork_mean = fork_was
     stride = max(args.timer_stride, 1)
 
     # peaks from guides/MI355X_MICROARCH.md: dense fp16 MFMA 2.5 PFLOP/s, HBM3E 8 TB/s

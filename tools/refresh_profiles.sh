@@ -7,10 +7,12 @@ set -e
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-extras --timer-stride 0 --roof-steps 0"
+# --single-stream: the head forward on the step's own stream, so that the trace times every kernel alone (the timed bench
+# steps run it on a second stream beside the CAM chain: 12.9 vs 13.2 ms per step)
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-extras --timer-stride 0 --roof-steps 0 --single-stream"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_stats -o p -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --timer-stride 0 --roof-steps 0 > $R/gpurun_out/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --timer-stride 0 --roof-steps 0 > $R/gpurun_out/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --timer-stride 0 --roof-steps 0 --single-stream > $R/gpurun_out/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --timer-stride 0 --roof-steps 0 --single-stream > $R/gpurun_out/pmc_write.log 2>&1
 cd $R
 python3 tools/prof_summary.py gpurun_out/prof_stats/p_results.db 14 100 > gpurun_out/${TAG}_kernel_stats.csv
 python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/${TAG}

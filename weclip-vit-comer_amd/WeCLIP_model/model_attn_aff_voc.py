@@ -64,6 +64,7 @@ class WeCLIP(nn.Module):
         # `comer.*` in the state dict; absent (and the reference contract untouched) by default.
         self.comer = CoMerInteraction(embedding_dim) if comer else None
         self.fork_head = os.environ.get("WECLIP_FORK_HEAD", "1") != "0"      # head forward beside the CAM chain (second stream)
+        self.fork_mean = os.environ.get("WECLIP_FORK_MEAN", "0") != "0"      # head-mean maps beside the blocks' GEMMs: measured slower, off
         self._side = None
         self.to(device)
 
@@ -101,11 +102,23 @@ class WeCLIP(nn.Module):
         rows, B, Lq = vis.embed(img)
         need = self._maps_needed(seg_trans) if want_maps else [False] * 11
         xs, maps = [], []
+        # The head-mean map of a block is read only by the affinity, after the encoder: with fork_mean its kernel goes to a second
+        # stream, to fill the CUs the block's next GEMMs leave idle (the 256x256 tiles of out-proj / fc2 / the next in-projection
+        # cover 0.75 / 0.75 / 2.25 rounds of the chip), joined after the last block.  Measured SLOWER (13.26-13.32 vs 13.07-13.20 ms
+        # per step): the GEMMs lose more to the shared L2 / fabric than the idle CUs give -- off by default.
+        mean_side = None
+        if self.fork_mean and img.is_cuda and any(need):
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=img.device)
+            mean_side = (self._side, [])
         for i in range(vis.transformer.layers - 1):
             rows, m = VE.run_block(vis.transformer.resblocks[i].pack(), rows, B, Lq, want_mean=need[i], x16_out=x16,
-                                   tag=b"@vit_attn")
+                                   tag=b"@vit_attn", mean_side=mean_side if need[i] else None)
             xs.append(rows)
             maps.append(m)
+        if mean_side is not None:
+            torch.cuda.current_stream().wait_stream(mean_side[0])
+            mean_side[1].clear()
         return xs, maps, B, Lq
 
     def forward(self, img, img_names="2007_000032", mode="train", labels=None, plan=None):

@@ -112,9 +112,11 @@ def layernorm(x, weight, bias, *, eps=1e-5, want32=False, want16=True, with_lo=F
     return y32, (Split(hi, lo) if want16 else None)
 
 
-def attention(qkv16, B, Lq, H, DH, want_mean=True, want_o32=False):
+def attention(qkv16, B, Lq, H, DH, want_mean=True, want_o32=False, mean_side=None):
     """qkv16 (B*L, 3E) fp16 with q pre-scaled by log2(e)/sqrt(DH).
-    Returns (o16 (B*L, E) fp16, lse (B,H,L) f32, mean (B,L,L) f32 or None)."""
+    Returns (o16 (B*L, E) fp16, lse (B,H,L) f32, mean (B,L,L) f32 or None).
+    mean_side = (stream, keep list): the head-mean kernel goes to that stream (behind the forward kernel); the caller joins
+    the stream before it reads the map and drops `keep` (the kernel's inputs) only after the join."""
     E = H * DH
     dev = qkv16.device
     lib = L.lib()
@@ -123,7 +125,14 @@ def attention(qkv16, B, Lq, H, DH, want_mean=True, want_o32=False):
     o32 = torch.empty(B * Lq, E, device=dev, dtype=F32) if want_o32 else None
     lib.wc_attn_fwd(L.ptr(qkv16, F16, "qkv"), L.ptr(o16), L.ptr(o32), L.ptr(lse), B, Lq, H, DH, L.stream())
     mean = None
-    if want_mean:
+    if want_mean and mean_side is not None:
+        side, keep = mean_side
+        side.wait_stream(torch.cuda.current_stream())
+        keep.extend((qkv16, lse))
+        with torch.cuda.stream(side):
+            mean = torch.empty(B, Lq, Lq, device=dev, dtype=F32)
+            lib.wc_attn_mean(L.ptr(qkv16), L.ptr(lse), L.ptr(mean), B, Lq, H, DH, L.stream())
+    elif want_mean:
         mean = torch.empty(B, Lq, Lq, device=dev, dtype=F32)
         lib.wc_attn_mean(L.ptr(qkv16), L.ptr(lse), L.ptr(mean), B, Lq, H, DH, L.stream())
     if want_o32:
