@@ -263,7 +263,7 @@ def roofline_leg(args, step, loader, dev):
     merged = {}
     for name, r in summ.items():          # fold the tagged records back into their kernels for the per-kernel rows
         base = name.split("@")[0]
-        m = merged.setdefault(base, {"ms": 0.0, "launches": 0, "work": 0.0})
+        m = merged.setdefault(base, {"ms": 0.0, "launches": 0, "work": 0.0, "est_ms": 0.0})
         for k in m:
             m[k] += r[k]
     summ = merged
@@ -276,9 +276,9 @@ def roofline_leg(args, step, loader, dev):
         ach = r["work"] / sec / (1e12 if bound == "mfma" else 1e9)
         roofs.append({"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                       "frac": round(ach / peak, 4), "traffic": traffic.get(name), "launches_timed": r["launches"],
-                      "sampling": f"1 of {stride} launches, {n} eager steps",
+                      "sampling": f"1 of {stride} instrumented launches on average (fixed pseudo-random pick), {n} eager steps",
                       "avg_launch_us": round(r["ms"] * 1e3 / max(r["launches"], 1), 2),
-                      "share_of_eager_step": round(r["ms"] * stride * 1e-3 / dt, 4)})
+                      "share_of_eager_step": round(r["est_ms"] * 1e-3 / dt, 4)})
     roofs.sort(key=lambda x: -x["share_of_eager_step"])
     # the north-star group "ViT attention" = in-projection + QK^T/softmax/PV + head-mean maps + out-projection is
     # reported by the library under its own tag when the launch sites carry it (csrc/core.hip wc_prof groups)

@@ -29,9 +29,11 @@ int wc_device_count(void);
 int wc_device_arch(int dev, char* buf, int buflen);
 
 /* Per-kernel HIP-event timing of the dominant kernels (GEMMs, attention, PAR), for bench.py's roofline leg.
- * wc_prof_enable(n) clears the records and records one of every n instrumented launches (n = 1: all; an event pair
- * fences its launch, ~6 us), (0) stops.  wc_prof_report synchronises the device and
- * writes one "kernel name \t launches \t total ms \t algorithmic work (flop or bytes)" line per kernel. */
+ * wc_prof_enable(n) clears the records and records one of every n instrumented launches on average (a fixed pseudo-random
+ * pick, so that the sample does not alias with the step; n = 1: all; an event pair fences its launch, ~6 us), (0) stops.
+ * The sweeps of a PAR.forward group share ONE pair (always recorded).  wc_prof_report synchronises the device and writes one
+ * "kernel name \t launches \t total ms \t algorithmic work (flop or bytes) \t ms scaled by each record's sampling weight"
+ * line per kernel. */
 void wc_prof_enable(int stride);
 /* Group tag appended to the kernel names of the launches that follow ("@vit_attn": in-projection, attention, head-mean
  * maps and out-projection of an encoder block, the north star's "ViT attention" group); NULL / "" clears it. */

@@ -497,34 +497,42 @@ extern "C" int wc_par_affinity(const float* img, float* aff, int B, int H, int W
     return WC_OK;
 }
 
+static const char* par_iter_name(int C, bool tiled, bool h16) {
+    static const char* hn[3] = {"par_iter_kernel<2, true, true, 8, 12>", "par_iter_kernel<3, true, true, 8, 12>", "par_iter_kernel<4, true, true, 8, 12>"};
+    static const char* names[2][3] = {{"par_iter_kernel<2, false>", "par_iter_kernel<3, false>", "par_iter_kernel<4, false>"},
+                                      {"par_iter_kernel<2, true>", "par_iter_kernel<3, true>", "par_iter_kernel<4, true>"}};
+    const int ci = C <= 2 ? 0 : (C == 3 ? 1 : 2);
+    return h16 ? hn[ci] : names[tiled ? 1 : 0][ci];
+}
+// algorithmic bytes of one sweep: the affinities (T 16-bit values + a scale, or T floats) + C mask planes read, C written
+static double par_iter_bytes(int B, int C, int H, int W, const ParTaps& tp, bool h16) {
+    return h16 ? B * (double)H * W * (2.0 * tp.n + 4.0 + 8.0 * C) : 4.0 * B * (double)H * W * (tp.n + 2 * C);
+}
+
+// prof: bracket this launch with its own event pair (a stand-alone sweep); the sweeps of a whole PAR.forward share one pair
 static int launch_iter(const float* aff, const float* src, float* dst, int B, int C, int H, int W,
-                       const ParTaps& tp, hipStream_t st, bool tiled, bool h16 = false) {
+                       const ParTaps& tp, hipStream_t st, bool tiled, bool h16 = false, bool prof = true) {
     dim3 grid(wc_cdiv(W, 64), wc_cdiv(H, 4), B);
     if (h16) {       // fp16-pair affinities (tiled layout, 48 taps)
-        const int pr = wc_prof_begin(st);
+        const int pr = prof ? wc_prof_begin(st) : -1;
         // blocks of 64 x 8 pixels with a 12-pixel halo: the tile serves dilations 1..12 (40 of the 48 taps); measured
         // 2.44 ms (4 rows, halo 4) -> 2.29 ms per 16-image PAR.forward
         dim3 grid8(wc_cdiv(W, 64), wc_cdiv(H, 8), B);
         if (C <= 2) hipLaunchKernelGGL((par_iter_kernel<2, true, true, 8, 12>), grid8, dim3(512), 0, st, aff, src, dst, C, H, W, tp);
         else if (C == 3) hipLaunchKernelGGL((par_iter_kernel<3, true, true, 8, 12>), grid8, dim3(512), 0, st, aff, src, dst, C, H, W, tp);
         else hipLaunchKernelGGL((par_iter_kernel<4, true, true, 8, 12>), grid8, dim3(512), 0, st, aff, src, dst, C, H, W, tp);
-        static const char* hn[3] = {"par_iter_kernel<2, true, true, 8, 12>", "par_iter_kernel<3, true, true, 8, 12>", "par_iter_kernel<4, true, true, 8, 12>"};
-        // algorithmic bytes of one sweep: T 16-bit affinities + the scale + C mask planes read, C written
-        wc_prof_end(pr, hn[C <= 2 ? 0 : (C == 3 ? 1 : 2)], B * (double)H * W * (2.0 * tp.n + 4.0 + 8.0 * C), st);
+        wc_prof_end(pr, par_iter_name(C, tiled, true), par_iter_bytes(B, C, H, W, tp, true), st);
         WC_LAUNCH_CHECK("par_iter_kernel");
         return WC_OK;
     }
 #define PAR_ITER_LAUNCH(CG_) \
     if (tiled) hipLaunchKernelGGL((par_iter_kernel<CG_, true>), grid, dim3(256), 0, st, aff, src, dst, C, H, W, tp); \
     else hipLaunchKernelGGL((par_iter_kernel<CG_, false>), grid, dim3(256), 0, st, aff, src, dst, C, H, W, tp);
-    const int pr = wc_prof_begin(st);
+    const int pr = prof ? wc_prof_begin(st) : -1;
     if (C <= 2) { PAR_ITER_LAUNCH(2) }
     else if (C == 3) { PAR_ITER_LAUNCH(3) }
     else { PAR_ITER_LAUNCH(4) }
-    // algorithmic bytes of one sweep: T affinity planes + C mask planes read, C written
-    static const char* names[2][3] = {{"par_iter_kernel<2, false>", "par_iter_kernel<3, false>", "par_iter_kernel<4, false>"},
-                                      {"par_iter_kernel<2, true>", "par_iter_kernel<3, true>", "par_iter_kernel<4, true>"}};
-    wc_prof_end(pr, names[tiled ? 1 : 0][C <= 2 ? 0 : (C == 3 ? 1 : 2)], 4.0 * B * (double)H * W * (tp.n + 2 * C), st);
+    wc_prof_end(pr, par_iter_name(C, tiled, false), par_iter_bytes(B, C, H, W, tp, false), st);
     WC_LAUNCH_CHECK("par_iter_kernel");
     return WC_OK;
 }
@@ -577,12 +585,14 @@ static int par_forward_impl(const float* img, const float* masks, float* out, fl
         launch_affinity(img + (long)b0 * 3 * HW, aff_ws, nb, H, W, tp, st, tiled, h16 && tiled);
         WC_LAUNCH_CHECK("par_affinity_kernel");
         const float* src = masks + (long)b0 * C * HW;
+        const int pr = wc_prof_begin_always(st);   // ONE event pair around the group's num_iter dependent sweeps
         for (int i = 0; i < num_iter; ++i) {
             float* dst = (((num_iter - i) & 1) ? out : tmp) + (long)b0 * C * HW;
-            int rc = launch_iter(aff_ws, src, dst, nb, C, H, W, tp, st, tiled, h16 && tiled);
+            int rc = launch_iter(aff_ws, src, dst, nb, C, H, W, tp, st, tiled, h16 && tiled, false);
             if (rc) return rc;
             src = dst;
         }
+        wc_prof_end_n(pr, par_iter_name(C, tiled, h16 && tiled), num_iter * par_iter_bytes(nb, C, H, W, tp, h16 && tiled), st, num_iter);
     }
     return WC_OK;
 }

@@ -35,14 +35,15 @@ class KernelTimer:
 
     @staticmethod
     def summary():
-        """kernel name -> dict(ms total, launches, work) after a device sync."""
+        """kernel name -> dict(ms total of the recorded launches, launches, work, est_ms = ms scaled by the sampling weight of
+        each record: the kernel's estimated total over the instrumented steps) after a device sync."""
         import ctypes
         buf = ctypes.create_string_buffer(1 << 16)
         L.lib().cdll.wc_prof_report(buf, len(buf))
         out = {}
         for line in buf.value.decode().splitlines():
-            name, n, ms, work = line.split("\t")
-            out[name] = {"ms": float(ms), "launches": int(n), "work": float(work)}
+            name, n, ms, work, est = line.split("\t")
+            out[name] = {"ms": float(ms), "launches": int(n), "work": float(work), "est_ms": float(est)}
         return out
 
 
