@@ -146,7 +146,9 @@ class WeCLIP(nn.Module):
             # Outside the seg-trans branch the CAM -> affinity -> PAR chain reads nothing the head produces (clip_tool.py:146-176
             # takes attn_pred only after iteration 15000): the head's forward runs on a second stream beside it (the HBM-bound
             # PAR sweeps and the small MFMA launches of the decoder fill each other's gaps) and joins before the losses.
-            fork = self.fork_head and want_cam and not seg_trans and img.is_cuda
+            # In the seg-trans branch the affinity does read attn_pred: the fork then covers the last-layer forward + GradCAM,
+            # and the CAM chain joins the head's stream right before the affinity weight (the callable below).
+            fork = self.fork_head and want_cam and img.is_cuda
             if fork:
                 main = torch.cuda.current_stream()
                 if self._side is None:
@@ -156,8 +158,14 @@ class WeCLIP(nn.Module):
                     seg, attn_pred = HeadFunction.apply(self.head_engine, x16, B, Lq, h, w, drop, *self.head_engine.params())
                 finally:
                     self.head_engine.fwd_stream = None
+
+                def joined_attn_pred():
+                    main.wait_stream(self._side)
+                    return attn_pred.detach()
+
                 with torch.no_grad():
-                    cam_labels = self.cam_labels(img, xs[-1], maps, None, img_names, labels, mode, seg_trans, h, w, plan=plan)
+                    cam_labels = self.cam_labels(img, xs[-1], maps, joined_attn_pred if seg_trans else None, img_names, labels, mode,
+                                                 seg_trans, h, w, plan=plan)
                 main.wait_stream(self._side)
                 return seg, cam_labels, attn_pred
             seg, attn_pred = HeadFunction.apply(self.head_engine, x16, B, Lq, h, w, drop, *self.head_engine.params())

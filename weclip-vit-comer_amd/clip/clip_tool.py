@@ -159,6 +159,13 @@ def batch_refined_cams(clip_model, last_rows, maps11, seg_attn, plan, text_hat, 
     need = maps[-n_last:] if seg_trans else maps[-8:]
     if any(m is None for m in need):
         raise RuntimeError("attention maps needed by the affinity were not computed")
+    if callable(seg_attn):      # attn_pred still being computed on another stream (WeCLIP.forward): join it only now
+        if seg_trans:
+            cams, probs, _ = st.grad_cam(text_hat, plan.text_idx, plan.n_text, plan.pair_img, plan.pair_cls, plan.Tmax)
+            W, c1 = CP.affinity_weight(maps, seg_attn(), seg_trans, n_last, keep=keep, return_c1=True)
+            R = CP.refine(W, cams, plan.pair_img, plan.pair_slot, plan.K, h, w, thr, c1=c1)
+            return R, cams, probs, st
+        seg_attn = None
     if _FORK_AFFINITY and last_rows.is_cuda:
         # the affinity weight (HBM-bound sums over the head-mean maps + Sinkhorn sweeps) needs nothing of the GradCAM chain
         # (MFMA-bound GEMMs through the last block): side by side on two streams, joined before the refinement
