@@ -14,7 +14,7 @@ sd = synth.make_clip_state_dict(seed=0, with_text=False)
 bg, fg = synth.make_text_features(20, 25, 512)
 fuse, dec = synth.make_head_state_dicts()
 model = WeCLIP(num_classes=21, clip_model=sd, embedding_dim=256, in_channels=[768] * 4, dataset_root_path=None,
-               device=dev, text_features=(bg.to(dev), fg.to(dev)))
+               device=dev, text_features=(bg.to(dev), fg.to(dev)), comer=len(sys.argv) > 1 and sys.argv[1] == "comer")
 model.decoder_fts_fuse.load_state_dict(fuse)
 model.decoder.load_state_dict(dec)
 model.train()

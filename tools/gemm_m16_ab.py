@@ -11,6 +11,8 @@ lib.wc_gemm_set_m16.argtypes = [ctypes.c_int]
 lib.wc_gemm_set_m16.restype = None
 lib.wc_gemm_set_w4.argtypes = [ctypes.c_int]
 lib.wc_gemm_set_w4.restype = None
+lib.wc_gemm_set_ring10.argtypes = [ctypes.c_int]
+lib.wc_gemm_set_ring10.restype = None
 
 
 def t(f, n=20, rounds=4):
@@ -42,17 +44,22 @@ for name, M, N, K, kw in cases:
     if kw.get("act") == 1: ref = ref * torch.sigmoid(1.702 * ref)
     if res is not None: ref = ref + res[:2048]
     r, err = {}, {}
-    for mode in (0, 1, 2, 0, 1, 2):
+    outs = {}
+    for mode in (0, 1, 2, 3, 0, 1, 2, 3):
         lib.wc_gemm_set_m16(1 if mode == 1 else 0)
         lib.wc_gemm_set_w4(1 if mode == 2 else 0)
+        lib.wc_gemm_set_ring10(1 if mode == 3 else 0)
         o = o32 if o32 is not None else o16
         o.zero_()
         r.setdefault(mode, []).append(t(f))
         out = (o32 if o32 is not None else o16)[:2048].float()
         err[mode] = float((out - ref).abs().max() / ref.abs().max())
+        outs[mode] = (o32 if o32 is not None else o16).clone()
     gf = 2.0 * M * N * K / 1e6
-    a0, a1, a2 = min(r[0]), min(r[1]), min(r[2])
+    a0, a1, a2, a3 = min(r[0]), min(r[1]), min(r[2]), min(r[3])
+    same = bool(torch.equal(outs[0], outs[3]))
     print(f"{name:8s} M={M} N={N} K={K}: 32x32x16 {a0:7.1f} us ({gf / a0:6.1f} TF/s, err {err[0]:.1e})   16x16x32 {a1:7.1f} us "
-          f"({gf / a1:6.1f} TF/s, err {err[1]:.1e}) ratio {a1 / a0:.3f}   4-wave {a2:7.1f} us ({gf / a2:6.1f} TF/s, err {err[2]:.1e}) ratio {a2 / a0:.3f}", flush=True)
+          f"({gf / a1:6.1f} TF/s, err {err[1]:.1e}) ratio {a1 / a0:.3f}   4-wave {a2:7.1f} us ({gf / a2:6.1f} TF/s, err {err[2]:.1e}) ratio {a2 / a0:.3f}   10-slot ring {a3:7.1f} us ({gf / a3:6.1f} TF/s, bit-identical {same}) ratio {a3 / a0:.3f}", flush=True)
 lib.wc_gemm_set_m16(0)
 lib.wc_gemm_set_w4(0)
+lib.wc_gemm_set_ring10(0)

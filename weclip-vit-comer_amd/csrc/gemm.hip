@@ -700,9 +700,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
 // XOR swizzle is conflict-free for that pattern as well) and the same 128 accumulator registers.  The matrix pipe takes the
 // same cycles either way; what differs is the clock the chip holds under the load (MI355X_MICROARCH.md, DVFS item 7).
 #define PP_SLOT 16384
-template <int EK, bool M16>
+// RING = half-tile slots in LDS: 8 (128 KiB, three half-tiles in flight across the barriers) or 10 (all 160 KiB, FIVE in flight;
+// the default).  A fifth of the staged lines miss the XCD's L2 and come from the Infinity Cache, and a half-tile is complete
+// only when its slowest line is; two more half-tiles in flight give 1-3 % (8192^3: 907 -> 881 us, QKV 78.9 -> 76.4 us,
+// bit-identical outputs) -- the depth of the ring is a small part of the transport side's 41 GB/s per CU, not its cause.
+template <int EK, bool M16, int RING = 8>
 __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 8 half-tile slots [128 rows][64 halfs], XOR-swizzled
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // RING half-tile slots [128 rows][64 halfs], XOR-swizzled
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -759,7 +763,9 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
 #define PP_WAIT(n_)                                                                 \
     {                                                                               \
         const int w__ = (n_);                                                       \
-        if (w__ >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");              \
+        if (RING == 10 && w__ >= 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   \
+        else if (RING == 10 && w__ == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); \
+        else if (w__ >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         \
         else if (w__ == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         \
         else if (w__ == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         \
         else if (w__ == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");         \
@@ -806,9 +812,14 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
     if constexpr (M16) gemm_colvals16(g, n0, wc, lane, bv, sc);
     else gemm_colvals(g, n0, wc, lane, 0, bv, sc);
 
-    // prologue: half-tiles 0..5 (nt >= 2 is guaranteed by the launcher), the first two landed
+    // prologue: half-tiles 0..5 (0..7 with the 10-slot ring; nt >= 2 is guaranteed by the launcher), the first two landed
     PP_STAGE(0, 0, 0); PP_STAGE(0, 1, 1); PP_STAGE(0, 2, 2); PP_STAGE(0, 3, 3); PP_STAGE(1, 0, 4); PP_STAGE(1, 1, 5);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (RING == 10) {
+        PP_STAGE(1, 2, 6); PP_STAGE(1, 3, 7);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();       // row group 1 runs one barrier behind group 0
 
@@ -847,7 +858,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
     {                                                                                                         \
         READS_;                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
-        if ((phi_) + 6 < nj) PP_STAGE(tj_, qj_, slotj_);                                                      \
+        if ((phi_) + (RING - 2) < nj) PP_STAGE(tj_, qj_, slotj_);                                             \
         PP_WAIT(nj - 3 - (phi_));                                                                             \
         __builtin_amdgcn_s_barrier();                                                                         \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
@@ -884,7 +895,8 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
     {                                                                                                         \
         READS_;                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                      \
+        if constexpr (RING == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                           \
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                 \
         __builtin_amdgcn_s_barrier();                                                                         \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -911,6 +923,62 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     }
     int t = 0;
+    if constexpr (RING == 10) {
+        // half-tile j -> slot j % 10: the pattern repeats every 20 half-tiles = 5 K-tiles; phase c stages half-tile c + 8
+        for (; t + 7 <= nt; t += 5) {
+            PP_PHASE_S(PP_READ_B(fb0, 1) PP_READ_A(0), t + 2, 0, 8, 0, fb0, 0);
+            PP_PHASE_S(PP_READ_B(fb1, 2), t + 2, 1, 9, 0, fb1, 1);
+            PP_PHASE_S(PP_READ_A(3), t + 2, 2, 0, 1, fb1, 1);
+            PP_PHASE_S(, t + 2, 3, 1, 1, fb0, 0);
+            PP_PHASE_S(PP_READ_B(fb0, 5) PP_READ_A(4), t + 3, 0, 2, 0, fb0, 0);
+            PP_PHASE_S(PP_READ_B(fb1, 6), t + 3, 1, 3, 0, fb1, 1);
+            PP_PHASE_S(PP_READ_A(7), t + 3, 2, 4, 1, fb1, 1);
+            PP_PHASE_S(, t + 3, 3, 5, 1, fb0, 0);
+            PP_PHASE_S(PP_READ_B(fb0, 9) PP_READ_A(8), t + 4, 0, 6, 0, fb0, 0);
+            PP_PHASE_S(PP_READ_B(fb1, 0), t + 4, 1, 7, 0, fb1, 1);
+            PP_PHASE_S(PP_READ_A(1), t + 4, 2, 8, 1, fb1, 1);
+            PP_PHASE_S(, t + 4, 3, 9, 1, fb0, 0);
+            PP_PHASE_S(PP_READ_B(fb0, 3) PP_READ_A(2), t + 5, 0, 0, 0, fb0, 0);
+            PP_PHASE_S(PP_READ_B(fb1, 4), t + 5, 1, 1, 0, fb1, 1);
+            PP_PHASE_S(PP_READ_A(5), t + 5, 2, 2, 1, fb1, 1);
+            PP_PHASE_S(, t + 5, 3, 3, 1, fb0, 0);
+            PP_PHASE_S(PP_READ_B(fb0, 7) PP_READ_A(6), t + 6, 0, 4, 0, fb0, 0);
+            PP_PHASE_S(PP_READ_B(fb1, 8), t + 6, 1, 5, 0, fb1, 1);
+            PP_PHASE_S(PP_READ_A(9), t + 6, 2, 6, 1, fb1, 1);
+            PP_PHASE_S(, t + 6, 3, 7, 1, fb0, 0);
+        }
+        for (; t < nt; t += 5) {          // the last K-tiles: guarded stages, draining waits (t % 5 == 0 here)
+            const int phi = 4 * t;
+            PP_PHASE(phi + 0, PP_READ_B(fb0, 1) PP_READ_A(0), t + 2, 0, 8, PP_MMA(0, fb0, 0));
+            PP_PHASE(phi + 1, PP_READ_B(fb1, 2), t + 2, 1, 9, PP_MMA(0, fb1, 1));
+            PP_PHASE(phi + 2, PP_READ_A(3), t + 2, 2, 0, PP_MMA(1, fb1, 1));
+            PP_PHASE(phi + 3, , t + 2, 3, 1, PP_MMA(1, fb0, 0));
+            if (t + 1 < nt) {
+                PP_PHASE(phi + 4, PP_READ_B(fb0, 5) PP_READ_A(4), t + 3, 0, 2, PP_MMA(0, fb0, 0));
+                PP_PHASE(phi + 5, PP_READ_B(fb1, 6), t + 3, 1, 3, PP_MMA(0, fb1, 1));
+                PP_PHASE(phi + 6, PP_READ_A(7), t + 3, 2, 4, PP_MMA(1, fb1, 1));
+                PP_PHASE(phi + 7, , t + 3, 3, 5, PP_MMA(1, fb0, 0));
+            }
+            if (t + 2 < nt) {
+                PP_PHASE(phi + 8, PP_READ_B(fb0, 9) PP_READ_A(8), t + 4, 0, 6, PP_MMA(0, fb0, 0));
+                PP_PHASE(phi + 9, PP_READ_B(fb1, 0), t + 4, 1, 7, PP_MMA(0, fb1, 1));
+                PP_PHASE(phi + 10, PP_READ_A(1), t + 4, 2, 8, PP_MMA(1, fb1, 1));
+                PP_PHASE(phi + 11, , t + 4, 3, 9, PP_MMA(1, fb0, 0));
+            }
+            if (t + 3 < nt) {
+                PP_PHASE(phi + 12, PP_READ_B(fb0, 3) PP_READ_A(2), t + 5, 0, 0, PP_MMA(0, fb0, 0));
+                PP_PHASE(phi + 13, PP_READ_B(fb1, 4), t + 5, 1, 1, PP_MMA(0, fb1, 1));
+                PP_PHASE(phi + 14, PP_READ_A(5), t + 5, 2, 2, PP_MMA(1, fb1, 1));
+                PP_PHASE(phi + 15, , t + 5, 3, 3, PP_MMA(1, fb0, 0));
+            }
+            if (t + 4 < nt) {
+                PP_PHASE(phi + 16, PP_READ_B(fb0, 7) PP_READ_A(6), t + 6, 0, 4, PP_MMA(0, fb0, 0));
+                PP_PHASE(phi + 17, PP_READ_B(fb1, 8), t + 6, 1, 5, PP_MMA(0, fb1, 1));
+                PP_PHASE(phi + 18, PP_READ_A(9), t + 6, 2, 6, PP_MMA(1, fb1, 1));
+                PP_PHASE(phi + 19, , t + 6, 3, 7, PP_MMA(1, fb0, 0));
+            }
+        }
+    } else {
     for (; t + 4 <= nt; t += 2) {
         PP_PHASE_S(PP_READ_B(fb0, 1) PP_READ_A(0), t + 1, 2, 6, 0, fb0, 0);
         PP_PHASE_S(PP_READ_B(fb1, 2), t + 1, 3, 7, 0, fb1, 1);
@@ -921,8 +989,6 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
         PP_PHASE_S(PP_READ_A(7), t + 3, 0, 4, 1, fb1, 1);
         PP_PHASE_S(, t + 3, 1, 5, 1, fb0, 0);
     }
-#undef PP_STAGE_H
-#undef PP_PHASE_S
     for (; t < nt; t += 2) {          // the last K-tiles: guarded stages, draining waits
         const int phi = 4 * t;
         // K-tile t (even): slots 0..3; stages half-tiles phi+6.. = (t+1: B1 A1), (t+2: A0 B0)
@@ -938,6 +1004,9 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
             PP_PHASE(phi + 7, , t + 3, 1, 5, PP_MMA(1, fb0, 0));
         }
     }
+    }
+#undef PP_STAGE_H
+#undef PP_PHASE_S
 #undef PP_PHASE
 #undef PP_MMA
 #undef PP_MMA16_Q
@@ -1739,6 +1808,8 @@ extern "C" int wc_sum_slices(const float* part, float* out, int nslices, long n,
 // stages FEWER bytes (N = 192, 384, 576: the 256-column tile would carry dead columns), never in the training step.
 static int g_w4 = -1;                    // 256x256 tiles on the 4-wave register-staged kernel (WECLIP_GEMM_W4 / wc_gemm_set_w4)
 extern "C" void wc_gemm_set_w4(int on) { g_w4 = on; }
+static int g_pp_ring10 = -1;             // 256x256 kernel with ten half-tile slots (WECLIP_GEMM_RING10 / wc_gemm_set_ring10)
+extern "C" void wc_gemm_set_ring10(int on) { g_pp_ring10 = on ? 1 : 0; }
 static int g_pp_m16 = -1;                // 256x256 kernel on 16x16x32 MFMAs (WECLIP_GEMM_M16 / wc_gemm_set_m16)
 extern "C" void wc_gemm_set_m16(int on) { g_pp_m16 = on ? 1 : 0; }
 static int g_p192_mode = -1;             // 0: never, 1: by staged bytes, 2: whenever the shape allows
@@ -1907,6 +1978,7 @@ static int gemm_f16_grouped_impl(const void* A0, const void* A1, const void* A2,
             WC_LAUNCH_CHECK("gemm_f16_p192_kernel");
         } else {
             if (g_pp_m16 < 0) g_pp_m16 = getenv("WECLIP_GEMM_M16") ? atoi(getenv("WECLIP_GEMM_M16")) : 0;
+            if (g_pp_ring10 < 0) g_pp_ring10 = getenv("WECLIP_GEMM_RING10") ? atoi(getenv("WECLIP_GEMM_RING10")) : 1;
             if (g_w4 < 0) g_w4 = getenv("WECLIP_GEMM_W4") ? atoi(getenv("WECLIP_GEMM_W4")) : 0;
             if (erf) {
                 static bool erf_attr = false;
@@ -1920,7 +1992,7 @@ static int gemm_f16_grouped_impl(const void* A0, const void* A1, const void* A2,
                     hipLaunchKernelGGL((gemm_f16_pp_kernel<3, false>), gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
                 else
                     hipLaunchKernelGGL((gemm_f16_pp_kernel<2, false>), gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
-                wc_prof_end(pr, use_aux ? "gemm_f16_pp_kernel<3, false>" : "gemm_f16_pp_kernel<2, false>", 2.0 * g.M * N * K, stream);
+                wc_prof_end(pr, use_aux ? "gemm_f16_pp_kernel<3, false, 8>" : "gemm_f16_pp_kernel<2, false, 8>", 2.0 * g.M * N * K, stream);
                 WC_LAUNCH_CHECK("gemm_f16_pp_kernel");
             } else if (g_w4) {
                 if (use_aux)
@@ -1942,14 +2014,27 @@ static int gemm_f16_grouped_impl(const void* A0, const void* A1, const void* A2,
                     hipLaunchKernelGGL((gemm_f16_pp_kernel<true, true>), gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
                 else
                     hipLaunchKernelGGL((gemm_f16_pp_kernel<false, true>), gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
+            } else if (g_pp_ring10) {
+                static bool r10_attr = false;
+                if (!r10_attr) {
+                    WC_CHECK_ARG(hipFuncSetAttribute((const void*)gemm_f16_pp_kernel<0, false, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * PP_SLOT) == hipSuccess &&
+                                 hipFuncSetAttribute((const void*)gemm_f16_pp_kernel<1, false, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * PP_SLOT) == hipSuccess,
+                                 "wc_gemm_f16: cannot reserve 160 KiB of LDS");
+                    r10_attr = true;
+                }
+                if (use_aux)
+                    hipLaunchKernelGGL((gemm_f16_pp_kernel<1, false, 10>), gridp, dim3(512), 10 * PP_SLOT, (hipStream_t)stream, g);
+                else
+                    hipLaunchKernelGGL((gemm_f16_pp_kernel<0, false, 10>), gridp, dim3(512), 10 * PP_SLOT, (hipStream_t)stream, g);
             } else {
                 if (use_aux)
                     hipLaunchKernelGGL((gemm_f16_pp_kernel<true, false>), gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
                 else
                     hipLaunchKernelGGL((gemm_f16_pp_kernel<false, false>), gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
             }
-            wc_prof_end(pr, g_pp_m16 ? (use_aux ? "gemm_f16_pp_kernel<1, true>" : "gemm_f16_pp_kernel<0, true>")
-                                     : (use_aux ? "gemm_f16_pp_kernel<1, false>" : "gemm_f16_pp_kernel<0, false>"), 2.0 * g.M * N * K, stream);
+            wc_prof_end(pr, g_pp_m16 ? (use_aux ? "gemm_f16_pp_kernel<1, true, 8>" : "gemm_f16_pp_kernel<0, true, 8>")
+                            : g_pp_ring10 ? (use_aux ? "gemm_f16_pp_kernel<1, false, 10>" : "gemm_f16_pp_kernel<0, false, 10>")
+                                          : (use_aux ? "gemm_f16_pp_kernel<1, false, 8>" : "gemm_f16_pp_kernel<0, false, 8>"), 2.0 * g.M * N * K, stream);
             WC_LAUNCH_CHECK("gemm_f16_pp_kernel");
         }
         if (!split) return WC_OK;
