@@ -700,9 +700,6 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
 // XOR swizzle is conflict-free for that pattern as well) and the same 128 accumulator registers.  The matrix pipe takes the
 // same cycles either way; what differs is the clock the chip holds under the load (MI355X_MICROARCH.md, DVFS item 7).
 #define PP_SLOT 16384
-#ifndef PP_SPLIT_DMA
-#define PP_SPLIT_DMA 0      // experiment: one of a phase's two DMA instructions in the read segment instead of among the MFMAs
-#endif
 // RING = half-tile slots in LDS: 8 (128 KiB, three half-tiles in flight across the barriers) or 10 (all 160 KiB, FIVE in flight;
 // the default).  A fifth of the staged lines miss the XCD's L2 and come from the Infinity Cache, and a half-tile is complete
 // only when its slowest line is; two more half-tiles in flight give 1-3 % (8192^3: 907 -> 881 us, QKV 78.9 -> 76.4 us,
@@ -898,10 +895,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
     {                                                                                                         \
         READS_;                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
-        if constexpr (RING == 10 && PP_SPLIT_DMA) {      /* first DMA of the phase behind the fragment reads */   \
-            PP_STAGE_H(tj_, qj_, slotj_, 0)                                                                   \
-            asm volatile("s_waitcnt vmcnt(11)" ::: "memory");                                                 \
-        } else if constexpr (RING == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                    \
+        if constexpr (RING == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                           \
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                 \
         __builtin_amdgcn_s_barrier();                                                                         \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
@@ -918,8 +912,8 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(GemmArgs g) {
             _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                \
                 acc[a_][0][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][ks], fb_[ks], acc[a_][0][b_], 0, 0, 0); \
                 acc[a_][1][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][ks], fb_[ks], acc[a_][1][b_], 0, 0, 0); \
-                if (ks == 0 && !(RING == 10 && PP_SPLIT_DMA)) PP_STAGE_H(tj_, qj_, slotj_, 0)                 \
-                if (ks == (RING == 10 && PP_SPLIT_DMA ? 1 : 2)) PP_STAGE_H(tj_, qj_, slotj_, 1)               \
+                if (ks == 0) PP_STAGE_H(tj_, qj_, slotj_, 0)                                                  \
+                if (ks == 2) PP_STAGE_H(tj_, qj_, slotj_, 1)                                                  \
             }                                                                                                 \
             asm volatile("" : "+v"(acc[a_][0][b_]), "+v"(acc[a_][1][b_]));                                    \
         }                                                                                                     \
