@@ -236,6 +236,39 @@ def test_gemm_tall_kernel_variants(ops, variant, M, N, K, nseg):
     assert _rel(o1["r"].float().cpu().double(), (ref - bias.cpu().double()) * (saved.cpu().double() > 0)) < 1e-3
 
 
+@pytest.mark.parametrize("nt", list(range(2, 15)) + [17, 23])
+def test_gemm_tall_ring_every_tail_length(ops, nt):
+    """The 256x256 kernel's K loop is unrolled over 5 K-tiles (10-slot LDS ring) with a guarded tail: every number of K-tiles
+    from 2 to 14 (all tail lengths on both sides of the steady loop's entry condition) and two longer odd ones, against the
+    8-slot build bit for bit and against the fp64 product."""
+    import ctypes
+    from weclip_vit_comer_amd import _lib as L
+    cd = L.lib().cdll
+    cd.wc_gemm_set_ring10.argtypes, cd.wc_gemm_set_ring10.restype = [ctypes.c_int], None
+    M, N, K = 20480 + 16, 512, 64 * nt
+    g = torch.Generator().manual_seed(nt)
+    a = torch.randn(M, K, generator=g).half().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).half().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    _set_p192(0)
+    try:
+        assert cd.wc_gemm_plan(M, N, K, 1, 1) in (1, 2)
+        outs = []
+        for ring10 in (1, 0):
+            cd.wc_gemm_set_ring10(ring10)
+            o = torch.zeros(M, N, device="cuda")
+            ops.gemm(a, w, M, N, K, bias=bias, out32=o)
+            torch.cuda.synchronize()
+            outs.append(o)
+    finally:
+        cd.wc_gemm_set_ring10(1)
+        _set_p192(1)
+    mm = M // 256 * 256
+    assert torch.equal(outs[0][:mm], outs[1][:mm])
+    ref = a.double() @ w.double().t() + bias.double()
+    assert _rel(outs[0].double(), ref) < 2e-6
+
+
 def test_gemm_ragged_rows_split(ops):
     """65 x 4 tiles of 256x256 on 256 CUs: the 16 ragged rows go to a second launch (128x128 kernel);
     residual / fp16 hi+lo outputs / saved pre-activation must line up across the seam."""
