@@ -172,18 +172,19 @@ def test_gemm_tall_192_column_tile(ops, M, N, K, nseg):
     assert _rel(o2["z"].float().cpu().double(), ref * torch.sigmoid(1.702 * ref)) < 1e-3
 
 
-@pytest.mark.parametrize("variant", ["m16", "w4"])
+@pytest.mark.parametrize("variant", ["m16", "w4", "r4"])
 @pytest.mark.parametrize("M,N,K,nseg", [(16400, 768, 768, 1), (16640, 2304, 768, 1), (16400, 1024, 128, 1), (16400, 768, 128, 3)])
 def test_gemm_tall_kernel_variants(ops, variant, M, N, K, nseg):
     """The two opt-in builds of the 256x256 tile (round 3): `m16` = the LDS-DMA kernel on v_mfma_f32_16x16x32_f16 (another
-    accumulator layout through every epilogue path), `w4` = four waves of 128x128, operands through registers.  Each epilogue
+    accumulator layout through every epilogue path), `w4` = four waves of 128x128, operands through registers; `r4` = four waves, LDS-DMA, a whole K-tile of fragments resident in
+    registers.  Each epilogue
     path against the fp64 product and, to fp32 accumulation-order accuracy, against the default kernel: wide fp16 (hi + lo,
     bias, column scale), narrow fp32 + residual (forced-fp16 rounding; fp32 + fp16), QuickGELU + saved pre-activation, ReLU' aux;
     two K-tiles (K = 128), three segments, ragged and whole row counts."""
     import ctypes
     from weclip_vit_comer_amd import _lib as L
     cd = L.lib().cdll
-    for f in (cd.wc_gemm_set_m16, cd.wc_gemm_set_w4):
+    for f in (cd.wc_gemm_set_m16, cd.wc_gemm_set_w4, cd.wc_gemm_set_r4):
         f.argtypes, f.restype = [ctypes.c_int], None
     _set_p192(0)
     g = torch.Generator().manual_seed(M + N + K + 1)
@@ -202,6 +203,7 @@ def test_gemm_tall_kernel_variants(ops, variant, M, N, K, nseg):
     def run(on):
         cd.wc_gemm_set_m16(1 if on and variant == "m16" else 0)
         cd.wc_gemm_set_w4(1 if on and variant == "w4" else 0)
+        cd.wc_gemm_set_r4(1 if on and variant == "r4" else 0)
         o = {}
         o["h"], o["l"] = torch.zeros(M, N, device="cuda", dtype=torch.float16), torch.zeros(M, N, device="cuda", dtype=torch.float16)
         ops.gemm(a, w, M, N, K, bias=bias, out16=o["h"], out16lo=o["l"], scale=0.18, scale_cols=N // 3)
@@ -223,6 +225,7 @@ def test_gemm_tall_kernel_variants(ops, variant, M, N, K, nseg):
     finally:
         cd.wc_gemm_set_m16(0)
         cd.wc_gemm_set_w4(0)
+        cd.wc_gemm_set_r4(0)
         _set_p192(1)
     for k in o0:      # same products, another fp32 summation order: a few fp32 ulps of the sum, one fp16 ulp on the fp16 outputs
         d = (o0[k].float() - o1[k].float()).abs().max().item()

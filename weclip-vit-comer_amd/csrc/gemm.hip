@@ -1222,6 +1222,176 @@ __global__ __launch_bounds__(256) void gemm_f16_w4_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// 256x256x64, four waves, a K-tile's fragments RESIDENT IN REGISTERS (round 3, experiment; the schedule the vendor library's
+// hand-written kernel uses): wave (wr, wc) owns 128x128 (256 accumulator registers), operands come in by
+// LDS-DMA into two LDS images, and a wave reads a WHOLE K-tile of its fragments (32 x 16 B = 128 registers) early:
+//   iteration t (image t & 1):
+//     phase A  MFMAs of k-step 0 | fragment reads of k-steps 2, 3 (k-steps 0, 1 were read in the previous iteration)
+//              barrier: every wave holds all of K-tile t in registers -> image t & 1 is FREE although 3/4 of the MFMAs remain
+//     phase B  MFMAs of k-step 1 | the 16 DMA instructions of K-tile t + 2 into that image
+//     phase C  MFMAs of k-step 2
+//     phase D  wait until K-tile t + 1 has landed (vmcnt(16): K-tile t + 2 stays in flight), barrier,
+//              MFMAs of k-step 3 | fragment reads of k-steps 0, 1 of K-tile t + 1 from the other image
+// so a DMA has ~1.6 K-tiles to land with only two images.
+template <int EK>
+__global__ __launch_bounds__(256) void gemm_f16_r4_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int gx = g.gx, gy = g.gy;
+    const int lin = blockIdx.x;
+    int tx, ty;
+    if (gy >= 16) {          // XCD-aware order, as in the kernels above
+        const int slot = lin >> 3;
+        ty = (slot / gx) * 8 + (lin & 7);
+        tx = slot - (slot / gx) * gx;
+    } else {
+        ty = lin / gx;
+        tx = lin - ty * gx;
+    }
+    if (ty >= gy) return;
+    const int m0 = ty * 256, n0 = tx * 256;
+
+    // DMA sources: wave w stages rows [64w, 64w + 64) of the A and of the W tile, 8 rows x 128 B per instruction; the XOR
+    // swizzle of the LDS image is applied on the source side (lane -> logical chunk), the destination is linear
+    const int r8 = lane >> 3;
+    unsigned offA[8], offB[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = wave * 64 + i * 8 + r8;
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int ra = m0 + row < g.M ? m0 + row : g.M - 1, rb = n0 + row < g.N ? n0 + row : g.N - 1;
+        offA[i] = (unsigned)(((long)ra * g.lda + c * 8) * 2);
+        offB[i] = (unsigned)(((long)rb * g.ldw + c * 8) * 2);
+    }
+    const int hh = lane >> 5, l31 = lane & 31;
+    int aaddr[4], baddr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int ra = wr * 128 + l31, rb = wc * 128 + l31;
+        aaddr[ks] = ra * 128 + (((2 * ks + hh) ^ ((ra >> 1) & 7)) << 4);
+        baddr[ks] = 32768 + rb * 128 + (((2 * ks + hh) ^ ((rb >> 1) & 7)) << 4);
+    }
+    f32x16 acc[2][2][2][2];      // [row block rb][column block cb][mi][ni]: MFMA tile (mt, nt) = (2 rb + mi, 2 cb + ni)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][i][j][r] = 0.f;
+
+    const int ktiles = g.K / BK;
+    const int nt = ktiles * g.nseg;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    f16x8 fa[4][4], fb[4][4];      // [k-step][row / column tile]: one whole K-tile
+    int wimg = 0;                  // byte offset of the image the next DMAs go to
+#define R4_BASES(t_)                                                                                          \
+    const int seg__ = (t_) / ktiles;                                                                          \
+    const long k0__ = (long)((t_) - seg__ * ktiles) * BK;                                                     \
+    const char* PA__ = reinterpret_cast<const char*>((seg__ == 0 ? g.A[0] : (seg__ == 1 ? g.A[1] : g.A[2])) + k0__); \
+    const char* PW__ = reinterpret_cast<const char*>((seg__ == 0 ? g.W[0] : (seg__ == 1 ? g.W[1] : g.W[2])) + k0__);
+    // DMA piece i (0..7 A, 8..15 W) of the K-tile whose bases are in scope
+#define R4_DMA(i_)                                                                                            \
+    {                                                                                                         \
+        unsigned o__ = (i_) < 8 ? offA[(i_) & 7] : offB[(i_) & 7];                                            \
+        asm volatile("" : "+v"(o__));                                                                         \
+        const char* src__ = ((i_) < 8 ? PA__ : PW__) + o__;                                                   \
+        char* dst__ = smem + wimg + ((i_) < 8 ? 0 : 32768) + (wave * 64 + ((i_) & 7) * 8) * 128;              \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)src__, (lds_ptr)dst__, 16, 0, 0);                           \
+    }
+    // fragment j (0..3 A row tiles, 4..7 W column tiles) of k-step ks_
+#define R4_READ(ks_, j_)                                                                                      \
+    if ((j_) < 4) fa[ks_][(j_) & 3] = *reinterpret_cast<const f16x8*>(smem + aaddr[ks_] + ((j_) & 3) * 4096);   \
+    else fb[ks_][(j_) & 3] = *reinterpret_cast<const f16x8*>(smem + baddr[ks_] + ((j_) & 3) * 4096);
+#define R4_SB __builtin_amdgcn_sched_barrier(0);
+#define R4_MMA(ks_, j_)                                                                                       \
+    {                                                                                                         \
+        constexpr int mt__ = (j_) >> 2, nt__ = (mt__ & 1) ? 3 - ((j_) & 3) : (j_) & 3;                        \
+        acc[mt__ >> 1][nt__ >> 1][mt__ & 1][nt__ & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                \
+            fa[ks_][mt__], fb[ks_][nt__], acc[mt__ >> 1][nt__ >> 1][mt__ & 1][nt__ & 1], 0, 0, 0);             \
+    }
+#define R4_REP16(X_) X_(0) X_(1) X_(2) X_(3) X_(4) X_(5) X_(6) X_(7) X_(8) X_(9) X_(10) X_(11) X_(12) X_(13) X_(14) X_(15)
+
+    // prologue: K-tiles 0 and 1 requested, K-tile 0 landed, its k-steps 0, 1 in registers
+    {
+        R4_BASES(0)
+#define R4_P(j_) R4_DMA(j_)
+        R4_REP16(R4_P)
+    }
+    wimg ^= W4_IMG;
+    if (nt > 1) {
+        R4_BASES(1)
+        R4_REP16(R4_P)
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#undef R4_P
+    wimg ^= W4_IMG;
+    __builtin_amdgcn_s_barrier();
+#define R4_P(j_) if ((j_) < 8) { R4_READ(0, (j_) & 7) } else { R4_READ(1, (j_) & 7) }
+    R4_REP16(R4_P)
+#undef R4_P
+
+    // read order inside a phase: the fragments the next MFMAs need first (A0 B0 B1 B2 B3 A1 A2 A3 of a k-step)
+#define R4_FR(r_) ((r_) == 0 ? 0 : (r_) <= 4 ? (r_) + 3 : (r_) - 4)
+#define R4_A(j_) { R4_READ(2 + ((j_) >> 3), R4_FR((j_) & 7)) } R4_SB R4_MMA(0, j_) R4_SB
+#define R4_B(j_) if (LD) { R4_DMA(j_) } R4_SB R4_MMA(1, j_) R4_SB
+#define R4_C(j_) R4_SB R4_MMA(2, j_) R4_SB
+#define R4_D(j_) if (WR) { R4_READ((j_) >> 3, R4_FR((j_) & 7)) } R4_SB R4_MMA(3, j_) R4_SB
+#define R4_ITER(t_)                                                                                           \
+    {                                                                                                         \
+        R4_BASES((t_) + 2)                                                                                    \
+        R4_SB                                                                                                 \
+        R4_REP16(R4_A)                                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+        __builtin_amdgcn_s_barrier();      /* the image of K-tile t is free */                                \
+        R4_SB                                                                                                 \
+        R4_REP16(R4_B)                                                                                        \
+        R4_REP16(R4_C)                                                                                        \
+        if (WR) {                                                                                             \
+            if (LD) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                         \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+            __builtin_amdgcn_s_barrier();  /* K-tile t + 1 is in the other image */                           \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) { aaddr[ks] ^= W4_IMG; baddr[ks] ^= W4_IMG; }    \
+        }                                                                                                     \
+        R4_SB                                                                                                 \
+        R4_REP16(R4_D)                                                                                        \
+        wimg ^= W4_IMG;                                                                                       \
+    }
+    int t = 0;
+    for (; t + 2 < nt; ++t) { constexpr bool WR = true, LD = true; R4_ITER(t) }
+    if (t + 1 < nt) { constexpr bool WR = true, LD = false; R4_ITER(t) ++t; }
+    { constexpr bool WR = false, LD = false; R4_ITER(t) }
+#undef R4_ITER
+#undef R4_A
+#undef R4_B
+#undef R4_C
+#undef R4_D
+#undef R4_FR
+#undef R4_REP16
+#undef R4_MMA
+#undef R4_SB
+#undef R4_READ
+#undef R4_DMA
+#undef R4_BASES
+    __syncthreads();                                 // every wave is done with the operand images: epilogue scratch
+    float bv0[2], sc0[2], bv1[2], sc1[2];
+    gemm_colvals(g, n0, wc * 2, lane, 0, bv0, sc0);
+    gemm_colvals(g, n0, wc * 2 + 1, lane, 0, bv1, sc1);
+    gemm_epilogue<EK, 2, false>(g, acc[0][0], m0 + wr * 128, n0, 0, wc * 2, lane, 0, smem + wave * 8192, bv0, sc0, 0);
+    gemm_epilogue<EK, 2, false>(g, acc[0][1], m0 + wr * 128, n0, 0, wc * 2 + 1, lane, 0, smem + wave * 8192, bv1, sc1, 0);
+    gemm_epilogue<EK, 2, false>(g, acc[1][0], m0 + wr * 128 + 64, n0, 0, wc * 2, lane, 0, smem + wave * 8192, bv0, sc0, 0);
+    gemm_epilogue<EK, 2, false>(g, acc[1][1], m0 + wr * 128 + 64, n0, 0, wc * 2 + 1, lane, 0, smem + wave * 8192, bv1, sc1, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // 256x192x64 variant of the ping-pong kernel (round 3): for N = 768 / 2304 a 192-column tile gives 4 / 12 tile columns, so
 // 16 images x 1025 tokens (64 full 256-row tiles) make 256 / 768 tiles = EXACTLY 1 / 3 rounds of the 256 CUs, where the
 // 256x256 tile leaves a quarter of the chip idle (192 tiles = 0.75 round, 576 = 2.25 rounds).
@@ -1806,6 +1976,8 @@ extern "C" int wc_sum_slices(const float* part, float* out, int nslices, long n,
 // (per CU the LDS-DMA path, 1.26 us per K-tile with 24 CUs active; contention between CUs adds to it: 1.66 us at 192 CUs),
 // so filling the idle quarter of the chip only raises the contention.  The 192-column tile is therefore taken only where it
 // stages FEWER bytes (N = 192, 384, 576: the 256-column tile would carry dead columns), never in the training step.
+static int g_r4 = 0;                     // 256x256 tiles on the 4-wave register-resident-fragments kernel (wc_gemm_set_r4; experiment)
+extern "C" void wc_gemm_set_r4(int on) { g_r4 = on ? 1 : 0; }
 static int g_w4 = -1;                    // 256x256 tiles on the 4-wave register-staged kernel (WECLIP_GEMM_W4 / wc_gemm_set_w4)
 extern "C" void wc_gemm_set_w4(int on) { g_w4 = on; }
 static int g_pp_ring10 = -1;             // 256x256 kernel with ten half-tile slots (WECLIP_GEMM_RING10 / wc_gemm_set_ring10)
@@ -1994,6 +2166,20 @@ static int gemm_f16_grouped_impl(const void* A0, const void* A1, const void* A2,
                     hipLaunchKernelGGL((gemm_f16_pp_kernel<2, false>), gridp, dim3(512), 8 * PP_SLOT, (hipStream_t)stream, g);
                 wc_prof_end(pr, use_aux ? "gemm_f16_pp_kernel<3, false, 8>" : "gemm_f16_pp_kernel<2, false, 8>", 2.0 * g.M * N * K, stream);
                 WC_LAUNCH_CHECK("gemm_f16_pp_kernel");
+            } else if (g_r4) {
+                static bool r4_attr = false;
+                if (!r4_attr) {
+                    WC_CHECK_ARG(hipFuncSetAttribute((const void*)gemm_f16_r4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W4_IMG) == hipSuccess &&
+                                 hipFuncSetAttribute((const void*)gemm_f16_r4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W4_IMG) == hipSuccess,
+                                 "wc_gemm_f16: cannot reserve 128 KiB of LDS");
+                    r4_attr = true;
+                }
+                if (use_aux)
+                    hipLaunchKernelGGL(gemm_f16_r4_kernel<1>, gridp, dim3(256), 2 * W4_IMG, (hipStream_t)stream, g);
+                else
+                    hipLaunchKernelGGL(gemm_f16_r4_kernel<0>, gridp, dim3(256), 2 * W4_IMG, (hipStream_t)stream, g);
+                wc_prof_end(pr, use_aux ? "gemm_f16_r4_kernel<1>" : "gemm_f16_r4_kernel<0>", 2.0 * g.M * N * K, stream);
+                WC_LAUNCH_CHECK("gemm_f16_r4_kernel");
             } else if (g_w4) {
                 if (use_aux)
                     hipLaunchKernelGGL(gemm_f16_w4_kernel<true>, gridp, dim3(256), 2 * W4_IMG, (hipStream_t)stream, g);
