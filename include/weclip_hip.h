@@ -179,7 +179,7 @@ int wc_gemm_log_report(char* buf, int cap);
  * 8-wave LDS-DMA ping-pong kernel.  Process-wide; initial value from WECLIP_GEMM_W4. */
 void wc_gemm_set_w4(int on);
 /* 256x256 tiles on the 4-wave kernel that keeps a whole K-tile of fragments in registers (LDS-DMA into two images, prefetch
- * distance ~1.6 K-tiles): an experiment, off by default.  Process-wide. */
+ * distance ~1.6 K-tiles): an experiment, off by default.  1 = DMA by global_load_lds, 2 = by buffer_load ... lds.  Process-wide. */
 void wc_gemm_set_r4(int on);
 /* Half-tile slots of the 256x256 kernel's LDS ring: 0 = 8 (128 KiB, three half-tiles in flight), 1 = 10 (160 KiB, five in
  * flight).  Bit-identical results.  Process-wide; initial value from WECLIP_GEMM_RING10. */

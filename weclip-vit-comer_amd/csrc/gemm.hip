@@ -1233,7 +1233,9 @@ __global__ __launch_bounds__(256) void gemm_f16_w4_kernel(GemmArgs g) {
 //     phase D  wait until K-tile t + 1 has landed (vmcnt(16): K-tile t + 2 stays in flight), barrier,
 //              MFMAs of k-step 3 | fragment reads of k-steps 0, 1 of K-tile t + 1 from the other image
 // so a DMA has ~1.6 K-tiles to land with only two images.
-template <int EK>
+// BUF: the DMA as `buffer_load_dwordx4 v, s[rsrc], s_off offen lds` (row-group offsets in SGPRs, two lane-offset registers for all
+// sixteen pieces, rows past the matrix read as zeros by the buffer's range check) instead of global_load_lds with a lane offset each.
+template <int EK, bool BUF = false>
 __global__ __launch_bounds__(256) void gemm_f16_r4_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1265,6 +1267,20 @@ __global__ __launch_bounds__(256) void gemm_f16_r4_kernel(GemmArgs g) {
         offA[i] = (unsigned)(((long)ra * g.lda + c * 8) * 2);
         offB[i] = (unsigned)(((long)rb * g.ldw + c * 8) * 2);
     }
+    // BUF: lane offsets inside an 8-row group (two variants: the swizzle of row 64w + 8i + r8 depends on the parity of i),
+    // scalar offsets of the row groups
+    int vA[2], vB[2], sA[8], sB[8];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int c = (lane & 7) ^ (((r8 >> 1) ^ (par * 4)) & 7);
+        vA[par] = (int)(((long)r8 * g.lda + c * 8) * 2);
+        vB[par] = (int)(((long)r8 * g.ldw + c * 8) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sA[i] = (int)(((long)(m0 + wave * 64 + i * 8) * g.lda) * 2);
+        sB[i] = (int)(((long)(n0 + wave * 64 + i * 8) * g.ldw) * 2);
+    }
     const int hh = lane >> 5, l31 = lane & 31;
     int aaddr[4], baddr[4];
 #pragma unroll
@@ -1291,19 +1307,27 @@ __global__ __launch_bounds__(256) void gemm_f16_r4_kernel(GemmArgs g) {
     typedef const __attribute__((address_space(1))) void* gbl_ptr;
     f16x8 fa[4][4], fb[4][4];      // [k-step][row / column tile]: one whole K-tile
     int wimg = 0;                  // byte offset of the image the next DMAs go to
+    const long bytesA = (long)g.M * g.lda * 2, bytesW = (long)g.N * g.ldw * 2;      // (< 4 GiB: checked by the launcher)
 #define R4_BASES(t_)                                                                                          \
     const int seg__ = (t_) / ktiles;                                                                          \
     const long k0__ = (long)((t_) - seg__ * ktiles) * BK;                                                     \
     const char* PA__ = reinterpret_cast<const char*>((seg__ == 0 ? g.A[0] : (seg__ == 1 ? g.A[1] : g.A[2])) + k0__); \
-    const char* PW__ = reinterpret_cast<const char*>((seg__ == 0 ? g.W[0] : (seg__ == 1 ? g.W[1] : g.W[2])) + k0__);
+    const char* PW__ = reinterpret_cast<const char*>((seg__ == 0 ? g.W[0] : (seg__ == 1 ? g.W[1] : g.W[2])) + k0__); \
+    __amdgpu_buffer_rsrc_t RA__ = __builtin_amdgcn_make_buffer_rsrc((void*)PA__, 0, BUF ? (int)(bytesA - k0__ * 2) : 0, 0x00020000); \
+    __amdgpu_buffer_rsrc_t RW__ = __builtin_amdgcn_make_buffer_rsrc((void*)PW__, 0, BUF ? (int)(bytesW - k0__ * 2) : 0, 0x00020000);
     // DMA piece i (0..7 A, 8..15 W) of the K-tile whose bases are in scope
 #define R4_DMA(i_)                                                                                            \
     {                                                                                                         \
-        unsigned o__ = (i_) < 8 ? offA[(i_) & 7] : offB[(i_) & 7];                                            \
-        asm volatile("" : "+v"(o__));                                                                         \
-        const char* src__ = ((i_) < 8 ? PA__ : PW__) + o__;                                                   \
         char* dst__ = smem + wimg + ((i_) < 8 ? 0 : 32768) + (wave * 64 + ((i_) & 7) * 8) * 128;              \
-        __builtin_amdgcn_global_load_lds((gbl_ptr)src__, (lds_ptr)dst__, 16, 0, 0);                           \
+        if constexpr (BUF) {                                                                                  \
+            if ((i_) < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(RA__, (lds_ptr)dst__, 16, vA[(i_) & 1], sA[(i_) & 7], 0, 0); \
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(RW__, (lds_ptr)dst__, 16, vB[(i_) & 1], sB[(i_) & 7], 0, 0);          \
+        } else {                                                                                              \
+            unsigned o__ = (i_) < 8 ? offA[(i_) & 7] : offB[(i_) & 7];                                        \
+            asm volatile("" : "+v"(o__));                                                                     \
+            const char* src__ = ((i_) < 8 ? PA__ : PW__) + o__;                                               \
+            __builtin_amdgcn_global_load_lds((gbl_ptr)src__, (lds_ptr)dst__, 16, 0, 0);                       \
+        }                                                                                                     \
     }
     // fragment j (0..3 A row tiles, 4..7 W column tiles) of k-step ks_
 #define R4_READ(ks_, j_)                                                                                      \
@@ -1977,7 +2001,7 @@ extern "C" int wc_sum_slices(const float* part, float* out, int nslices, long n,
 // so filling the idle quarter of the chip only raises the contention.  The 192-column tile is therefore taken only where it
 // stages FEWER bytes (N = 192, 384, 576: the 256-column tile would carry dead columns), never in the training step.
 static int g_r4 = 0;                     // 256x256 tiles on the 4-wave register-resident-fragments kernel (wc_gemm_set_r4; experiment)
-extern "C" void wc_gemm_set_r4(int on) { g_r4 = on ? 1 : 0; }
+extern "C" void wc_gemm_set_r4(int on) { g_r4 = on; }      // 1: global_load_lds, 2: buffer_load ... lds
 static int g_w4 = -1;                    // 256x256 tiles on the 4-wave register-staged kernel (WECLIP_GEMM_W4 / wc_gemm_set_w4)
 extern "C" void wc_gemm_set_w4(int on) { g_w4 = on; }
 static int g_pp_ring10 = -1;             // 256x256 kernel with ten half-tile slots (WECLIP_GEMM_RING10 / wc_gemm_set_ring10)
@@ -2174,7 +2198,15 @@ static int gemm_f16_grouped_impl(const void* A0, const void* A1, const void* A2,
                                  "wc_gemm_f16: cannot reserve 128 KiB of LDS");
                     r4_attr = true;
                 }
-                if (use_aux)
+                if (g_r4 == 2 && !use_aux) {
+                    static bool r4b_attr = false;
+                    if (!r4b_attr) {
+                        WC_CHECK_ARG(hipFuncSetAttribute((const void*)gemm_f16_r4_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W4_IMG) == hipSuccess,
+                                     "wc_gemm_f16: cannot reserve 128 KiB of LDS");
+                        r4b_attr = true;
+                    }
+                    hipLaunchKernelGGL((gemm_f16_r4_kernel<0, true>), gridp, dim3(256), 2 * W4_IMG, (hipStream_t)stream, g);
+                } else if (use_aux)
                     hipLaunchKernelGGL(gemm_f16_r4_kernel<1>, gridp, dim3(256), 2 * W4_IMG, (hipStream_t)stream, g);
                 else
                     hipLaunchKernelGGL(gemm_f16_r4_kernel<0>, gridp, dim3(256), 2 * W4_IMG, (hipStream_t)stream, g);
