@@ -65,7 +65,6 @@ class WeCLIP(nn.Module):
         self.comer = CoMerInteraction(embedding_dim) if comer else None
         self.fork_head = os.environ.get("WECLIP_FORK_HEAD", "1") != "0"      # head forward beside the CAM chain (second stream)
         self.fork_mean = os.environ.get("WECLIP_FORK_MEAN", "0") != "0"      # head-mean maps beside the blocks' GEMMs: measured slower, off
-        self._side = None
         self.to(device)
 
     def get_param_groups(self):
@@ -108,9 +107,7 @@ class WeCLIP(nn.Module):
         # per step): the GEMMs lose more to the shared L2 / fabric than the idle CUs give -- off by default.
         mean_side = None
         if self.fork_mean and img.is_cuda and any(need):
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=img.device)
-            mean_side = (self._side, [])
+            mean_side = (CT.side_stream(img.device), [])
         for i in range(vis.transformer.layers - 1):
             rows, m = VE.run_block(vis.transformer.resblocks[i].pack(), rows, B, Lq, want_mean=need[i], x16_out=x16,
                                    tag=b"@vit_attn", mean_side=mean_side if need[i] else None)
@@ -144,29 +141,28 @@ class WeCLIP(nn.Module):
                 p = self.decoder_fts_fuse.dropout.p
                 drop = ((torch.rand(B, self.embedding_dim, device=img.device) >= p).float() / (1.0 - p)).contiguous()
             # Outside the seg-trans branch the CAM -> affinity -> PAR chain reads nothing the head produces (clip_tool.py:146-176
-            # takes attn_pred only after iteration 15000): the head's forward runs on a second stream beside it (the HBM-bound
-            # PAR sweeps and the small MFMA launches of the decoder fill each other's gaps) and joins before the losses.
+            # takes attn_pred only after iteration 15000): the head's forward runs on a second stream beside it and joins before the
+            # losses (measured: the gain comes from running beside the last-layer / GradCAM GEMMs; beside the PAR sweeps it is a loss).
             # In the seg-trans branch the affinity does read attn_pred: the fork then covers the last-layer forward + GradCAM,
             # and the CAM chain joins the head's stream right before the affinity weight (the callable below).
             fork = self.fork_head and want_cam and img.is_cuda
             if fork:
                 main = torch.cuda.current_stream()
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=img.device)
-                self.head_engine.fwd_stream = self._side
+                side = CT.side_stream(img.device)
+                self.head_engine.fwd_stream = side
                 try:
                     seg, attn_pred = HeadFunction.apply(self.head_engine, x16, B, Lq, h, w, drop, *self.head_engine.params())
                 finally:
                     self.head_engine.fwd_stream = None
 
                 def joined_attn_pred():
-                    main.wait_stream(self._side)
+                    main.wait_stream(side)
                     return attn_pred.detach()
 
                 with torch.no_grad():
                     cam_labels = self.cam_labels(img, xs[-1], maps, joined_attn_pred if seg_trans else None, img_names, labels, mode,
                                                  seg_trans, h, w, plan=plan)
-                main.wait_stream(self._side)
+                main.wait_stream(side)
                 return seg, cam_labels, attn_pred
             seg, attn_pred = HeadFunction.apply(self.head_engine, x16, B, Lq, h, w, drop, *self.head_engine.params())
         else:
@@ -175,14 +171,13 @@ class WeCLIP(nn.Module):
             fork = self.fork_head and want_cam and not seg_trans and img.is_cuda and self.head_impl == "hip" and self.training
             if fork:
                 main = torch.cuda.current_stream()
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=img.device)
-                self._side.wait_stream(main)
-                with torch.cuda.stream(self._side):
+                side = CT.side_stream(img.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
                     seg, attn_pred = self._module_head(img, xs, x16, comer_tokens, B, Lq, h, w)
                 with torch.no_grad():
                     cam_labels = self.cam_labels(img, xs[-1], maps, None, img_names, labels, mode, seg_trans, h, w, plan=plan)
-                main.wait_stream(self._side)
+                main.wait_stream(side)
                 return seg, cam_labels, attn_pred
             seg, attn_pred = self._module_head(img, xs, x16, comer_tokens, B, Lq, h, w)
         if mode == "val" and not self.val_runs_cam:
@@ -194,7 +189,7 @@ class WeCLIP(nn.Module):
 
     def side_streams(self):
         """Streams (besides the caller's) that forward / backward work of this model may run on."""
-        return [self._side] if self._side is not None else []
+        return CT.side_streams()      # (kept outside the module: a stream object must not end up in a pickled / deep-copied model)
 
     def _module_head(self, img, xs, x16, comer_tokens, B, Lq, h, w):
         """Adapters [+ ViT-CoMer inserts] -> decoder -> attn_pred through autograd nodes (every head form but the fused engine)."""

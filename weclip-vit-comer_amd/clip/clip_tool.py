@@ -170,7 +170,7 @@ def batch_refined_cams(clip_model, last_rows, maps11, seg_attn, plan, text_hat, 
         # the affinity weight (HBM-bound sums over the head-mean maps + Sinkhorn sweeps) needs nothing of the GradCAM chain
         # (MFMA-bound GEMMs through the last block): side by side on two streams, joined before the refinement
         main = torch.cuda.current_stream()
-        side = _side_stream(last_rows.device)
+        side = side_stream(last_rows.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             W, c1 = CP.affinity_weight(maps, seg_attn, seg_trans, n_last, keep=keep, return_c1=True)
@@ -187,11 +187,16 @@ _FORK_AFFINITY = os.environ.get("WECLIP_FORK_AFFINITY", "0") != "0"      # measu
 _SIDE = {}
 
 
-def _side_stream(dev):
-    key = (dev.type, dev.index)
+def side_stream(dev):
+    """The package's second HIP stream on `dev` (head forward beside the CAM chain; the optional affinity / head-mean forks)."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=dev)
     return _SIDE[key]
+
+
+def side_streams():
+    return list(_SIDE.values())
 
 
 def _single(img_path, image, image_features, attn_weight_list, seg_attn, bg_text_features, fg_text_features,
