@@ -55,8 +55,10 @@ def parse():
     ap.add_argument("--single-stream", action="store_true",
                     help="head forward on the step's own stream instead of beside the CAM chain (profiling passes: a kernel trace "
                          "then times every kernel alone)")
-    ap.add_argument("--cpu-images", type=int, default=2, help="images in the bounded CPU-oracle sample")
-    ap.add_argument("--cpu-images-1thread", type=int, default=1, help="images in the single-thread CPU-oracle sample (0: skip)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region of --steps steps is run this many times; `value` is the first, all are reported")
+    ap.add_argument("--cpu-images", type=int, default=1, help="images per point of the CPU-oracle thread sweep")
+    ap.add_argument("--cpu-threads", default="1,8,32,all", help="thread counts of the CPU-oracle sweep")
     return ap.parse_args()
 
 
@@ -99,22 +101,27 @@ def cpu_baseline(args):
         loss.backward()
         return time.time() - t0
 
-    what = (f"images {args.size}x{args.size}, K={args.classes_per_image}: oracle forward (encoder, GradCAM, affinity, PAR) + "
-            f"losses + head backward")
-    n = args.cpu_images
-    dt = run(n)
-    out = {"value": n / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"{n} {what}, {dt:.1f} s"}
-    if args.cpu_images_1thread > 0:          # n in {1, all cores}
-        allc = torch.get_num_threads()
-        torch.set_num_threads(1)
-        try:
-            n1 = args.cpu_images_1thread
-            dt1 = run(n1)
-            out["single_thread"] = {"value": n1 / dt1, "unit": "images/sec", "cores": 1, "sample": f"{n1} {what}, {dt1:.1f} s"}
-        finally:
-            torch.set_num_threads(allc)
-    return out
+    what = (f"{args.cpu_images} image(s) {args.size}x{args.size}, K={args.classes_per_image}: oracle forward (encoder, GradCAM, "
+            f"affinity, PAR) + losses + head backward")
+    allc = torch.get_num_threads()
+    counts = []
+    for tok in str(args.cpu_threads).split(","):
+        n = allc if tok.strip() == "all" else int(tok)
+        if 1 <= n <= allc and n not in counts:
+            counts.append(n)
+    sweep = {}
+    try:
+        for n in counts:          # SURVEY section 8d asks n in {1, all}; the port's many small torch ops peak in between
+            torch.set_num_threads(n)
+            dt = run(args.cpu_images)
+            sweep[n] = (args.cpu_images / dt, dt)
+    finally:
+        torch.set_num_threads(allc)
+    best = max(sweep, key=lambda n: sweep[n][0])
+    return {"value": sweep[best][0], "unit": "images/sec", "cores": best, "best_threads": best, "kind": "port",
+            "host_cores": allc,
+            "sample": f"{what}; best of a thread sweep, {sweep[best][1]:.1f} s at {best} threads",
+            "thread_sweep": {str(n): {"images_per_sec": round(v[0], 4), "seconds": round(v[1], 1)} for n, v in sweep.items()}}
 
 
 def make_model(dev, comer=False, seg_trans=False):
@@ -153,14 +160,17 @@ def timed_steps(step, loader, n, world, dev):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    per_rank = [dt]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return dt, t_enq, t_cpu
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [float(x.item()) for x in allt]
+        dt = max(per_rank)                      # the job is as slow as its slowest rank
+    return dt, t_enq, t_cpu, per_rank
 
 
-def run_leg(args, dev, rank, world, *, comer=False, seg_trans=False, steps=None, warmup=None, graph=True):
+def run_leg(args, dev, rank, world, *, comer=False, seg_trans=False, steps=None, warmup=None, graph=True, repeats=1):
     """Build a model + TrainStep, warm up, time `steps` steps.  -> (dict, step, loader)"""
     from weclip_vit_comer_amd.data import SyntheticVOCLoader
     from weclip_vit_comer_amd.train_step import TrainStep
@@ -168,8 +178,8 @@ def run_leg(args, dev, rank, world, *, comer=False, seg_trans=False, steps=None,
     warmup = args.warmup if warmup is None else warmup
     model = make_model(dev, comer=comer, seg_trans=seg_trans)
     if args.single_stream:
-        model.fork_head = model.fork_mean = False
-    use_graph = graph and (not comer or os.environ.get("WECLIP_COMER_GRAPH", "1") != "0")
+        model.fork_head = False
+    use_graph = graph
     step = TrainStep(model, graph=use_graph)
     loader = SyntheticVOCLoader(args.batch, args.size, args.classes_per_image, rank=rank, world=world, device=dev,
                                 source="uint8")      # device-side rescale / flip / crop / normalise inside every step
@@ -179,7 +189,12 @@ def run_leg(args, dev, rank, world, *, comer=False, seg_trans=False, steps=None,
     for _ in range(warmup):
         img, labels = loader.next()
         step(img, labels=labels)
-    dt, t_enq, t_cpu = timed_steps(step, loader, steps, world, dev)
+    dt, t_enq, t_cpu, per_rank = timed_steps(step, loader, steps, world, dev)
+    # the same region again (a 0.26 s region cannot resolve 2 %): `value` stays the FIRST region of exactly
+    # `steps` steps; the repeats show the run-to-run spread inside one process on one box
+    rep_ms = [dt / steps * 1e3]
+    for _ in range(max(0, repeats - 1)):
+        rep_ms.append(timed_steps(step, loader, steps, world, dev)[0] / steps * 1e3)
     # host work per step, free of back-pressure: each step enqueued onto an IDLE queue (in the timed region above the host
     # runs ahead of the GPU-bound device and then blocks in the loader's pinned-buffer event, which is waiting, not work)
     import torch
@@ -192,15 +207,36 @@ def run_leg(args, dev, rank, world, *, comer=False, seg_trans=False, steps=None,
         t_idle += time.perf_counter() - t0
     torch.cuda.synchronize()
     dp_check = None
+    dp_diag = None
     if world > 1:      # every rank must hold the same parameters after the same number of all-reduced steps
         import torch.distributed as dist
+        # diagnostics for the first multi-GPU hardware run: the gradient exchange alone (the bucket's all-reduce + 1/world scale,
+        # 20 back-to-back calls on an otherwise idle GPU, HIP events on this rank's stream) and the spread of the ranks' clocks
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        keep = step.bucket.flat.clone()
+        step.bucket.all_reduce_mean()
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0.record()
+        for _ in range(20):
+            step.bucket.all_reduce_mean()
+        e1.record()
+        torch.cuda.synchronize()
+        step.bucket.flat.copy_(keep)
+        dp_diag = {"allreduce_ms_per_step": round(e0.elapsed_time(e1) / 20, 4),
+                   "allreduce_bytes": int(step.bucket.flat.numel() * 4),
+                   "rank_ms_per_step_min": round(min(per_rank) / steps * 1e3, 3),
+                   "rank_ms_per_step_max": round(max(per_rank) / steps * 1e3, 3)}
         ps = [p.detach().double() for p in model.get_param_groups()[3]]
         ck = torch.stack([sum(p.sum() for p in ps), sum((p * p).sum() for p in ps)]).to(dev)
         allck = [torch.zeros_like(ck) for _ in range(world)]
         dist.all_gather(allck, ck)
         dp_check = {"params_identical_across_ranks": bool(all(torch.equal(allck[0], c) for c in allck)),
                     "param_checksum": [float(v) for v in allck[0].tolist()]}
+    srt = sorted(rep_ms)
     res = {"value": round(world * args.batch * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3), "dp_check": dp_check,
+           "dp_diag": dp_diag, "repeat_ms_per_step": [round(r, 3) for r in rep_ms],
+           "repeat_median_ms": round(srt[len(srt) // 2], 3), "repeat_min_ms": round(srt[0], 3), "repeat_max_ms": round(srt[-1], 3),
            "host_enqueue_ms_per_step": round(t_enq / steps * 1e3, 3),
            "host_cpu_ms_per_step": round(t_cpu / steps * 1e3, 3),
            "host_work_ms_per_step_idle_queue": round(t_idle / 5 * 1e3, 3), "steps": steps,
@@ -208,7 +244,7 @@ def run_leg(args, dev, rank, world, *, comer=False, seg_trans=False, steps=None,
     return res, step, loader
 
 
-def roofline_leg(args, step, loader, dev):
+def roofline_leg(args, step, loader, dev, use_traffic=True):
     """Eager instrumented steps of the same TrainStep: HIP-event pairs at the C library's launch sites."""
     import torch
     from weclip_vit_comer_amd import ops
@@ -216,8 +252,8 @@ def roofline_leg(args, step, loader, dev):
     step.graph = False
     # one stream for these steps: an event pair around a launch must time THAT kernel, not its share of the GPU beside the
     # head forward that the timed (graph) steps run on a second stream
-    fork_was = (getattr(step.model, "fork_head", False), getattr(step.model, "fork_mean", False))
-    step.model.fork_head = step.model.fork_mean = False
+    fork_was = getattr(step.model, "fork_head", False)
+    step.model.fork_head = False
     for _ in range(2):
         img, labels = loader.next()
         step(img, labels=labels)
@@ -232,7 +268,7 @@ def roofline_leg(args, step, loader, dev):
     dt = time.perf_counter() - t0
     summ = ops.KernelTimer.summary()
     ops.KernelTimer.enable(0)
-    step.model.fork_head, step.model.fork_mean = fork_was
+    step.model.fork_head = fork_was
     stride = max(args.timer_stride, 1)
 
     # peaks from guides/MI355X_MICROARCH.md: dense fp16 MFMA 2.5 PFLOP/s, HBM3E 8 TB/s
@@ -240,15 +276,23 @@ def roofline_leg(args, step, loader, dev):
 
     def peak_of(name):
         return ("hbm", 8000.0, "GB/s") if name.startswith(HBM) else ("mfma", 2500.0, "TFLOP/s")
-    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
-    # (tools/refresh_profiles.sh + tools/pmc_traffic.py -> profiles/r03_traffic.json; 2*FETCH_SIZE + WRITE_SIZE, KiB,
-    # per the MI355X guide); keyed by the same kernel names.  null when no pass exists for this configuration.
-    traffic, tsrc = {}, None
-    for fn in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
-        tpath = os.path.join(ROOT, "profiles", fn)
-        if os.path.exists(tpath) and B == 16 and S == 512 and K == 2:
-            traffic = {k: round(v["hbm_bytes_per_launch"]) for k, v in json.load(open(tpath)).items()}
-            tsrc = "profiles/" + fn + " (committed rocprofv3 --pmc passes of this command, not this run)"
+    # HBM traffic per launch from committed rocprofv3 PMC passes of this same command (tools/refresh_profiles.sh +
+    # tools/pmc_traffic.py -> profiles/rNN_traffic.json; 2*FETCH_SIZE + WRITE_SIZE, KiB, per the MI355X guide), keyed by the
+    # same kernel names -- accepted ONLY when the kernel sources the passes were taken from are the sources of this build
+    # (content hash recorded in the file); otherwise null, with the reason in `traffic_source`.
+    import glob
+    import __graft_entry__
+    cur = __graft_entry__._load_build_module().source_hash()
+    traffic, tsrc = {}, "none: no profiles/r*_traffic.json carries the source hash of this build (%s)" % cur
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        if not (B == 16 and S == 512 and K == 2) or not use_traffic:
+            tsrc = "none: PMC passes exist for B=16, 512x512, K=2 without the inserts only"
+            break
+        data = json.load(open(tpath))
+        if data.get("__meta__", {}).get("source_hash") == cur:
+            traffic = {k: round(v["hbm_bytes_per_launch"]) for k, v in data.items() if k != "__meta__"}
+            tsrc = ("profiles/" + os.path.basename(tpath) + " (committed rocprofv3 --pmc passes of this command on the same "
+                    "kernel sources, hash %s; a separate run, as the guide prescribes)" % cur)
             break
     # north-star group "ViT attention": in-projection + attention forward + head-mean maps + out-projection of the 12 ViT
     # blocks (tagged at their call sites, clip/vit_engine.py) -- flops over time of the group as a whole
@@ -263,7 +307,7 @@ def roofline_leg(args, step, loader, dev):
     merged = {}
     for name, r in summ.items():          # fold the tagged records back into their kernels for the per-kernel rows
         base = name.split("@")[0]
-        m = merged.setdefault(base, {"ms": 0.0, "launches": 0, "work": 0.0, "est_ms": 0.0})
+        m = merged.setdefault(base, {"ms": 0.0, "launches": 0, "work": 0.0, "est_ms": 0.0, "bytes": 0.0})
         for k in m:
             m[k] += r[k]
     summ = merged
@@ -273,8 +317,15 @@ def roofline_leg(args, step, loader, dev):
         sec = r["ms"] * 1e-3
         if sec <= 0:
             continue
-        ach = r["work"] / sec / (1e12 if bound == "mfma" else 1e9)
-        roofs.append({"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+        extra = {}
+        if r["bytes"] > 0:      # kernels that report their algorithmic HBM bytes (row-streaming GEMM, deformable attention): HBM-bound
+            bound, peak, unit = "hbm", 8000.0, "GB/s"
+            ach = r["bytes"] / sec / 1e9
+            if r["work"] > 0:
+                extra = {"mfma_tflops": round(r["work"] / sec / 1e12, 1), "mfma_frac": round(r["work"] / sec / 2.5e15, 4)}
+        else:
+            ach = r["work"] / sec / (1e12 if bound == "mfma" else 1e9)
+        roofs.append({"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, **extra,
                       "frac": round(ach / peak, 4), "traffic": traffic.get(name), "launches_timed": r["launches"],
                       "sampling": f"1 of {stride} instrumented launches on average (fixed pseudo-random pick), {n} eager steps",
                       "avg_launch_us": round(r["ms"] * 1e3 / max(r["launches"], 1), 2),
@@ -349,7 +400,8 @@ def main():
     if args.precision:
         config.precision = args.precision
 
-    res, step, loader = run_leg(args, dev, rank, world, comer=args.comer, seg_trans=args.seg_trans, graph=not args.no_graph)
+    res, step, loader = run_leg(args, dev, rank, world, comer=args.comer, seg_trans=args.seg_trans, graph=not args.no_graph,
+                                repeats=args.repeats)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -374,6 +426,9 @@ def main():
         "host_work_ms_per_step_idle_queue": res["host_work_ms_per_step_idle_queue"],
         "launch_mode": res["launch_mode"],
         "dp_check": res["dp_check"],
+        "dp_diag": res["dp_diag"],
+        "repeat_ms_per_step": res["repeat_ms_per_step"],
+        "repeat_median_ms": res["repeat_median_ms"], "repeat_min_ms": res["repeat_min_ms"], "repeat_max_ms": res["repeat_max_ms"],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -418,8 +473,18 @@ def main():
                 config.par_q16 = True
             torch.cuda.empty_cache()
         if not args.comer:
-            r, _, _ = run_leg(args, dev, rank, world, comer=True, steps=few, warmup=2)
+            r, cstep, cloader = run_leg(args, dev, rank, world, comer=True, steps=few, warmup=2)
             r["note"] = "BASELINE configs[2] as written (+ ViT-CoMer inserts); parity unpinned: the reference ships no CoMer code"
+            if args.timer_stride > 0 and args.roof_steps > 0:
+                # the inserts' own kernels against their rooflines: the deformable-attention gathers and the
+                # row-streaming GEMM of the 86 016 x 256 x 256 Linear layers report ALGORITHMIC bytes (nL * nP * 4 corner rows of dh
+                # values per (query, head); A + side input + outputs once) -> achieved GB/s of the 8 TB/s HBM peak; the GEMM also
+                # its TFLOP/s.  Same HIP-event pairs at the library's launch sites as the main roofline.
+                croofs, cmeta = roofline_leg(args, cstep, cloader, dev, use_traffic=False)
+                keep = ("msda_", "gemm_row_kernel", "mrfp_", "ln_bwd", "gemm_km")
+                r["roofline"] = [x for x in croofs if x["kernel"].startswith(keep)]
+                r["eager_instrumented_ms_per_step"] = cmeta["eager_instrumented_ms_per_step"]
+            del cstep, cloader
             out["with_comer"] = r
             torch.cuda.empty_cache()
         out["encoder_only_b32"] = encoder_leg(args, dev)

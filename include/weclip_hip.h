@@ -158,32 +158,32 @@ int wc_gemm_f16_grouped(const void* A0, const void* A1, const void* A2, const vo
                         long ldaux, const void* auxh, const float* cscale, long sCS, int zdiv, long sA2, long sW2,
                         long sC2, long sB2, long sX2, void* stream);
 
+/* Row-streaming GEMM for tall, narrow products: C[M, N <= 256] = epilogue(A[M, K] W[N, K]^T), K = 128 | 256, fp16 operands,
+ * fp32 accumulate (csrc/gemm_row.hip).  Replaces the same F.linear / 1x1-conv call sites as wc_gemm_f16 where the output row is
+ * one complete channel vector: the Linear layers of the ViT-CoMer inserts (no reference code: ViT_CoMer.pdf section 3.2-3.3,
+ * SURVEY.md section 8 row a-9) and WeCLIP_model/segformer_head.py:22-28, Decoder/TransDecoder.py:98-125 at N = 256.  The launch
+ * is bound by HBM bytes, not flops: weights stay in registers, A and the side input stream through LDS once, every output row
+ * leaves as whole coalesced rows.  Epilogue, in this order:  v = (acc + bias[n]) * cscale[n];  P32 = v;  act (0 none, 2 ReLU,
+ * 6 GELU(erf); 5: v *= (auxh[m, n] > 0); 7: v *= GELU'(aux[m, n]));  v += resid[m, n];  C32 = v;  C16 = fp16(v);  and, for
+ * N == 256, up to two LayerNorms of the finished row (fp32 statistics, clip/model.py:177-183 arithmetic) written as fp16:
+ * ln_o{0,1}[m, :] = LN(v; ln_g, ln_b, eps) -- the operand of the next GEMM, without a LayerNorm launch.  At most ONE side input
+ * per launch (resid, or aux with act 7, or auxh with act 5).  Any subset of outputs; null pointers = absent.
+ * ldc = row pitch of C32 / P32, ldc16 = row pitch of C16 (it may be a column slice of a wider buffer).
+ * lda, ldw % 8 == 0; ldc, ldc16, ldr, ldaux % 4 == 0 (ldaux % 8 for act 5); fp32 buffers 16-byte, fp16 outputs 8-byte aligned.
+ * wc_gemm_row_supported: 1 when (M, N, K) is a shape this entry accepts. */
+int wc_gemm_row_supported(int M, int N, int K);
+int wc_gemm_row_f16(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias,
+                    const float* cscale, int act, const float* aux, const void* auxh, long ldaux, const float* resid, long ldr,
+                    float* C32, void* C16, float* P32, long ldc, long ldc16, const float* ln_g0, const float* ln_b0, void* ln_o0,
+                    const float* ln_g1, const float* ln_b1, void* ln_o1, float eps, void* stream);
+
 /* Which kernel wc_gemm_f16 runs for a shape (for profiling / roofline bookkeeping only):
  * 0 = 128x128x64 kernel, 1 = 256x256x64 ping-pong kernel, 2 = ping-pong kernel + 128x128 kernel on the ragged
- * last M % 256 rows (two launches), 3 / 4 = the same two with the 256x192x64 tile (N %% 192 == 0). */
+ * last M % 256 rows (two launches). */
 int wc_gemm_plan(int M, int N, int K, int nseg, int batch);
-/* Tile-width policy of the tall GEMMs: mode 0 = 256x256 only, 1 = by the bytes a launch stages into LDS (default: the
- * narrower tile only where the wider one would carry dead columns), 2 = 256x192 whenever the shape allows; cost > 0
- * replaces the relative cost of a byte staged by the 192-column kernel (default 1.0).
- * Process-wide; for benchmarks and tests (the environment variables WECLIP_GEMM_P192 / WECLIP_GEMM_P192_COST set the
- * initial values). */
-void wc_gemm_set_p192(int mode, float cost);
-/* MFMA shape of the 256x256 kernel: 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16 (same schedule, operand bytes and
- * accumulator registers; fp32 sums of 32 instead of 16 products per instruction, so results differ in the last fp32 bits).
- * Process-wide; initial value from WECLIP_GEMM_M16. */
-void wc_gemm_set_m16(int on);
 /* Per-shape timing of the GEMM entry points when WECLIP_GEMM_LOG=1 (an event pair around every call): writes
  * "entry M= N= K= seg= batch= plan= act=\tcalls\tms\tflop" lines into buf, clears the log, returns the number of lines. */
 int wc_gemm_log_report(char* buf, int cap);
-/* 256x256 tiles on the 4-wave kernel (128x128 wave tiles, operands through registers: global_load -> ds_write) instead of the
- * 8-wave LDS-DMA ping-pong kernel.  Process-wide; initial value from WECLIP_GEMM_W4. */
-void wc_gemm_set_w4(int on);
-/* 256x256 tiles on the 4-wave kernel that keeps a whole K-tile of fragments in registers (LDS-DMA into two images, prefetch
- * distance ~1.6 K-tiles): an experiment, off by default.  1 = DMA by global_load_lds, 2 = by buffer_load ... lds.  Process-wide. */
-void wc_gemm_set_r4(int on);
-/* Half-tile slots of the 256x256 kernel's LDS ring: 0 = 8 (128 KiB, three half-tiles in flight), 1 = 10 (160 KiB, five in
- * flight).  Bit-identical results.  Process-wide; initial value from WECLIP_GEMM_RING10. */
-void wc_gemm_set_ring10(int on);
 /* out[i] = alpha * sum_s part[s*n + i]: reduction of split-K partial products (the slices are a
  * batched wc_gemm_f16 over K ranges: sA = sW = K/slices, sC = M*N). */
 int wc_sum_slices(const float* part, float* out, int nslices, long n, float alpha, void* stream);
@@ -484,7 +484,10 @@ int wc_rows_add_f32(const float* src, float* dst, int B, int R, int C, long ld_s
  * coeff_ws: device scratch of *n_ints ints as reported by wc_augment_workspace_ints(B, crop, &n_ints) (the per-coordinate filter tables).
  * The rescale is Pillow's Image.BILINEAR for 8-bit images reproduced exactly (transforms.py:41: triangle filter of support
  * max(in/out, 1), double-precision coefficients rounded to 22-bit fixed point, uint8 rounding after the horizontal and after
- * the vertical pass); in/out <= 4 (the caller checks: rescale_range is [0.5, 2.0]). */
+ * the vertical pass).  PRECONDITION, checked on the device: in/out <= 4 on both axes (Hs <= 4 rh, Ws <= 4 rw; the reference's
+ * rescale_range is [0.5, 2.0]).  The filter tables hold 9 taps; an output coordinate that would need more makes every pixel
+ * it touches NaN instead of applying a truncated (non-Pillow) filter.  data.DeviceAugment also rejects it on the host when
+ * the params are host-resident. */
 int wc_augment_workspace_ints(int B, int crop, long* n_ints);       /* HOST out-parameter */
 int wc_augment_normalize(const void* src_u8, const void* params, float* dst, int* coeff_ws, int B, int Hs, int Ws, int crop,
                          const float* mean3, const float* std3, void* stream);

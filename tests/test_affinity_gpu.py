@@ -83,6 +83,24 @@ def test_box_mask_matches_oracle_on_structured_cams(P, thr):
         np.testing.assert_array_equal(V[0, :, p].cpu().numpy(), (ref * cams[p].reshape(h, w).numpy()).reshape(-1))
 
 
+def test_box_mask_kernel_matches_hand_derived_opencv_semantics(P):
+    """box_mask_kernel on the hand-derived vectors of tests/cv2_cases.py (documented OpenCV semantics, worked out by hand from
+    clip/utils.py:115-142): strict threshold at int(thr * max), 8-connectivity, holes, the dropped border row / column,
+    the empty map -> [[0,0,0,0]]."""
+    from tests.cv2_cases import cases
+    cs = cases()
+    for thr in sorted({c[2] for c in cs}):
+        sel = [c for c in cs if c[2] == thr]
+        h, w = sel[0][1].shape
+        cams = torch.stack([torch.from_numpy(c[1]).reshape(-1) for c in sel])
+        n = len(sel)
+        V, mask, boxes, nbox = P.box_masks(cams.cuda(), torch.zeros(n, dtype=I32).cuda(), torch.arange(n, dtype=I32).cuda(), 1, n, h, w,
+                                           thr, True, True)
+        for p, (name, cam, _, want) in enumerate(sel):
+            got = mask[p].cpu().numpy().reshape(h, w)
+            assert np.array_equal(got, want), (name, got, want)
+
+
 def test_upsample_with_bg_vs_oracle(P):
     B, h, w, K, H, W = 2, 4, 6, 3, 64, 96
     g = torch.Generator().manual_seed(9)

@@ -29,3 +29,10 @@ def test_bench_two_ranks_share_one_gpu_and_stay_in_step():
     assert d["scaling"] == "weak" and d["steps"] == 3 and d["value"] > 0
     assert d["dp_check"]["params_identical_across_ranks"] is True          # both ranks applied the same mean gradient
     assert d["launch_mode"] == "hipGraph replay"
+    # diagnostics of the first multi-GPU hardware run: the gradient exchange alone and the ranks' clocks
+    g = d["dp_diag"]
+    assert g["allreduce_ms_per_step"] > 0 and g["allreduce_bytes"] >= 4 * 5985045
+    assert 0 < g["rank_ms_per_step_min"] <= g["rank_ms_per_step_max"] <= d["ms_per_step"] + 1e-3
+    # the timed region is repeated inside the run (a region of 20 steps cannot resolve 2 %): first repeat = `value`
+    assert len(d["repeat_ms_per_step"]) == 5 and d["repeat_ms_per_step"][0] == d["ms_per_step"]
+    assert d["repeat_min_ms"] <= d["repeat_median_ms"] <= d["repeat_max_ms"]

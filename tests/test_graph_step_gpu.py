@@ -127,3 +127,39 @@ def test_bucketed_signatures_keep_real_label_distributions_to_a_few_graphs():
         assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(a.nan_to_num(), b.nan_to_num()), \
             (i, batches[i][1], (a - b).abs().max().item())
     assert torch.equal(pe, pg)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_forked_module_head_in_train_mode_equals_single_stream(graph):
+    """with the ViT-CoMer inserts (module-form head) a TRAINING forward forks the head to the side stream, so its
+    autograd nodes -- and the direct gradient writes into the all-reduce bucket -- run there and TrainStep joins the stream
+    after backward().  Train mode (Dropout2d on), fixed seed, eager and graph mode: losses and the whole gradient bucket must
+    equal the single-stream step bit for bit (a missing join / a racing bucket write would show here)."""
+    from weclip_vit_comer_amd.train_step import TrainStep
+
+    def run(fork):
+        torch.manual_seed(0)
+        m = _model(train=True, comer=True)
+        with torch.no_grad():
+            for t in m.comer.cti:
+                t.gamma.fill_(0.3)
+        m.fork_head = fork
+        step = TrainStep(m, graph=graph)
+        assert bool(m.comer.direct_grads)
+        losses, grads, forked = [], [], []
+        for seed, labels in BATCHES:
+            out = step(synth.make_images(2, H, W, seed=seed).cuda(), labels=labels)
+            losses.append([o.item() for o in out])
+            grads.append(step.bucket.flat.clone())
+            forked.append(bool(m.side_streams()))
+        if graph:
+            assert len(step._graphs) == 1 and next(iter(step._graphs.values()))["graph"] is not None
+        return losses, grads, forked
+
+    l1, g1, f1 = run(True)
+    l0, g0, f0 = run(False)
+    assert all(f1) and not any(f0)            # the fork really happened in one run and not in the other
+    assert l1 == l0, (l1, l0)
+    for a, b in zip(g1, g0):
+        assert torch.equal(a, b), (a - b).abs().max().item()
+    assert all(g.abs().max().item() > 0 for g in g1)

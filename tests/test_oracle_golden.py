@@ -262,3 +262,36 @@ def test_vitb_320_reference_default_crop(golden):
     np.testing.assert_allclose(aux[0]["refined"], g["refined"], rtol=2e-3, atol=1e-6)
     np.testing.assert_allclose(seg[0].numpy(), g["seg"], rtol=0, atol=2e-4)
     assert (labels[0].numpy() != g["cam_labels"]).mean() <= 5e-4
+
+
+def test_box_step_matches_hand_derived_opencv_semantics():
+    """The oracle's scoremap2bbox + fill against hand-derived vectors (tests/cv2_cases.py: every case cites the OpenCV
+    documentation it follows).  Keeps "unverified vs real cv2" (no OpenCV in the image) but pins the documented semantics."""
+    from tests.cv2_cases import cases
+    for name, cam, thr, want in cases():
+        got = O.box_mask(cam, thr)
+        assert np.array_equal(got, want), (name, got, want)
+
+
+def test_cv2_stand_in_of_the_fixture_generator_matches_hand_derived_vectors():
+    """The functional cv2 stand-in that the fixture generator installs under the imported reference (oracle/refharness.py)
+    run through the reference's own sequence of calls (clip/utils.py:115-142, clip_tool.py:179-183 restated on the stub's
+    functions): same hand-derived masks, so the committed fixtures were produced under the documented semantics too."""
+    from oracle import refharness
+    from tests.cv2_cases import cases
+    cv2 = refharness._cv2_stub()
+    for name, cam, thr, want in cases():
+        h, w = cam.shape
+        img = np.expand_dims((cam * 255).astype(np.uint8), 2)
+        _, binm = cv2.threshold(src=img, thresh=int(thr * np.max(img)), maxval=255, type=cv2.THRESH_BINARY)
+        contours = cv2.findContours(image=binm, mode=cv2.RETR_TREE, method=cv2.CHAIN_APPROX_SIMPLE)[0]
+        boxes = [[0, 0, 0, 0]]
+        if len(contours):
+            boxes = []
+            for c in contours:
+                x, y, bw, bh = cv2.boundingRect(c)
+                boxes.append([x, y, min(x + bw, w - 1), min(y + bh, h - 1)])
+        got = np.zeros((h, w), np.float32)
+        for x0, y0, x1, y1 in boxes:
+            got[y0:y1, x0:x1] = 1
+        assert np.array_equal(got, want), (name, got, want)

@@ -107,169 +107,28 @@ def test_gemm_tall_pingpong(ops):
     assert _rel(out.cpu().double(), a2.double() @ w2.double().t()) < 2e-6
 
 
-def _set_p192(mode, cost=0.0):
-    import ctypes
-    from weclip_vit_comer_amd import _lib as L
-    L.lib().cdll.wc_gemm_set_p192.argtypes = [ctypes.c_int, ctypes.c_float]
-    L.lib().cdll.wc_gemm_set_p192.restype = None
-    L.lib().cdll.wc_gemm_set_p192(int(mode), float(cost))
-
-
-@pytest.mark.parametrize("M,N,K,nseg", [(16400, 768, 768, 1), (16400, 2304, 768, 1), (16400, 768, 3072, 1), (8300, 1344, 256, 1),
-                                        (16400, 768, 768, 2), (16400, 768, 128, 3)])
-def test_gemm_tall_192_column_tile(ops, M, N, K, nseg):
-    """The 256x192 ping-pong kernel (round 3; N %% 192 == 0, even K-tile count >= 4) against the fp64 product AND, bit for
-    bit, against the 256x256 kernel on the same operands (every output element accumulates the same MFMA k-steps in the same
-    order): the wide fp16 epilogue (QKV: bias, q-scale columns; hi+lo outputs), the narrow fp32 + residual one (proj / fc2:
-    forced-fp16 rounding, fp32 + fp16 outputs), QuickGELU with the saved pre-activation, ReLU' aux, the ragged 16 rows."""
-    import ctypes
-    from weclip_vit_comer_amd import _lib as L
-    g = torch.Generator().manual_seed(M + N + K)
-    a = ops.Split(torch.randn(M, K, generator=g).half().cuda(), (torch.randn(M, K, generator=g) * 1e-3).half().cuda() if nseg > 1 else None)
-    w = ops.Split((torch.randn(N, K, generator=g) * 0.05).half().cuda(), (torch.randn(N, K, generator=g) * 5e-5).half().cuda() if nseg > 2 else None)
-    bias = torch.randn(N, generator=g).cuda()
-    res = torch.randn(M, N, generator=g).cuda()
-    saved = torch.randn(M, N, generator=g).half().cuda()
-    ref = a.hi.double() @ w.hi.double().t()
-    if nseg > 1:
-        ref += a.lo.double() @ w.hi.double().t()
-    if nseg > 2:
-        ref += a.hi.double() @ w.lo.double().t()
-    ref = (ref + bias.double()).cpu()
-
-    def run(mode):
-        _set_p192(mode)
-        plan = L.lib().cdll.wc_gemm_plan(M, N, K, nseg, 1)
-        o = {}
-        o["h"], o["l"] = torch.zeros(M, N, device="cuda", dtype=torch.float16), torch.zeros(M, N, device="cuda", dtype=torch.float16)
-        ops.gemm(a, w, M, N, K, bias=bias, out16=o["h"], out16lo=o["l"], scale=0.18, scale_cols=N // 3)
-        o["x1"] = torch.zeros(M, N, device="cuda")
-        ops.gemm(a, w, M, N, K, bias=bias, resid=res, out32=o["x1"], round16=True)
-        o["x2"], o["x2h"] = torch.zeros(M, N, device="cuda"), torch.zeros(M, N, device="cuda", dtype=torch.float16)
-        ops.gemm(a, w, M, N, K, bias=bias, resid=res, out32=o["x2"], out16=o["x2h"])
-        o["z"], o["u"] = torch.zeros(M, N, device="cuda", dtype=torch.float16), torch.zeros(M, N, device="cuda")
-        ops.gemm(a, w, M, N, K, bias=bias, out16=o["z"], act=1, pre32=o["u"])
-        o["r"] = torch.zeros(M, N, device="cuda", dtype=torch.float16)
-        ops.gemm(a, w, M, N, K, out16=o["r"], act=5, auxh=saved, ldaux=N)
-        torch.cuda.synchronize()
-        return plan, o
-
-    try:
-        p0, o0 = run(0)
-        p2, o2 = run(2)
-    finally:
-        _set_p192(1)
-    assert p0 in (1, 2) and p2 in (3, 4), (p0, p2)
-    mm = M // 256 * 256      # the ragged M % 256 rows may go to the few-rows kernel (4-way K split) in one mode only
-    for k in o0:
-        assert torch.equal(o0[k][:mm], o2[k][:mm]), (k, (o0[k].float() - o2[k].float()).abs().max().item())
-        assert (o0[k][mm:].float() - o2[k][mm:].float()).abs().max().item() <= 2e-3 * max(1.0, o0[k][mm:].float().abs().max().item())
-    sc = torch.ones(N, dtype=torch.float64)
-    sc[:N // 3] = 0.18
-    assert _rel((o2["h"].float() + o2["l"].float()).cpu().double(), ref * sc) < 2e-6
-    assert _rel(o2["x2"].cpu().double(), ref + res.cpu().double()) < 2e-6
-    assert _rel(o2["u"].cpu().double(), ref) < 2e-6
-    assert _rel(o2["z"].float().cpu().double(), ref * torch.sigmoid(1.702 * ref)) < 1e-3
-
-
-@pytest.mark.parametrize("variant", ["m16", "w4", "r4"])
-@pytest.mark.parametrize("M,N,K,nseg", [(16400, 768, 768, 1), (16640, 2304, 768, 1), (16400, 1024, 128, 1), (16400, 768, 128, 3)])
-def test_gemm_tall_kernel_variants(ops, variant, M, N, K, nseg):
-    """The two opt-in builds of the 256x256 tile (round 3): `m16` = the LDS-DMA kernel on v_mfma_f32_16x16x32_f16 (another
-    accumulator layout through every epilogue path), `w4` = four waves of 128x128, operands through registers; `r4` = four waves, LDS-DMA, a whole K-tile of fragments resident in
-    registers.  Each epilogue
-    path against the fp64 product and, to fp32 accumulation-order accuracy, against the default kernel: wide fp16 (hi + lo,
-    bias, column scale), narrow fp32 + residual (forced-fp16 rounding; fp32 + fp16), QuickGELU + saved pre-activation, ReLU' aux;
-    two K-tiles (K = 128), three segments, ragged and whole row counts."""
-    import ctypes
-    from weclip_vit_comer_amd import _lib as L
-    cd = L.lib().cdll
-    for f in (cd.wc_gemm_set_m16, cd.wc_gemm_set_w4, cd.wc_gemm_set_r4):
-        f.argtypes, f.restype = [ctypes.c_int], None
-    _set_p192(0)
-    g = torch.Generator().manual_seed(M + N + K + 1)
-    a = ops.Split(torch.randn(M, K, generator=g).half().cuda(), (torch.randn(M, K, generator=g) * 1e-3).half().cuda() if nseg > 1 else None)
-    w = ops.Split((torch.randn(N, K, generator=g) * 0.05).half().cuda(), (torch.randn(N, K, generator=g) * 5e-5).half().cuda() if nseg > 2 else None)
-    bias = torch.randn(N, generator=g).cuda()
-    res = torch.randn(M, N, generator=g).cuda()
-    saved = torch.randn(M, N, generator=g).half().cuda()
-    ref = a.hi.double() @ w.hi.double().t()
-    if nseg > 1:
-        ref += a.lo.double() @ w.hi.double().t()
-    if nseg > 2:
-        ref += a.hi.double() @ w.lo.double().t()
-    ref = (ref + bias.double()).cpu()
-
-    def run(on):
-        cd.wc_gemm_set_m16(1 if on and variant == "m16" else 0)
-        cd.wc_gemm_set_w4(1 if on and variant == "w4" else 0)
-        cd.wc_gemm_set_r4(1 if on and variant == "r4" else 0)
-        o = {}
-        o["h"], o["l"] = torch.zeros(M, N, device="cuda", dtype=torch.float16), torch.zeros(M, N, device="cuda", dtype=torch.float16)
-        ops.gemm(a, w, M, N, K, bias=bias, out16=o["h"], out16lo=o["l"], scale=0.18, scale_cols=N // 3)
-        o["x1"] = torch.zeros(M, N, device="cuda")
-        ops.gemm(a, w, M, N, K, bias=bias, resid=res, out32=o["x1"], round16=True)
-        o["x2"], o["x2h"] = torch.zeros(M, N, device="cuda"), torch.zeros(M, N, device="cuda", dtype=torch.float16)
-        ops.gemm(a, w, M, N, K, bias=bias, resid=res, out32=o["x2"], out16=o["x2h"])
-        o["z"], o["u"] = torch.zeros(M, N, device="cuda", dtype=torch.float16), torch.zeros(M, N, device="cuda")
-        ops.gemm(a, w, M, N, K, bias=bias, out16=o["z"], act=1, pre32=o["u"])
-        o["r"] = torch.zeros(M, N, device="cuda", dtype=torch.float16)
-        ops.gemm(a, w, M, N, K, out16=o["r"], act=5, auxh=saved, ldaux=N)
-        torch.cuda.synchronize()
-        return o
-
-    try:
-        assert cd.wc_gemm_plan(M, N, K, nseg, 1) in (1, 2)
-        o0 = run(False)
-        o1 = run(True)
-    finally:
-        cd.wc_gemm_set_m16(0)
-        cd.wc_gemm_set_w4(0)
-        cd.wc_gemm_set_r4(0)
-        _set_p192(1)
-    for k in o0:      # same products, another fp32 summation order: a few fp32 ulps of the sum, one fp16 ulp on the fp16 outputs
-        d = (o0[k].float() - o1[k].float()).abs().max().item()
-        assert d <= 2e-3 * max(1.0, o0[k].float().abs().max().item()), (k, d)
-    sc = torch.ones(N, dtype=torch.float64)
-    sc[:N // 3] = 0.18
-    assert _rel((o1["h"].float() + o1["l"].float()).cpu().double(), ref * sc) < 2e-6
-    assert _rel(o1["x2"].cpu().double(), ref + res.cpu().double()) < 2e-6
-    assert _rel(o1["u"].cpu().double(), ref) < 2e-6
-    assert _rel(o1["z"].float().cpu().double(), ref * torch.sigmoid(1.702 * ref)) < 1e-3
-    assert _rel(o1["r"].float().cpu().double(), (ref - bias.cpu().double()) * (saved.cpu().double() > 0)) < 1e-3
-
-
 @pytest.mark.parametrize("nt", list(range(2, 15)) + [17, 23])
 def test_gemm_tall_ring_every_tail_length(ops, nt):
     """The 256x256 kernel's K loop is unrolled over 5 K-tiles (10-slot LDS ring) with a guarded tail: every number of K-tiles
     from 2 to 14 (all tail lengths on both sides of the steady loop's entry condition) and two longer odd ones, against the
-    8-slot build bit for bit and against the fp64 product."""
-    import ctypes
+    fp64 product, and against the erf build of the same kernel (8-slot ring, 2-K-tile unroll: another tail code path) bit for
+    bit in front of the activation (`pre32`)."""
     from weclip_vit_comer_amd import _lib as L
-    cd = L.lib().cdll
-    cd.wc_gemm_set_ring10.argtypes, cd.wc_gemm_set_ring10.restype = [ctypes.c_int], None
     M, N, K = 20480 + 16, 512, 64 * nt
     g = torch.Generator().manual_seed(nt)
     a = torch.randn(M, K, generator=g).half().cuda()
     w = (torch.randn(N, K, generator=g) * 0.05).half().cuda()
     bias = torch.randn(N, generator=g).cuda()
-    _set_p192(0)
-    try:
-        assert cd.wc_gemm_plan(M, N, K, 1, 1) in (1, 2)
-        outs = []
-        for ring10 in (1, 0):
-            cd.wc_gemm_set_ring10(ring10)
-            o = torch.zeros(M, N, device="cuda")
-            ops.gemm(a, w, M, N, K, bias=bias, out32=o)
-            torch.cuda.synchronize()
-            outs.append(o)
-    finally:
-        cd.wc_gemm_set_ring10(1)
-        _set_p192(1)
+    assert L.lib().cdll.wc_gemm_plan(M, N, K, 1, 1) in (1, 2)
+    o = torch.zeros(M, N, device="cuda")
+    ops.gemm(a, w, M, N, K, bias=bias, out32=o)
+    pre, o6 = torch.zeros(M, N, device="cuda"), torch.zeros(M, N, device="cuda", dtype=torch.float16)
+    ops.gemm(a, w, M, N, K, bias=bias, pre32=pre, out16=o6, act=6)
+    torch.cuda.synchronize()
     mm = M // 256 * 256
-    assert torch.equal(outs[0][:mm], outs[1][:mm])
+    assert torch.equal(o[:mm], pre[:mm])
     ref = a.double() @ w.double().t() + bias.double()
-    assert _rel(outs[0].double(), ref) < 2e-6
+    assert _rel(o.double(), ref) < 2e-6
 
 
 def test_gemm_ragged_rows_split(ops):
@@ -407,3 +266,72 @@ def test_attention_vs_reference(ops, B, L, H, DH):
     assert (lse.cpu().double() - ref_lse).abs().max().item() < 1e-4
     # P is rounded to fp16 before PV and O to fp16 on output
     assert (o16.cpu().double() - o).abs().max().item() < 4e-3 * max(1.0, o.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K", [(40013, 256, 256), (86016, 256, 256), (4100, 256, 128), (16384, 128, 256), (9000, 96, 256),
+                                   (777, 256, 256), (16, 64, 128)])
+def test_gemm_row_kernel_every_epilogue(ops, M, N, K):
+    """csrc/gemm_row.hip (round 4: weights stationary in registers, 16-row tiles streamed through LDS, whole-row epilogue)
+    against the fp64 product and, where the tile kernels cover the same epilogue, against wc_gemm_f16 on the same operands:
+    plain fp32 / fp16 outputs, bias + column scale + fp32 residual, ReLU, ReLU' from the saved fp16 output, exact GELU with
+    the saved pre-activation, GELU' from it, and the fused LayerNorm outputs (bit-identical to layernorm_kernel on the fp32
+    output).  Persistent workgroups (more tiles than 2 x CUs), ragged row counts, N < 256 (idle waves / lanes), K = 128."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).half().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.06).half().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    cs = (torch.rand(N, generator=g) + 0.5).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    saved = torch.randn(M, N, generator=g).half().cuda()
+    u = torch.randn(M, N, generator=g).cuda()
+    ref = (a.double() @ w.double().t()).cpu()
+    refb = ref + bias.double().cpu()
+    z32 = lambda: torch.zeros(M, N, device="cuda")
+    z16 = lambda: torch.zeros(M, N, device="cuda", dtype=torch.float16)
+    # plain
+    o32, o16 = z32(), z16()
+    ops.gemm_row(a, w, M, N, K, out32=o32, out16=o16)
+    assert _rel(o32.cpu().double(), ref) < 2e-6
+    assert torch.equal(o16, o32.half())
+    # bias * column scale + residual
+    o = z32()
+    ops.gemm_row(a, w, M, N, K, bias=bias, cscale=cs, resid=res, out32=o)
+    assert _rel(o.cpu().double(), refb * cs.double().cpu() + res.double().cpu()) < 2e-6
+    t = z32()
+    ops.gemm(a, w, M, N, K, bias=bias, cscale=cs.view(1, N), sCS=0, resid=res, out32=t)
+    assert (o - t).abs().max().item() <= 2e-5 * max(1.0, t.abs().max().item())        # (another fp32 summation order)
+    # ReLU with fp16 output; ReLU' from a saved fp16 tensor
+    h = z16()
+    ops.gemm_row(a, w, M, N, K, bias=bias, act=2, out16=h)
+    assert _rel(h.float().cpu().double(), refb.clamp_min(0)) < 1e-3
+    if N % 8 == 0:
+        o = z32()
+        ops.gemm_row(a, w, M, N, K, act=5, auxh=saved, ldaux=N, out32=o)
+        assert _rel(o.cpu().double(), ref * (saved.double().cpu() > 0)) < 2e-6
+    # exact GELU with the saved pre-activation, and its derivative
+    pre, gl = z32(), z16()
+    ops.gemm_row(a, w, M, N, K, bias=bias, act=6, pre32=pre, out16=gl)
+    assert _rel(pre.cpu().double(), refb) < 2e-6
+    assert _rel(gl.float().cpu().double(), torch.nn.functional.gelu(refb)) < 1e-3
+    o = z32()
+    ops.gemm_row(a, w, M, N, K, act=7, aux=u, ldaux=N, out32=o)
+    ud = u.double().cpu()
+    dg = 0.5 * (1 + torch.erf(ud / 2 ** 0.5)) + ud * torch.exp(-0.5 * ud * ud) / (2 * torch.pi) ** 0.5
+    assert _rel(o.cpu().double(), ref * dg) < 2e-6
+    # fused LayerNorm outputs: bit-identical to the LayerNorm kernel run on the fp32 output
+    if N == 256:
+        g0, b0 = (torch.rand(N, generator=g) + 0.5).cuda(), torch.randn(N, generator=g).cuda()
+        g1, b1 = (torch.rand(N, generator=g) + 0.5).cuda(), torch.randn(N, generator=g).cuda()
+        o, l0, l1 = z32(), z16(), z16()
+        ops.gemm_row(a, w, M, N, K, bias=bias, resid=res, out32=o, ln=[(g0, b0, l0), (g1, b1, l1)], eps=1e-5)
+        assert _rel(o.cpu().double(), refb + res.double().cpu()) < 2e-6
+        for gam, bet, got in ((g0, b0, l0), (g1, b1, l1)):
+            want = ops.layernorm(o, gam, bet, eps=1e-5, want32=False, want16=True)[1].hi
+            assert torch.equal(got, want)
+        only = z16()
+        ops.gemm_row(a, w, M, N, K, bias=bias, resid=res, ln=[(g0, b0, only)])      # LayerNorm output alone
+        assert torch.equal(only, l0)
+    # determinism
+    o2 = z32()
+    ops.gemm_row(a, w, M, N, K, out32=o2)
+    assert torch.equal(o2, o32)

@@ -84,3 +84,36 @@ def test_device_input_pipeline_matches_oracle_at_bench_size():
     assert aug(imgs.cuda()).shape == out.shape      # fresh draw path
     with pytest.raises(RuntimeError):
         aug(imgs.cuda(), aug.pack([(0.2, 0, 75, 100, 0, 0, 0, 0)] * 4))      # beyond the 4x down-scaling the tables hold
+    # device-resident params skip the host check: the C ABI's own precondition check poisons the pixels (never a truncated filter)
+    bad = aug(imgs.cuda(), aug.pack([(0.2, 0, 75, 100, 0, 0, 0, 0)] * 4).cuda())
+    # (at the image border Pillow clips the filter's support, which may leave <= 9 taps: those pixels stay exact and finite)
+    assert torch.isnan(bad[:, :, 4:71, 4:96]).all() and not torch.isnan(bad[:, :, 75:, :]).any() and not torch.isnan(bad[:, :, :, 100:]).any()
+
+
+@pytest.mark.parametrize("case", ["dx_only", "dw_only", "both"])
+def test_trainable_linear_partial_gradients(case):
+    """weclip::linear through register_autograd with a frozen weight (dx only), a frozen input (dW / db only) and both:
+    the backward op hands back one placeholder PER unused slot (outputs of a custom op may not alias each other)."""
+    import weclip_vit_comer_amd as W
+    W.register_torch_ops()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(512, 128, generator=g)
+    wt = torch.randn(40, 128, generator=g) * 0.1
+    b = torch.randn(40, generator=g)
+    dy = torch.randn(512, 40, generator=g)
+    xc = x.cuda().requires_grad_(case != "dw_only")
+    wc = wt.cuda().requires_grad_(case != "dx_only")
+    bc = b.cuda().requires_grad_(case != "dx_only")
+    y = torch.ops.weclip.linear(xc, wc, bc, 2)
+    y.backward(dy.cuda())
+    # fp64 reference through the ReLU mask of the HIP forward (a pre-activation within fp16 rounding of 0 may land on either side)
+    xr = x.double().requires_grad_(case != "dw_only")
+    wr = wt.double().requires_grad_(case != "dx_only")
+    br = b.double().requires_grad_(case != "dx_only")
+    ((xr @ wr.t() + br) * (y.detach().cpu() > 0)).backward(dy.double())
+    for name, got, ref in (("dx", xc.grad, xr.grad), ("dw", wc.grad, wr.grad), ("db", bc.grad, br.grad)):
+        if ref is None:
+            assert got is None, name
+            continue
+        err = (got.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 3e-3, (case, name, err)

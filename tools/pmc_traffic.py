@@ -39,6 +39,12 @@ def main(fetch_dir, write_dir, out_prefix):
         fh.write("kernel,launches,FETCH_SIZE_KiB_avg,WRITE_SIZE_KiB_avg,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
         for r in rows:
             fh.write("%s,%d,%.2f,%.2f,%.0f\n" % r)
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("_b", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                     "weclip-vit-comer_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    summary["__meta__"] = {"source_hash": b.source_hash(), "note": "hash of csrc/*.hip, *.h + hipcc flags at collection time"}
     json.dump(summary, open(out_prefix + "_traffic.json", "w"), indent=1)
     print("wrote", out_prefix + "_pmc_traffic.csv", "and _traffic.json;", len(rows), "kernels")
 

@@ -2,7 +2,9 @@
 (`transformer.resblocks.{i}.{attn.in_proj_weight,attn.in_proj_bias,attn.out_proj,ln_1,ln_2,
 mlp.c_fc,mlp.c_proj}`, `linear_pred`).  3 pre-LN blocks (width 256, 8 heads) with the myAtt
 quirks -- fp32 in-projection/softmax, out-projection forced to fp16 (clip/myAtt.py:199-201,321) --
-then a 1x1 conv.  Trainable: runs as differentiable stock PyTorch-ROCm ops for now.
+then a 1x1 conv.  Trainable.  On the GPU the training step runs the three blocks, `linear_pred` and attn_pred forward and
+backward inside head_engine.HeadEngine (HIP flash attention forward / backward, MFMA GEMMs, fused LayerNorm backward); these
+modules own the parameters / state-dict keys, and their torch `forward` is the CPU path and the `WECLIP_HEAD=torch` A/B path.
 """
 import math
 from collections import OrderedDict

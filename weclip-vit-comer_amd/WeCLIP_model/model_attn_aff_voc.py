@@ -64,7 +64,6 @@ class WeCLIP(nn.Module):
         # `comer.*` in the state dict; absent (and the reference contract untouched) by default.
         self.comer = CoMerInteraction(embedding_dim) if comer else None
         self.fork_head = os.environ.get("WECLIP_FORK_HEAD", "1") != "0"      # head forward beside the CAM chain (second stream)
-        self.fork_mean = os.environ.get("WECLIP_FORK_MEAN", "0") != "0"      # head-mean maps beside the blocks' GEMMs: measured slower, off
         self.to(device)
 
     def get_param_groups(self):
@@ -101,21 +100,11 @@ class WeCLIP(nn.Module):
         rows, B, Lq = vis.embed(img)
         need = self._maps_needed(seg_trans) if want_maps else [False] * 11
         xs, maps = [], []
-        # The head-mean map of a block is read only by the affinity, after the encoder: with fork_mean its kernel goes to a second
-        # stream, to fill the CUs the block's next GEMMs leave idle (the 256x256 tiles of out-proj / fc2 / the next in-projection
-        # cover 0.75 / 0.75 / 2.25 rounds of the chip), joined after the last block.  Measured SLOWER (13.26-13.32 vs 13.07-13.20 ms
-        # per step): the GEMMs lose more to the shared L2 / fabric than the idle CUs give -- off by default.
-        mean_side = None
-        if self.fork_mean and img.is_cuda and any(need):
-            mean_side = (CT.side_stream(img.device), [])
         for i in range(vis.transformer.layers - 1):
             rows, m = VE.run_block(vis.transformer.resblocks[i].pack(), rows, B, Lq, want_mean=need[i], x16_out=x16,
-                                   tag=b"@vit_attn", mean_side=mean_side if need[i] else None)
+                                   tag=b"@vit_attn")
             xs.append(rows)
             maps.append(m)
-        if mean_side is not None:
-            torch.cuda.current_stream().wait_stream(mean_side[0])
-            mean_side[1].clear()
         return xs, maps, B, Lq
 
     def forward(self, img, img_names="2007_000032", mode="train", labels=None, plan=None):
@@ -129,6 +118,7 @@ class WeCLIP(nn.Module):
         seg_trans = self.iter_num > self.seg_trans_after or mode == "val"
         img = img.cuda().float().contiguous()
         hip_head = self.head_impl == "hip" and self.comer is None
+        self._bwd_forked = False              # set when this forward created autograd nodes on the side stream
         comer_tokens = self.comer is not None and self.head_impl == "hip" and self.comer.engine_ok(img)
         x16 = VE.X16Stack(self.encoder.visual.transformer.layers - 1) if (hip_head or comer_tokens) else None
         with torch.no_grad():
@@ -173,6 +163,7 @@ class WeCLIP(nn.Module):
                 main = torch.cuda.current_stream()
                 side = CT.side_stream(img.device)
                 side.wait_stream(main)
+                self._bwd_forked = True
                 with torch.cuda.stream(side):
                     seg, attn_pred = self._module_head(img, xs, x16, comer_tokens, B, Lq, h, w)
                 with torch.no_grad():
@@ -188,8 +179,18 @@ class WeCLIP(nn.Module):
         return seg, cam_labels, attn_pred
 
     def side_streams(self):
-        """Streams (besides the caller's) that forward / backward work of this model may run on."""
-        return CT.side_streams()      # (kept outside the module: a stream object must not end up in a pickled / deep-copied model)
+        """Streams (besides the caller's) that BACKWARD work of the last forward runs on: TrainStep joins them after
+        `loss.backward()`.  Only the module-form head forked under `torch.cuda.stream(side)` leaves autograd nodes there (the
+        fused HeadFunction keeps its node on the caller's stream); a forward that did not fork returns nothing, so a step being
+        captured into a HIP graph never waits on a stream outside its capture.  The stream objects live in clip_tool (a stream
+        must not end up in a pickled / deep-copied model).
+        Allocator note: tensors allocated on the side stream (seg, attn_pred, the inserts' saved activations) are used by the
+        caller's stream only after `main.wait_stream(side)`, and are freed on the host after `loss.backward()` has been enqueued;
+        the side stream's next use starts with `side.wait_stream(main)` in the next forward, i.e. behind every kernel that read
+        them, so the caching allocator cannot hand their blocks to a kernel that overtakes a reader."""
+        if not getattr(self, "_bwd_forked", False):
+            return []
+        return CT.side_streams()
 
     def _module_head(self, img, xs, x16, comer_tokens, B, Lq, h, w):
         """Adapters [+ ViT-CoMer inserts] -> decoder -> attn_pred through autograd nodes (every head form but the fused engine)."""

@@ -2,10 +2,12 @@
 (`linears_modulelist.{i}.proj{,_2}`, `linear_fuse`, Dropout2d(0.1)); 11 x MLP(768->256, ReLU,
 256->256) on the frozen feature maps, channel concat, 1x1 conv fuse.
 
-Trainable: forward and backward currently run as stock PyTorch-ROCm ops (autograd); the frozen
-encoder features arrive as image-major token rows straight from the HIP encoder, so the
-(11,B,768,h,w) stack/permute copies of the reference (model_attn_aff_voc.py:115-125) are skipped
-on the internal path (`forward_rows`).
+Trainable.  On the GPU the training step does not go through these modules' `forward`: head_engine.HeadEngine runs the
+eleven adapters + the fuse conv (and the decoder) forward AND backward as explicit HIP launches on the encoder's fp16 token
+rows (grouped MFMA GEMMs, split-K weight gradients written straight into the all-reduce bucket); the modules own the
+parameters and the state-dict keys.  The torch forms below are the CPU path and the `WECLIP_HEAD=torch` A/B path; the frozen
+encoder features arrive as image-major token rows, so the (11,B,768,h,w) stack/permute copies of the reference
+(model_attn_aff_voc.py:115-125) are skipped on the internal path (`forward_rows`).
 """
 import torch
 import torch.nn as nn

@@ -32,6 +32,18 @@ def _stamp(src):
     return h.hexdigest()
 
 
+def source_hash():
+    """Content hash of every kernel source + header + the compile flags: identifies the build a profile was taken from
+    (bench.py accepts a committed PMC traffic file only when its recorded hash equals this one)."""
+    h = hashlib.sha1()
+    h.update(" ".join(FLAGS).encode())
+    for f in sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode())
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _compile(src):
     obj = os.path.join(OBJ, src[:-4] + ".o")
     stamp_file = obj + ".stamp"

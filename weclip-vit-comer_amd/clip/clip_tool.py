@@ -166,29 +166,18 @@ def batch_refined_cams(clip_model, last_rows, maps11, seg_attn, plan, text_hat, 
             R = CP.refine(W, cams, plan.pair_img, plan.pair_slot, plan.K, h, w, thr, c1=c1)
             return R, cams, probs, st
         seg_attn = None
-    if _FORK_AFFINITY and last_rows.is_cuda:
-        # the affinity weight (HBM-bound sums over the head-mean maps + Sinkhorn sweeps) needs nothing of the GradCAM chain
-        # (MFMA-bound GEMMs through the last block): side by side on two streams, joined before the refinement
-        main = torch.cuda.current_stream()
-        side = side_stream(last_rows.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            W, c1 = CP.affinity_weight(maps, seg_attn, seg_trans, n_last, keep=keep, return_c1=True)
-        cams, probs, _ = st.grad_cam(text_hat, plan.text_idx, plan.n_text, plan.pair_img, plan.pair_cls, plan.Tmax)
-        main.wait_stream(side)
-    else:
-        cams, probs, _ = st.grad_cam(text_hat, plan.text_idx, plan.n_text, plan.pair_img, plan.pair_cls, plan.Tmax)
-        W, c1 = CP.affinity_weight(maps, seg_attn, seg_trans, n_last, keep=keep, return_c1=True)
+    # (the affinity weight beside the GradCAM GEMMs on a second stream was measured neutral to slower in round 3: one stream)
+    cams, probs, _ = st.grad_cam(text_hat, plan.text_idx, plan.n_text, plan.pair_img, plan.pair_cls, plan.Tmax)
+    W, c1 = CP.affinity_weight(maps, seg_attn, seg_trans, n_last, keep=keep, return_c1=True)
     R = CP.refine(W, cams, plan.pair_img, plan.pair_slot, plan.K, h, w, thr, c1=c1)
     return R, cams, probs, st
 
 
-_FORK_AFFINITY = os.environ.get("WECLIP_FORK_AFFINITY", "0") != "0"      # measured neutral to slightly slower (12.84-12.96 vs 12.75-12.84 ms): off
 _SIDE = {}
 
 
 def side_stream(dev):
-    """The package's second HIP stream on `dev` (head forward beside the CAM chain; the optional affinity / head-mean forks)."""
+    """The package's second HIP stream on `dev` (head forward beside the CAM chain)."""
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=dev)

@@ -58,7 +58,7 @@ class X16Stack(list):
         return Split(self.big[i], self.big_lo[i] if self.big_lo is not None else None)
 
 
-def run_block(pk, x, B, L, want_mean=True, keep=None, x16_out=None, tag=None, mean_side=None):
+def run_block(pk, x, B, L, want_mean=True, keep=None, x16_out=None, tag=None):
     """x (B*L, E) fp32 -> (x_out fp32, head-mean map (B,L,L) or None).
     `keep`, if a dict, receives intermediates needed by the analytic backward.
     `tag`: bench.py's roofline group of the attention half (in-projection, attention, head-mean, out-projection)."""
@@ -74,7 +74,7 @@ def run_block(pk, x, B, L, want_mean=True, keep=None, x16_out=None, tag=None, me
     if keep is not None:
         o16, lse, mean, o32 = ops.attention(qkv, B, L, H, DH, want_mean=want_mean, want_o32=True)
     else:
-        o16, lse, mean = ops.attention(qkv, B, L, H, DH, want_mean=want_mean, mean_side=mean_side)
+        o16, lse, mean = ops.attention(qkv, B, L, H, DH, want_mean=want_mean)
     x1 = torch.empty(M, E, device=dev, dtype=F32)
     ops.gemm(o16, pk.out_w, M, E, E, bias=pk.out_b, resid=x, out32=x1, round16=True)
     if tag:

@@ -46,6 +46,7 @@ class ComerEngine:
         self.wc = ops.WeightCache()
         self._ref = {}
         self.adapters = None        # the 4 WeCLIP adapter MLPs (segformer_head.MLP) when the engine also runs them (forward_tokens)
+        self.row_gemm = True        # Linear layers on the row-streaming GEMM kernel (False: the tile kernels + LayerNorm launches, for A/B)
 
     # ------------------------------------------------------------------------------------------ parameters
     def params(self):
@@ -140,6 +141,26 @@ class ComerEngine:
         lib.wc_msda_prep_bwd(L.ptr(gl), L.ptr(ga), L.ptr(attn), None, L.ptr(dow16), hs, nL, B, Lq, M, P, ld, L.stream())
         return gv, dow16
 
+    def _mm(self, a, w, M, N, K, *, ln=(), cscale=None, ldc16=None, **kw):
+        """GEMM dispatch: the row-streaming kernel (csrc/gemm_row.hip: weights stationary, whole-row epilogue, LayerNorm of the
+        output fused) where the shape allows, else the tile kernels + separate LayerNorm launches.  `ln`: [(LayerNorm module,
+        fp16 out (M, N))] of the finished fp32 row; `cscale`: (N,) column scale after the bias."""
+        a16 = a.hi if isinstance(a, Split) else a
+        w16 = w.hi if isinstance(w, Split) else w
+        if self.row_gemm and ops.gemm_row_ok(M, N, K) and (not ln or N == 256) and kw.get("lda", K) % 8 == 0:
+            kw.pop("rpg", None)
+            ops.gemm_row(a16, w16, M, N, K, cscale=cscale, ldc16=ldc16, eps=ln[0][0].eps if ln else 1e-5,
+                         ln=[(self._b(m.weight), self._b(m.bias), o) for m, o in ln], **kw)
+            return
+        if ldc16 is not None and kw.get("out16") is not None:
+            raise RuntimeError("ComerEngine._mm: a separate fp16 pitch needs the row kernel")
+        if cscale is not None:
+            kw.update(cscale=cscale.view(1, N), sCS=0)
+        ops.gemm(a16, w16, M, N, K, **kw)
+        for m, o in ln:
+            L.lib().wc_layernorm(L.ptr(kw["out32"], F32, "x"), N, L.ptr(self._b(m.weight), F32), L.ptr(self._b(m.bias), F32), m.eps, None,
+                                 L.ptr(o, F16, "ln.out"), None, M, N, L.stream())
+
     @staticmethod
     def _f16(x, alpha=1.0, cs=None):
         """fp32 rows -> fp16 operand (optionally x alpha, x a column scale)."""
@@ -177,6 +198,8 @@ class ComerEngine:
             m, t = net.mrfp[i], net.cti[i]
             hid = m.fc1.weight.shape[0]
             s = {}
+            e16 = lambda rows: torch.empty(rows, C, device=dev, dtype=F16)
+            q1 = e16(Mv)
             if x16 is not None:        # the WeCLIP adapter of this stage's ViT block, on the patch rows of the f16 tokens
                 ad = self.adapters[i]
                 Cin = x16[i].shape[1]
@@ -184,54 +207,55 @@ class ComerEngine:
                 ops.gemm(x16[i].view(-1)[Cin:], W(f"a{i}.p1"), nhw, C, Cin, bias=self._b(ad.proj.bias), out16=t1, act=2, batch=B,
                          sA=Lq * Cin, sW=0, sC=nhw * C)
                 v = torch.empty(Mv, C, device=dev, dtype=F32)
-                ops.gemm(t1, W(f"a{i}.p2"), Mv, C, C, bias=self._b(ad.proj_2.bias), out32=v)
+                self._mm(t1, W(f"a{i}.p2"), Mv, C, C, bias=self._b(ad.proj_2.bias), out32=v, ln=[(t.nv_q, q1)])      # q1 = LN(v)
                 s.update(t1=t1, x16=x16[i], Lq=Lq)
             else:
                 v = maps[i].detach().float().contiguous().view(Mv, C)
+                q1 = self._ln16(v, t.nv_q)
             # ---- MRFP: c1 = c + fc2(gelu(dwconv(fc1(c))))
             x1 = torch.empty(Mc, hid, device=dev, dtype=F32)
-            ops.gemm(c16, W(f"m{i}.fc1"), Mc, hid, C, bias=self._b(m.fc1.bias), out32=x1)
+            self._mm(c16, W(f"m{i}.fc1"), Mc, hid, C, bias=self._b(m.fc1.bias), out32=x1)
             x2 = torch.empty(Mc, hid, device=dev, dtype=F32)
             g16 = torch.empty(Mc, hid, device=dev, dtype=F16)
             lib.wc_mrfp_dwconv_fwd(L.ptr(x1), L.ptr(self._b(m.dw3.weight).view(-1), F32), L.ptr(self._b(m.dw3.bias), F32),
                                    L.ptr(self._b(m.dw5.weight).view(-1), F32), L.ptr(self._b(m.dw5.bias), F32), L.ptr(x2), L.ptr(g16),
                                    hs3, len(shapes), B, hid, L.stream())
             c1 = torch.empty(Mc, C, device=dev, dtype=F32)
-            ops.gemm(g16, W(f"m{i}.fc2"), Mc, C, hid, bias=self._b(m.fc2.bias), resid=c, out32=c1)
+            f1, q2 = e16(Mc), e16(Mc)         # LN(c1) with the parameters of nv_f (values of CTI-toV) and of nc_q (queries of CTI-toC)
+            self._mm(g16, W(f"m{i}.fc2"), Mc, C, hid, bias=self._b(m.fc2.bias), resid=c, out32=c1, ln=[(t.nv_f, f1), (t.nc_q, q2)])
             # ---- CTI-toV: v1 = v + gamma * out_proj(msda(LN(v) -> offsets / weights, value_proj(LN(c1))))
-            q1 = self._ln16(v, t.nv_q)
-            f1 = self._ln16(c1, t.nv_f)
             val1 = torch.empty(Mc, C, device=dev, dtype=F16)          # fp16 values: half the gather traffic of the deformable attention
-            ops.gemm(f1, W(f"v{i}.vp"), Mc, C, C, bias=self._b(t.to_v.value_proj.bias), out16=val1)
+            self._mm(f1, W(f"v{i}.vp"), Mc, C, C, bias=self._b(t.to_v.value_proj.bias), out16=val1)
             n1 = W(f"v{i}.ow").hi.shape[0]
             ld1 = (n1 + 63) // 64 * 64
             ow1 = torch.empty(Mv, ld1, device=dev, dtype=F32)
-            ops.gemm(q1, W(f"v{i}.ow"), Mv, n1, C, out32=ow1, ldc=ld1)
+            self._mm(q1, W(f"v{i}.ow"), Mv, n1, C, out32=ow1, ldc=ld1)
             o1, loc1, at1 = self._msda_fwd(val1, shapes, ow1, ld1, t.to_v, ref_v, B, nhw)
             v1 = torch.empty(Mv, C, device=dev, dtype=F32)
-            ops.gemm(o1, W(f"v{i}.op"), Mv, C, C, bias=self._b(t.to_v.output_proj.bias), cscale=self._b(t.gamma).view(1, C), sCS=0,
-                     resid=v, out32=v1)
-            lib.wc_rows_copy_f16(L.ptr(v1, F32), 1, L.ptr(cat16.view(-1)[2 * i * C:]), 1, Mv, C, C, 0, 2 * nst * C, 0, L.stream())
+            f2 = e16(Mv)
+            row = self.row_gemm       # (the row kernel also drops v1's fp16 copy into its column slice of the fuse input)
+            self._mm(o1, W(f"v{i}.op"), Mv, C, C, bias=self._b(t.to_v.output_proj.bias), cscale=self._b(t.gamma), resid=v, out32=v1,
+                     out16=cat16.view(-1)[2 * i * C:] if row else None, ldc16=2 * nst * C if row else None, ln=[(t.nc_f, f2)])
+            if not row:
+                lib.wc_rows_copy_f16(L.ptr(v1, F32), 1, L.ptr(cat16.view(-1)[2 * i * C:]), 1, Mv, C, C, 0, 2 * nst * C, 0, L.stream())
             # ---- CTI-toC: c2 = c1 + out_proj(msda(LN(c1), value_proj(LN(v1))))
-            q2 = self._ln16(c1, t.nc_q)
-            f2 = self._ln16(v1, t.nc_f)
             val2 = torch.empty(Mv, C, device=dev, dtype=F16)
-            ops.gemm(f2, W(f"c{i}.vp"), Mv, C, C, bias=self._b(t.to_c.value_proj.bias), out16=val2)
+            self._mm(f2, W(f"c{i}.vp"), Mv, C, C, bias=self._b(t.to_c.value_proj.bias), out16=val2)
             n2 = W(f"c{i}.ow").hi.shape[0]
             ld2 = (n2 + 63) // 64 * 64
             ow2 = torch.empty(Mc, ld2, device=dev, dtype=F32)
-            ops.gemm(q2, W(f"c{i}.ow"), Mc, n2, C, out32=ow2, ldc=ld2)
+            self._mm(q2, W(f"c{i}.ow"), Mc, n2, C, out32=ow2, ldc=ld2)
             o2, loc2, at2 = self._msda_fwd(val2, [(h, w)], ow2, ld2, t.to_c, ref_c, B, S)
             c2 = torch.empty(Mc, C, device=dev, dtype=F32)
-            ops.gemm(o2, W(f"c{i}.op"), Mc, C, C, bias=self._b(t.to_c.output_proj.bias), resid=c1, out32=c2)
+            n3 = e16(Mc)
+            self._mm(o2, W(f"c{i}.op"), Mc, C, C, bias=self._b(t.to_c.output_proj.bias), resid=c1, out32=c2, ln=[(t.ffn_norm, n3)])
             # ---- FFN: c3 = c2 + ffn2(gelu(ffn0(LN(c2))))
-            n3 = self._ln16(c2, t.ffn_norm)
             u = torch.empty(Mc, C, device=dev, dtype=F32)
             g2 = torch.empty(Mc, C, device=dev, dtype=F16)
-            ops.gemm(n3, W(f"f{i}.0"), Mc, C, C, bias=self._b(t.ffn[0].bias), pre32=u, out16=g2, act=6)
+            self._mm(n3, W(f"f{i}.0"), Mc, C, C, bias=self._b(t.ffn[0].bias), pre32=u, out16=g2, act=6)
             c3 = torch.empty(Mc, C, device=dev, dtype=F32)
             c3_16 = torch.empty(Mc, C, device=dev, dtype=F16)
-            ops.gemm(g2, W(f"f{i}.2"), Mc, C, C, bias=self._b(t.ffn[2].bias), resid=c2, out32=c3, out16=c3_16)
+            self._mm(g2, W(f"f{i}.2"), Mc, C, C, bias=self._b(t.ffn[2].bias), resid=c2, out32=c3, out16=c3_16)
             lib.wc_rows_copy_f16(L.ptr(c3_16.view(-1)[n16 * C:], F16), 0, L.ptr(cat16.view(-1)[(2 * i + 1) * C:]), B, nhw, C, C, S * C,
                                  2 * nst * C, nhw * 2 * nst * C, L.stream())
             s.update(c16=c16, x1=x1, x2=x2, g16=g16, c1=c1, v=v, q1=q1, f1=f1, val1=val1, loc1=loc1, at1=at1, o1=o1, v1=v1, ld1=ld1,
@@ -248,10 +272,17 @@ class ComerEngine:
         """Where a parameter's gradient may be WRITTEN (not accumulated): its `.grad` when the owner opted in
         (`CoMerInteraction.direct_grads`, set by TrainStep: the flat all-reduce bucket is zeroed every step and every gradient
         is produced exactly once per backward), else None -> a fresh tensor handed back to autograd."""
-        if p is None or not getattr(self.net, "direct_grads", False):
+        rng = getattr(self.net, "direct_grads", False)
+        if p is None or not rng:
             return None
         g = p.grad
-        return g if (g is not None and g.is_contiguous() and g.dtype == F32 and g.data_ptr() % 16 == 0) else None
+        if g is None or not g.is_contiguous() or g.dtype != F32 or g.data_ptr() % 16:
+            return None
+        # only views of THE bucket that opted in are overwritten: any other .grad (gradient accumulation, a second TrainStep
+        # without a bucket, a harness calling backward twice) gets a fresh tensor that autograd accumulates as usual
+        if rng is not True and not (rng[0] <= g.data_ptr() < rng[1]):
+            return None
+        return g
 
     def _wgrad(self, dy16, x16, M, N, K, grads, pw, pb, lda=None, xmap=None):
         """pw.grad / pb.grad (unscaled) of y = x W^T + b from the fp16 operands dy16 (M, lda >= N) [x GS] and x16 (M, K)."""
@@ -323,7 +354,7 @@ class ComerEngine:
         pieces = []
         for j in range(2 * nst):
             d = torch.empty(Mv, C, device=dev, dtype=F32)
-            ops.gemm(dy16, fuseT[j * C:(j + 1) * C], Mv, C, C, out32=d)
+            self._mm(dy16, fuseT[j * C:(j + 1) * C], Mv, C, C, out32=d)
             pieces.append(d)
         dc3 = None
         for i in reversed(range(nst)):
@@ -336,35 +367,35 @@ class ComerEngine:
             # ---- FFN
             dc3_16 = self._f16(dc3)
             du16 = torch.empty(Mc, C, device=dev, dtype=F16)
-            ops.gemm(dc3_16, WT(f"f{i}.2"), Mc, C, C, out16=du16, act=7, aux=s["u"], ldaux=C, rpg=1)
+            self._mm(dc3_16, WT(f"f{i}.2"), Mc, C, C, out16=du16, act=7, aux=s["u"], ldaux=C, rpg=1)
             self._wgrad(dc3_16, s["g2"], Mc, C, C, grads, t.ffn[2].weight, t.ffn[2].bias)
             dn3 = torch.empty(Mc, C, device=dev, dtype=F32)
-            ops.gemm(du16, WT(f"f{i}.0"), Mc, C, C, out32=dn3)
+            self._mm(du16, WT(f"f{i}.0"), Mc, C, C, out32=dn3)
             self._wgrad(du16, s["n3"], Mc, C, C, grads, t.ffn[0].weight, t.ffn[0].bias)
             dc2, dc2_16 = self._ln_bwd(dn3, s["c2"], t.ffn_norm, dc3, grads, want16=True)
             # ---- CTI-toC
             do2 = torch.empty(Mc, C, device=dev, dtype=F16)
-            ops.gemm(dc2_16, WT(f"c{i}.op"), Mc, C, C, out16=do2)
+            self._mm(dc2_16, WT(f"c{i}.op"), Mc, C, C, out16=do2)
             self._wgrad(dc2_16, s["o2"], Mc, C, C, grads, t.to_c.output_proj.weight, t.to_c.output_proj.bias)
             dval2_16, dow2 = self._msda_bwd(s["val2"], [(h, w)], s["loc2"], s["at2"], do2, t.to_c, B, S, s["ld2"])
             dq2 = torch.empty(Mc, C, device=dev, dtype=F32)
-            ops.gemm(dow2, WT(f"c{i}.ow"), Mc, C, s["ld2"], out32=dq2)
+            self._mm(dow2, WT(f"c{i}.ow"), Mc, C, s["ld2"], out32=dq2)
             self._ow_grads(dow2, s["q2"], Mc, s["n2"], s["ld2"], t.to_c, grads)
             dc1 = self._ln_bwd(dq2, s["c1"], t.nc_q, dc2, grads)
             df2 = torch.empty(Mv, C, device=dev, dtype=F32)
-            ops.gemm(dval2_16, WT(f"c{i}.vp"), Mv, C, C, out32=df2)
+            self._mm(dval2_16, WT(f"c{i}.vp"), Mv, C, C, out32=df2)
             self._wgrad(dval2_16, s["f2"], Mv, C, C, grads, t.to_c.value_proj.weight, t.to_c.value_proj.bias)
             dv1, dv1_16 = self._ln_bwd(df2, s["v1"], t.nc_f, pieces[2 * i], grads, want16=True)
             # ---- CTI-toV: v1 = v + gamma * (o1 Wop^T + bop)
             gam = self._b(t.gamma)
             gdv1_16 = self._f16(dv1, cs=gam.view(1, C))
             do1 = torch.empty(Mv, C, device=dev, dtype=F16)
-            ops.gemm(gdv1_16, WT(f"v{i}.op"), Mv, C, C, out16=do1)
+            self._mm(gdv1_16, WT(f"v{i}.op"), Mv, C, C, out16=do1)
             G, gsum = self._wgrad(dv1_16, s["o1"], Mv, C, C, grads, None, None)          # G = dv1^T o1, gsum = dv1^T 1 (unscaled)
             self._gamma_jobs.append((t, G, gsum))
             dval1_16, dow1 = self._msda_bwd(s["val1"], shapes, s["loc1"], s["at1"], do1, t.to_v, B, nhw, s["ld1"])
             dq1 = torch.empty(Mv, C, device=dev, dtype=F32)
-            ops.gemm(dow1, WT(f"v{i}.ow"), Mv, C, s["ld1"], out32=dq1)
+            self._mm(dow1, WT(f"v{i}.ow"), Mv, C, s["ld1"], out32=dq1)
             self._ow_grads(dow1, s["q1"], Mv, s["n1"], s["ld1"], t.to_v, grads)
             dvs[i] = self._ln_bwd(dq1, s["v"], t.nv_q, dv1, grads)
             if "t1" in s:              # the adapter MLP behind v: v = t1 W2^T + b2, t1 = relu(x W1^T + b1); x is frozen
@@ -372,16 +403,16 @@ class ComerEngine:
                 dv16 = self._f16(dvs[i])
                 self._wgrad(dv16, s["t1"], Mv, C, C, grads, ad.proj_2.weight, ad.proj_2.bias)
                 dt1 = torch.empty(Mv, C, device=dev, dtype=F16)
-                ops.gemm(dv16, WT(f"a{i}.p2"), Mv, C, C, out16=dt1, act=5, auxh=s["t1"], ldaux=C)
+                self._mm(dv16, WT(f"a{i}.p2"), Mv, C, C, out16=dt1, act=5, auxh=s["t1"], ldaux=C)
                 self._wgrad(dt1, s["x16"], Mv, C, s["x16"].shape[1], grads, ad.proj.weight, ad.proj.bias, xmap=(nhw, s["Lq"], 1))
                 dvs[i] = None
             df1 = torch.empty(Mc, C, device=dev, dtype=F32)
-            ops.gemm(dval1_16, WT(f"v{i}.vp"), Mc, C, C, out32=df1)
+            self._mm(dval1_16, WT(f"v{i}.vp"), Mc, C, C, out32=df1)
             self._wgrad(dval1_16, s["f1"], Mc, C, C, grads, t.to_v.value_proj.weight, t.to_v.value_proj.bias)
             dc1, dc1_16 = self._ln_bwd(df1, s["c1"], t.nv_f, dc1, grads, want16=True)
             # ---- MRFP
             dx2 = torch.empty(Mc, hid, device=dev, dtype=F16)          # fp16 out: the epilogue's wide (row-major) path
-            ops.gemm(dc1_16, WT(f"m{i}.fc2"), Mc, hid, C, out16=dx2, act=7, aux=s["x2"], ldaux=hid, rpg=1)
+            self._mm(dc1_16, WT(f"m{i}.fc2"), Mc, hid, C, out16=dx2, act=7, aux=s["x2"], ldaux=hid, rpg=1)
             self._wgrad(dc1_16, s["g16"], Mc, C, hid, grads, m.fc2.weight, m.fc2.bias)
             dx1_16 = torch.empty(Mc, hid, device=dev, dtype=F16)
             half = hid // 2
@@ -399,7 +430,7 @@ class ComerEngine:
             grads[id(m.dw3.weight)], grads[id(m.dw3.bias)] = dw3.view(m.dw3.weight.shape), db3
             grads[id(m.dw5.weight)], grads[id(m.dw5.bias)] = dw5.view(m.dw5.weight.shape), db5
             dc = torch.empty(Mc, C, device=dev, dtype=F32)
-            ops.gemm(dx1_16, WT(f"m{i}.fc1"), Mc, C, hid, out32=dc, resid=dc1)
+            self._mm(dx1_16, WT(f"m{i}.fc1"), Mc, C, hid, out32=dc, resid=dc1)
             self._wgrad(dx1_16, s["c16"], Mc, hid, C, grads, m.fc1.weight, m.fc1.bias)
             dc3 = dc
         return dc3, dvs, grads

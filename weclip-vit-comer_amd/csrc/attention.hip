@@ -636,7 +636,7 @@ extern "C" int wc_attn_fwd(const void* qkv, void* out, float* out32, float* lse,
     WC_CHECK_ARG(E % 8 == 0 && B <= 65535 && H <= 65535 && (long)wc_cdiv(L, 128) * H * (B + 7) < (1L << 30),
                  "wc_attn_fwd: bad shape");
     const size_t lds = DH == 64 ? 2 * (64 * (64 * 2 + 16) + 64 * 128) : 2 * (64 * (32 * 2 + 16) + 64 * 64);
-    static const int nw_env = getenv("WECLIP_ATTN_NW") ? atoi(getenv("WECLIP_ATTN_NW")) : 0;
+    const int nw_env = 0;      // 0: by batch size (a process switch existed through round 3)
     // 8 waves (256 queries per workgroup) when that still fills the chip; the small decoder / tiny cases keep 4
     const int NWv = nw_env ? nw_env : ((DH == 64 && (long)wc_cdiv(L, 256) * H * B >= 512) ? 8 : 4);
     const int nthr = NWv * 64;

@@ -58,7 +58,11 @@ __global__ __launch_bounds__(256) void aug_coeff_kernel(const AugParams* __restr
     int xmax = (int)(center + support + 0.5);
     if (xmax > in_size) xmax = in_size;
     int n = xmax - xmin;
-    if (n > AUG_KMAX) n = AUG_KMAX;                                        // excluded on the host (scale >= 1/4)
+    if (n > AUG_KMAX) {                                                    // down-scaling beyond 4x: the table cannot hold Pillow's
+        e[0] = 0;                                                          // filter -> the pixel is POISONED (NaN), never a
+        e[1] = -1;                                                         // silently different filter (checked precondition)
+        return;
+    }
     double k[AUG_KMAX], ww = 0.0;
 #pragma unroll
     for (int x = 0; x < AUG_KMAX; ++x) {
@@ -92,7 +96,9 @@ __global__ __launch_bounds__(256) void augment_normalize_kernel(const unsigned c
     const int* ex = tab + (((long)b * 2 + 1) * crop + x) * AUG_ENT;
     const int ymin = ey[0], ny = ey[1], xmin = ex[0], nx = ex[1];
     float v0 = 0.f, v1 = 0.f, v2 = 0.f;                                    // canvas padding (mean_rgb = [0, 0, 0])
-    if (ny > 0 && nx > 0) {
+    if (ny < 0 || nx < 0) {                                                // precondition in/out <= 4 violated (aug_coeff_kernel)
+        v0 = v1 = v2 = __builtin_nanf("");
+    } else if (ny > 0 && nx > 0) {
         const unsigned char* S = src + ((long)b * Hs * Ws + (long)ymin * Ws + xmin) * 3;
         int a0 = 1 << (AUG_PREC - 1), a1 = a0, a2 = a0;
         for (int j = 0; j < ny; ++j) {

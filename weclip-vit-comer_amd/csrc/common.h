@@ -37,6 +37,7 @@ static inline int wc_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // optional HIP-event timing of a launch (core.hip; no-ops unless wc_prof_enable(1))
 int wc_prof_begin(void* stream);
 void wc_prof_end(int idx, const char* name, double work, void* stream);
+void wc_prof_end2(int idx, const char* name, double work, double bytes, void* stream);   // + algorithmic HBM bytes
 int wc_prof_begin_always(void* stream);            // records whenever profiling is on (brackets around many launches)
 void wc_prof_end_n(int idx, const char* name, double work, void* stream, int n);   // one event pair around n launches
 

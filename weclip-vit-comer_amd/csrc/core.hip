@@ -48,7 +48,7 @@ extern "C" int wc_device_arch(int dev, char* buf, int buflen) {
 // the dominant kernels bracket themselves with wc_prof_begin / wc_prof_end.  Off by default (one branch per launch).
 // An event pair around a launch costs ~6 us of GPU time (it fences the neighbouring kernels), so bench.py records a
 // regular 1-in-n sample of the instrumented launches rather than all ~290 per step (which costs 10 % throughput).
-struct ProfRec { const char* name; const char* tag; hipEvent_t e0, e1; double work; int n; int weight; };
+struct ProfRec { const char* name; const char* tag; hipEvent_t e0, e1; double work, bytes; int n; int weight; };
 static int g_prof_stride = 0;          // 0 = off; n = record one of every n instrumented launches
 static const char* g_prof_tag = "";    // group tag of the call site (e.g. "@vit_attn"), appended to the kernel name in the report
 static unsigned long g_prof_ctr = 0;
@@ -108,6 +108,7 @@ static int prof_begin_rec(void* stream, int weight) {
     r.e0 = prof_event();
     r.e1 = prof_event();
     r.work = 0.0;
+    r.bytes = 0.0;
     r.n = 1;
     hipEventRecord(r.e0, (hipStream_t)stream);
     g_prof.push_back(r);
@@ -121,6 +122,14 @@ void wc_prof_end(int idx, const char* name, double work, void* stream) {
     hipEventRecord(g_prof[idx].e1, (hipStream_t)stream);
 }
 
+// The same with a second figure: the ALGORITHMIC HBM bytes of the launch, for kernels that are reported against both
+// rooflines (the row-streaming GEMM: flops and bytes; the deformable-attention gathers: bytes only, work = 0).
+void wc_prof_end2(int idx, const char* name, double work, double bytes, void* stream) {
+    if (idx < 0) return;
+    g_prof[idx].bytes = bytes;
+    wc_prof_end(idx, name, work, stream);
+}
+
 // One event pair around n back-to-back launches of the same kernel (the PAR sweeps): `work` is the total of the n launches;
 // the report counts n launches, so the average per launch carries the ~1 us between dependent kernels but not the ~6 us an
 // event pair around every single launch adds by fencing it off from its neighbours.
@@ -131,11 +140,12 @@ void wc_prof_end_n(int idx, const char* name, double work, void* stream, int n) 
 }
 
 // Aggregated records after a device synchronisation: returns the number of distinct kernel names and writes
-// "name\tlaunches\tms\twork\tms scaled by the sampling weight of each record\n" lines into buf (truncated at cap).
+// "name\tlaunches\tms\twork\tms scaled by the sampling weight of each record\talgorithmic bytes\n" lines into buf (truncated at cap).
 extern "C" int wc_prof_report(char* buf, int cap) {
     hipDeviceSynchronize();
     std::map<std::string, std::pair<double, std::pair<double, long>>> agg;   // name -> (ms, (work, launches))
     std::map<std::string, double> est;                                       // name -> sum of ms * record weight
+    std::map<std::string, double> byt;                                       // name -> algorithmic bytes of the recorded launches
     for (auto& r : g_prof) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
@@ -144,12 +154,13 @@ extern "C" int wc_prof_report(char* buf, int cap) {
         a.second.first += r.work;
         a.second.second += r.n;
         est[std::string(r.name) + r.tag] += (double)ms * r.weight;
+        byt[std::string(r.name) + r.tag] += r.bytes;
     }
     int off = 0;
     if (cap > 0) buf[0] = 0;
     for (auto& kv : agg) {
-        const int n = snprintf(buf + off, off < cap ? cap - off : 0, "%s\t%ld\t%.6f\t%.6e\t%.6f\n", kv.first.c_str(),
-                               kv.second.second.second, kv.second.first, kv.second.second.first, est[kv.first]);
+        const int n = snprintf(buf + off, off < cap ? cap - off : 0, "%s\t%ld\t%.6f\t%.6e\t%.6f\t%.6e\n", kv.first.c_str(),
+                               kv.second.second.second, kv.second.first, kv.second.second.first, est[kv.first], byt[kv.first]);
         if (n < 0 || off + n >= cap) break;
         off += n;
     }

@@ -1,0 +1,386 @@
+// Shared by the GEMM kernels (gemm.hip, gemm_km.hip, gemm_row.hip): argument block, fragment types and the epilogue.
+#pragma once
+#include "common.h"
+
+// per-shape timing of the GEMM entry points (gemm.hip; WECLIP_GEMM_LOG=1)
+int shape_log_begin(void* stream);
+void shape_log_end(int idx, const char* kind, int M, int N, int K, int nseg, int batch, int plan, int act, void* stream);
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define LDS_ROW 144   // bytes per padded tile row (64 halfs = 128 B + 16 B pad)
+
+struct GemmArgs {
+    const __half* A[3];
+    const __half* W[3];
+    int nseg;
+    int M, N, K;
+    long lda, ldw;
+    long sA, sW, sC, sR;  // batch strides in elements (blockIdx.z); sR = residual's
+    const float* bias;    // [N] fp32 or null
+    const float* resid;   // [M,ldr] fp32 or null
+    long ldr;
+    float* C32;
+    __half* C16;
+    __half* C16lo;
+    long ldc;
+    int act;              // 0 none, 1 QuickGELU x*sigmoid(1.702x), 2 ReLU, 3 sigmoid, 6 GELU (erf); 4 / 5 / 7: see aux / auxh
+    int round16;          // round (acc+bias) through fp16 first (forced-fp16 out-proj, myAtt.py:321)
+    float scale;          // multiply columns n < scale_cols by scale (q / sqrt(dh), myAtt.py:54)
+    int scale_cols;
+    float* P32;           // optional fp32 copy of the pre-activation value (acc + bias)
+    const float* aux;     // act 4: v *= QuickGELU'(aux[arow*ldaux + n]), arow = rowmap[m / rpg]*rpg + m % rpg; act 7: v *= GELU'(aux[..])
+    const int* rowmap;
+    int row0;             // row index of this launch's first row in the caller's matrix (rowmap arithmetic after a row split)
+    int rpg;
+    long ldaux;
+    const __half* auxh;   // act 5: v *= (auxh[m*ldaux + n] > 0)  (ReLU backward from the saved fp16 output)
+    const float* cscale;  // optional per-batch column scale after bias: v *= cscale[z*sCS + n] (Dropout2d)
+    long sCS;
+    int gx, gy;           // tile grid (N tiles, M tiles); the launch is 1-D over gx * roundup8(gy)
+    int auxvec;           // act 5: auxh rows are 8-byte addressable per 4 columns
+    int vec;              // outputs / residual are 16-byte addressable per 4 columns: LDS-transposed wide epilogue
+    // two-level batch (grouped small GEMMs, e.g. 11 adapters x B images in one launch): z2 = z / zdiv, z1 = z % zdiv;
+    // A, W, C move by z1 * s? + z2 * s?2; bias by z2 * sB2 and the act-5 aux by z2 * sX2 (elements)
+    int zdiv;
+    long sA2, sW2, sC2, sB2, sX2;
+};
+
+// Epilogue shared by the kernel variants.  C/D layout of the 32x32 MFMA: col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Every run-time option (activation, fp16 rounding, which outputs
+// exist) is tested once per block of 8/16 accumulator values, never per value: the per-value scalar
+// branches of a naive epilogue cost more than its stores.  Side inputs (residual / aux) of a block are
+// fetched together so the loads overlap; out-of-range rows/cols read a clamped address and are not stored.
+// AUX (act 4/5) is a separate instantiation so the common epilogue carries no aux registers.
+#define WC_EPI_ACT(v_, n_)                                                                        \
+    if (act == 1) {                                                                               \
+        _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_)                                       \
+            (v_)[e_] = (v_)[e_] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * (v_)[e_]));                   \
+    } else if (act == 2) {                                                                        \
+        _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_) (v_)[e_] = fmaxf((v_)[e_], 0.f);      \
+    } else if (act == 3) {                                                                        \
+        _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_) (v_)[e_] = __builtin_amdgcn_rcpf(1.0f + __expf(-(v_)[e_])); \
+    } else if (ERF && act == 6) {      /* (erff costs registers: only in the builds that serve act 6 / 7) */ \
+        _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_)                                       \
+            (v_)[e_] = 0.5f * (v_)[e_] * (1.0f + erff((v_)[e_] * 0.70710678118654752f));          \
+    }
+
+// Per-column epilogue constants of a lane's two output columns (bias, scale): fetched BEFORE the K loop of a
+// tile so that their latency (and, with LDS-DMA in flight, the in-order wait behind it) is off the epilogue.
+__device__ __forceinline__ void gemm_colvals(const GemmArgs& g, int n0, int wc, int lane, long zb, float (&bv)[2],
+                                             float (&sc)[2], long bbase = 0) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int col = n0 + wc * 64 + ni * 32 + (lane & 31);
+        const int colc = col < g.N ? col : g.N - 1;
+        bv[ni] = g.bias ? g.bias[bbase + colc] : 0.f;
+        sc[ni] = (col < g.scale_cols) ? g.scale : 1.0f;
+        if (g.cscale) sc[ni] *= g.cscale[zb * g.sCS + colc];
+    }
+}
+
+// The same for the 16x16 MFMA layout (L16 below): a lane owns FOUR columns of the 64-wide block, 16 apart.
+__device__ __forceinline__ void gemm_colvals16(const GemmArgs& g, int n0, int wc, int lane, float (&bv)[4], float (&sc)[4]) {
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+        const int col = n0 + wc * 64 + ci * 16 + (lane & 15);
+        const int colc = col < g.N ? col : g.N - 1;
+        bv[ci] = g.bias ? g.bias[colc] : 0.f;
+        sc[ci] = (col < g.scale_cols) ? g.scale : 1.0f;
+        if (g.cscale) sc[ci] *= g.cscale[colc];
+    }
+}
+
+// NI = column tiles (of 32) of the wave's block: 2 (64 x 64) or 1 (64 x 32: the third column tile of the 256x192 kernel).
+// L16: the accumulators come from v_mfma_f32_16x16x32_f16.  A 32x32 block is then FOUR 16x16 tiles (tr, tc) packed into the
+// same 16 registers, r = (tr*2 + tc)*4 + i, holding row tr*16 + (lane>>4)*4 + i, column tc*16 + (lane&15); registers 8c'..8c'+7
+// still cover the rows [16c', 16c'+16) of the block, so the chunking of the wide path is unchanged, and a lane's per-column
+// constants are bv / sc[ni*2 + tc] (gemm_colvals16).
+template <int NI>
+__device__ __forceinline__ float epi_acc(const f32x16 (&acc)[2][NI], int mi, int ni, int r) { return acc[mi][ni][r]; }
+template <int NI>
+__device__ __forceinline__ float epi_acc(const f32x4 (&acc)[2][NI][4], int mi, int ni, int r) { return acc[mi][ni][r >> 2][r & 3]; }
+
+// EK = epilogue kind of the build: 0 plain (act 0..3), 1 side input (act 4 QuickGELU', act 5 ReLU'), 2 erf GELU (act 6),
+// 3 erf GELU' with side input (act 7).  The erf forms live in builds of their own: carried by every build they cost the
+// 128x128 kernel its second workgroup per CU (244 -> 260 registers: 65 -> 95 us on the decoder shapes, round 3).
+template <int EK, int NI = 2, bool L16 = false, class ACC>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, ACC& acc, int m0, int n0, int wr, int wc,
+                                              int lane, long zb, char* scratch, const float (&bv)[L16 ? 2 * NI : 2],
+                                              const float (&sc)[L16 ? 2 * NI : 2], long cb, long xb = 0) {
+    constexpr bool AUX = (EK & 1) != 0, ERF = EK >= 2;
+    const int act = g.act;
+    // layout of accumulator register r (0..15) of block (mi, ni): row inside the 32-row block, column inside the 64-wide block,
+    // index of the lane's per-column constants
+    // (row = lane part + compile-time part: kept apart so that row * ldc stays one lane-dependent base + scalar multiples of ldc)
+    const int rowl = L16 ? ((lane >> 4) << 2) : 4 * (lane >> 5);
+#define EPI_ROWC(r_) (L16 ? ((((r_) >> 3) << 4) + ((r_) & 3)) : (((r_) & 3) + 8 * (((r_) >> 2) & 3)))
+#define EPI_ROW(r_) (rowl + EPI_ROWC(r_))
+#define EPI_COL(ni_, r_) (L16 ? ((ni_) * 32 + ((((r_) >> 2) & 1) << 4) + (lane & 15)) : ((ni_) * 32 + (lane & 31)))
+#define EPI_CI(ni_, r_) (L16 ? ((ni_) * 2 + (((r_) >> 2) & 1)) : (ni_))
+    const bool has_res = g.resid != nullptr;
+    const bool r16 = g.round16 != 0;
+    if (g.vec && !g.P32 && g.C16 && !g.C32) {   // fp32 outputs are already 128-B coalesced per half-wave: measured slower there
+        // Wide epilogue: the MFMA C layout gives a lane one column and 16 scattered rows (64 narrow
+        // stores per lane, store-issue bound).  Each wave instead drops 16 finished rows at a time into
+        // its own 4 KiB of LDS scratch and re-reads them row-major, 4 columns per lane: residual / aux
+        // side inputs are one 16-B (8-B) load, outputs one 8-B store per 4 values.
+        float* tile0 = reinterpret_cast<float*>(scratch);     // two 4-KiB buffers per wave, alternated by chunk
+        const int c4 = (lane & 15) * 4;
+        const int gcol = n0 + wc * 64 + c4;
+        const bool full = gcol + 3 < g.N;
+        const bool has_lo = g.C16lo != nullptr;
+        const bool has_sc = g.scale_cols > 0 || g.cscale != nullptr;     // uniform: most launches carry no column scale
+        // act 4: the fp32 aux rows (row-mapped, 16 B per lane and row) of chunk c+1 are requested before chunk c is
+        // processed, so their HBM latency hides behind one chunk of epilogue work instead of stalling every chunk
+        float ua[2][4][4];
+        auto aux_load = [&](int c, float (&dst)[4][4]) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int grow = m0 + wr * 64 + c * 16 + it * 4 + (lane >> 4);
+                dst[it][0] = dst[it][1] = dst[it][2] = dst[it][3] = 0.f;
+                if (grow < g.M && gcol < g.N && (NI == 2 || c4 < 32)) {
+                    const long arow = g.rowmap ? (long)g.rowmap[(grow + g.row0) / g.rpg] * g.rpg + (grow + g.row0) % g.rpg : grow;
+                    const float* up = g.aux + arow * g.ldaux + gcol;
+                    if (full) {
+                        const float4 u4 = *reinterpret_cast<const float4*>(up);
+                        dst[it][0] = u4.x; dst[it][1] = u4.y; dst[it][2] = u4.z; dst[it][3] = u4.w;
+                    } else {
+                        for (int k = 0; k < 4 && gcol + k < g.N; ++k) dst[it][k] = up[k];
+                    }
+                }
+            }
+        };
+        if constexpr (AUX) {
+            if (ERF ? act == 7 : act == 4) aux_load(0, ua[0]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {            // rows [16c, 16c+16) of the wave's 64x64 sub-tile
+            const int mi = c >> 1, rq0 = (c & 1) * 8;
+            float* tile = tile0 + (c & 1) * 1024;
+            float v[NI * 8];
+            if constexpr (AUX) {
+                if ((ERF ? act == 7 : act == 4) && c + 1 < 4) aux_load(c + 1, ua[(c + 1) & 1]);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) v[ni * 8 + rr] = epi_acc<NI>(acc, mi, ni, rq0 + rr) + bv[EPI_CI(ni, rr)];
+            if (r16) {
+#pragma unroll
+                for (int e = 0; e < NI * 8; ++e) v[e] = __half2float(__float2half(v[e]));
+            }
+            if (has_sc) {
+#pragma unroll
+                for (int e = 0; e < NI * 8; ++e) v[e] *= sc[EPI_CI(e >> 3, e & 7)];
+            }
+            if constexpr (!AUX) { WC_EPI_ACT(v, NI * 8) }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr)
+                    tile[EPI_ROW(rr) * 64 + EPI_COL(ni, rr)] = v[ni * 8 + rr];      // (rr < 8: rows 0..15 of the chunk)
+            // same wave reads what it wrote: LDS ops of a wave complete in order, no barrier needed
+            float f[4][4];
+            bool ok[4];
+            long o[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rl = it * 4 + (lane >> 4);
+                const int grow = m0 + wr * 64 + c * 16 + rl;
+                const float4 t4 = *reinterpret_cast<const float4*>(tile + rl * 64 + c4);
+                f[it][0] = t4.x; f[it][1] = t4.y; f[it][2] = t4.z; f[it][3] = t4.w;
+                ok[it] = grow < g.M && gcol < g.N && (NI == 2 || c4 < 32);      // NI == 1: the lanes of columns 32..63 idle
+                o[it] = (long)(grow < g.M ? grow : g.M - 1) * g.ldc + (gcol < g.N ? gcol : 0);
+            }
+            if constexpr (AUX) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    if (!ok[it]) continue;
+                    const int grow = m0 + wr * 64 + c * 16 + it * 4 + (lane >> 4);
+                    if (!ERF && act == 4) {
+                        const float (&u)[4] = ua[c & 1][it];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u[k]));
+                            f[it][k] *= sg * (1.0f + 1.702f * u[k] * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
+                        }
+                    } else if (ERF && act == 7) {
+                        const float (&u)[4] = ua[c & 1][it];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)      // d/du [u * Phi(u)] = Phi(u) + u * phi(u)
+                            f[it][k] *= 0.5f * (1.0f + erff(u[k] * 0.70710678118654752f)) + u[k] * 0.3989422804014327f * __expf(-0.5f * u[k] * u[k]);
+                    } else if (!ERF) {
+                        const __half* hp = g.auxh + xb + (long)grow * g.ldaux + gcol;
+                        if (full && g.auxvec) {          // one 8-byte load of the four saved activations
+                            typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
+                            const f16x4_ hv = *reinterpret_cast<const f16x4_*>(hp);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) f[it][k] *= (float)hv[k] > 0.f ? 1.f : 0.f;
+                        } else {
+                            for (int k = 0; k < 4 && gcol + k < g.N; ++k) f[it][k] *= __half2float(hp[k]) > 0.f ? 1.f : 0.f;   // ReLU'
+                        }
+                    }
+                }
+            }
+            if (has_res) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    if (!ok[it]) continue;
+                    const int grow = m0 + wr * 64 + c * 16 + it * 4 + (lane >> 4);
+                    const float* rp = g.resid + zb * g.sR + (long)grow * g.ldr + gcol;
+                    if (full) { const float4 rr4 = *reinterpret_cast<const float4*>(rp); f[it][0] += rr4.x; f[it][1] += rr4.y; f[it][2] += rr4.z; f[it][3] += rr4.w; }
+                    else for (int k = 0; k < 4 && gcol + k < g.N; ++k) f[it][k] += rp[k];
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                __half h[4], l[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) h[k] = __float2half(f[it][k]);
+                if (has_lo) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) l[k] = __float2half(f[it][k] - __half2float(h[k]));
+                }
+                if (!ok[it]) continue;
+                if (full) {
+                    // non-temporal: the fp16 outputs (75 MB per QKV launch) are not read again by this kernel and would
+                    // push the operand rows out of the L2s (A/B on the step, interleaved: 13.45 -> 13.36 ms)
+                    __builtin_nontemporal_store(*reinterpret_cast<u32x2*>(h), reinterpret_cast<u32x2*>(g.C16 + cb + o[it]));
+                    if (has_lo) __builtin_nontemporal_store(*reinterpret_cast<u32x2*>(l), reinterpret_cast<u32x2*>(g.C16lo + cb + o[it]));
+                } else {
+                    for (int k = 0; k < 4 && gcol + k < g.N; ++k) {
+                        g.C16[cb + o[it] + k] = h[k];
+                        if (has_lo) g.C16lo[cb + o[it] + k] = l[k];
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // all 64 residual values of the wave's sub-tile are requested up front: one memory latency, not four
+    // (the output may alias the residual, so the compiler cannot hoist these loads over the stores itself)
+    float rva[AUX ? 1 : 2][AUX ? 1 : NI][16];
+    if (!AUX && has_res) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int rbase = m0 + wr * 64 + mi * 32 + rowl;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = n0 + wc * 64 + EPI_COL(ni, r);
+                    const int colc = col < g.N ? col : g.N - 1;
+                    int row = rbase + EPI_ROWC(r);
+                    if (row > g.M - 1) row = g.M - 1;
+                    rva[AUX ? 0 : mi][AUX ? 0 : ni][r] = g.resid[zb * g.sR + (long)row * g.ldr + colc];
+                }
+            }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            // a lane's columns of this block: one (32x32 layout) or two, 16 apart (L16)
+            int colv[2], colcv[2];
+            bool colokv[2];
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc) {
+                colv[tc] = n0 + wc * 64 + EPI_COL(ni, tc * 4);
+                colokv[tc] = colv[tc] < g.N;
+                colcv[tc] = colokv[tc] ? colv[tc] : g.N - 1;
+            }
+#define EPI_TC(r_) (L16 ? (((r_) >> 2) & 1) : 0)
+            const int rbase = m0 + wr * 64 + mi * 32 + rowl;
+            float uv[16], v[16], pre[16];
+            float (&rv)[16] = rva[AUX ? 0 : mi][AUX ? 0 : ni];
+            if constexpr (AUX) {      // the aux variants are register-bound: residual per block
+                if (has_res) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int row = rbase + EPI_ROWC(r);
+                        if (row > g.M - 1) row = g.M - 1;
+                        rv[r] = g.resid[zb * g.sR + (long)row * g.ldr + colcv[EPI_TC(r)]];
+                    }
+                }
+            }
+            if constexpr (AUX) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = rbase + EPI_ROWC(r);
+                    if (row > g.M - 1) row = g.M - 1;
+                    const int colc = colcv[EPI_TC(r)];
+                    if (!ERF && act == 4) {
+                        const long arow = g.rowmap ? (long)g.rowmap[(row + g.row0) / g.rpg] * g.rpg + (row + g.row0) % g.rpg : row;
+                        const float u = g.aux[arow * g.ldaux + colc];
+                        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u));
+                        uv[r] = sg * (1.0f + 1.702f * u * (1.0f - sg));   // d/du [u*sigmoid(1.702u)]
+                    } else if (ERF && act == 7) {
+                        const long arow = g.rowmap ? (long)g.rowmap[(row + g.row0) / g.rpg] * g.rpg + (row + g.row0) % g.rpg : row;
+                        const float u = g.aux[arow * g.ldaux + colc];
+                        uv[r] = 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
+                    } else if (!ERF) {
+                        uv[r] = __half2float(g.auxh[xb + (long)row * g.ldaux + colc]) > 0.f ? 1.f : 0.f;   // ReLU'
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = epi_acc<NI>(acc, mi, ni, r) + bv[EPI_CI(ni, r)];
+            if (r16) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = __half2float(__float2half(v[r]));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { v[r] *= sc[EPI_CI(ni, r)]; pre[r] = v[r]; }
+            if constexpr (AUX) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] *= uv[r];
+            } else {
+                WC_EPI_ACT(v, 16)
+            }
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += rv[r];
+            }
+            // element r lives at o0 + drow(r) * ldc + (its column - the lane's first column)
+            const long o0 = cb + (long)rbase * g.ldc + colv[0];
+#define EPI_OFF(r_) ((long)EPI_ROWC(r_) * g.ldc + (EPI_TC(r_) ? 16 : 0))
+#define EPI_OK(r_) (colokv[EPI_TC(r_)] && rbase + EPI_ROWC(r_) < g.M)
+            if (g.P32) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (EPI_OK(r)) g.P32[o0 + EPI_OFF(r)] = pre[r];
+            }
+            if (g.C32) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // (non-temporal here was measured on the step and is slightly slower: the fp32 outputs are the
+                    // residual stream, re-read at once by the LayerNorm that follows)
+                    if (EPI_OK(r)) g.C32[o0 + EPI_OFF(r)] = v[r];
+                }
+            }
+            if (g.C16) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (EPI_OK(r)) g.C16[o0 + EPI_OFF(r)] = __float2half(v[r]);
+                if (g.C16lo) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (EPI_OK(r)) g.C16lo[o0 + EPI_OFF(r)] = __float2half(v[r] - __half2float(__float2half(v[r])));
+                }
+            }
+        }
+#undef EPI_OFF
+#undef EPI_OK
+#undef EPI_TC
+#undef EPI_ROW
+#undef EPI_ROWC
+#undef EPI_COL
+#undef EPI_CI
+}
+

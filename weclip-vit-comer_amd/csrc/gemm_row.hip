@@ -1,0 +1,358 @@
+// Row-streaming GEMM for TALL, NARROW products:  C[M, N <= 256] = epilogue(A[M, K] W[N, K]^T),  K = 128 or 256.
+//
+// Call sites: the Linear / 1x1-conv layers of the ViT-CoMer inserts (86 016 pyramid rows x 256 channels per image batch; no
+// reference code: ViT_CoMer.pdf section 3.2-3.3) and every other F.linear of the hot path whose
+// output row is one complete channel vector (WeCLIP_model/segformer_head.py:22-28 proj_2, Decoder/TransDecoder.py).
+//
+// Why a kernel of its own.  At K = N = 256 such a product moves 0.5 KiB of operand and 1-2.5 KiB of output / residual per
+// row for 131 kflop: it is bound by HBM bytes (86 016 rows: 44 MB in, 88-220 MB out), not by the matrix pipe, and the
+// 256x256 tile kernel ran it at a third of the HBM rate (1.3 rounds of one workgroup per CU that load, multiply and store
+// one after the other; weights re-staged through LDS for every tile; 64-byte output segments).  Here
+//   * the WEIGHTS ARE STATIONARY IN REGISTERS: a wave owns 64 output columns and keeps their whole K extent as MFMA B
+//     fragments (128 registers at K = 256), loaded once per workgroup; workgroups are persistent (two per CU, each walks
+//     its 32-row tiles), so the only operand traffic is A, read exactly once;
+//   * A tiles (32 rows x K) arrive by LDS-DMA into a two-slot ring, the next tile's DMA issued before this tile's MFMAs;
+//     XOR-swizzled 16-byte chunks (chunk c of row r at c ^ (r & 15)) keep the ds_read_b128 fragment reads conflict-free;
+//   * the epilogue works on WHOLE ROWS: the accumulators are dropped into a [32][256] fp32 tile in LDS, then a wave takes a
+//     row at a time -- lane l owns columns 4l..4l+3 -- so that every side input (residual, saved pre-activation) is one
+//     1-KiB coalesced load and every output one 1-KiB (fp32) / 512-B (fp16) coalesced store;
+//   * and because a workgroup holds complete rows, the LayerNorm(s) that consume the output (up to two different affine
+//     parameter sets) are computed right there and leave as the fp16 operand of the next GEMM: no LayerNorm launch, no
+//     second read of the 88 MB activation.
+// Two workgroups of four waves per CU overlap each other's load / multiply / store phases.
+//
+// vmcnt discipline: LDS-DMA, loads and stores share one in-order counter.  Each iteration issues the next tile's DMA first
+// and contains ONE explicit `s_waitcnt vmcnt(0)` -- after the row phase's first side loads, before its first store -- which
+// therefore also covers that DMA; the barrier at the top of the next iteration then makes every wave's pieces visible.  No
+// counted waits (a spilled register or a skipped store cannot break the accounting).
+#include "gemm_common.h"
+#include <stdlib.h>
+
+struct RowArgs {
+    const __half* A;
+    const __half* W;
+    int M, N, K;
+    long lda, ldw;
+    const float* bias;      // [N] or null
+    const float* cscale;    // [N] or null: v *= cscale[n] after the bias (CTI gate gamma)
+    int act;                // 0 none, 2 ReLU, 6 GELU (erf); 5: v *= (auxh > 0); 7: v *= GELU'(aux)
+    const float* aux;       // act 7: saved pre-activation, fp32 (M, ldaux)
+    const __half* auxh;     // act 5: saved fp16 output (M, ldaux)
+    long ldaux;
+    const float* resid;     // [M, ldr] fp32 or null, added last
+    long ldr;
+    float* C32;             // any subset of the three outputs
+    __half* C16;
+    float* P32;             // value before the activation (after bias and column scale)
+    long ldc, ldc16;        // row pitch of C32 / P32, and of C16 (e.g. a column slice of a wider concat buffer)
+    const float* ln_g[2];   // fused LayerNorm outputs of the final value (N == 256 only): gamma, beta, fp16 out (M, N)
+    const float* ln_b[2];
+    __half* ln_o[2];
+    float eps;
+    int ntiles;
+};
+
+#define ROW_TM 16
+#define ROW_BAR()                                              \
+    {                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_s_barrier();                          \
+        asm volatile("" ::: "memory");                         \
+    }
+// LDS access inside the loop is inline asm throughout: hipcc cannot tell which LDS bytes an in-flight LDS-DMA writes and puts
+// `s_waitcnt vmcnt(0)` in front of any LDS read it can see, which would drain the ring; the waits below are placed by hand.
+typedef float rf32x4 __attribute__((ext_vector_type(4)));
+#define ROW_LD128(dst_, addr_) asm volatile("ds_read_b128 %0, %1" : "=v"(dst_) : "v"(addr_))
+#define ROW_LD64(dst_, addr_) asm volatile("ds_read_b64 %0, %1" : "=v"(dst_) : "v"(addr_))
+#define ROW_ST32(addr_, val_) asm volatile("ds_write_b32 %0, %1" ::"v"(addr_), "v"(val_) : "memory")
+
+// LDS: 3 A slots (16 rows x K fp16) | 2 side slots (16 x 256 fp32) | C tile (16 x 256 fp32) | 6 x 256 column constants
+// = 78 KiB at K = 256: two workgroups per CU.
+template <int KT, bool ERF>
+__global__ __launch_bounds__(256, 2) void gemm_row_kernel(RowArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int K = KT * 64;
+    constexpr int SLOT = ROW_TM * K * 2;      // bytes of one A tile
+    constexpr int CPR = K / 8;                // 16-byte chunks per A row
+    constexpr int KS = K / 32;                // MFMA k-steps (v_mfma_f32_16x16x32_f16)
+    constexpr int NDMA = ROW_TM * CPR / 256;  // A pieces per thread and tile (2 at K = 256, 1 at K = 128)
+    constexpr int SSLOT = ROW_TM * 256 * 4;   // bytes of one side-input slot
+    constexpr int SIDE0 = 3 * SLOT, CB0 = SIDE0 + 2 * SSLOT, CT0 = CB0 + ROW_TM * 256 * 4;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    const unsigned lbase = (unsigned)(size_t)(lds_ptr)smem;
+    float* Ct = reinterpret_cast<float*>(smem + CT0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q16 = lane >> 4;
+    const int G = gridDim.x;
+    const int nmy = (g.ntiles - (int)blockIdx.x + G - 1) / G;
+    const int act = g.act;
+    // the ONE side input of the launch (checked by the host): fp32 rows (the residual, or the saved pre-activation of act 7)
+    // or fp16 rows (the saved output of act 5); it arrives by LDS-DMA like A, as a dense [16][N] image, so that the row phase
+    // costs no registers and no load sits between its stores in the in-order vmcnt queue
+    const char* sptr = g.resid ? reinterpret_cast<const char*>(g.resid)
+                               : (ERF && act == 7) ? reinterpret_cast<const char*>(g.aux)
+                                                   : act == 5 ? reinterpret_cast<const char*>(g.auxh) : nullptr;
+    const int sel = act == 5 ? 2 : 4;                          // bytes per side element
+    const long sld = g.resid ? g.ldr : g.ldaux;                // side row pitch in elements
+    const int spr = g.N * sel / 16;                            // 16-byte pieces per side row (N % 8 == 0 for fp16 sides)
+    const int spieces = ROW_TM * spr;                          // <= 1024
+    const int nsd = sptr ? (spieces + 255) / 256 : 0;          // side DMA instructions per thread and tile (uniform)
+
+    // A pieces of this thread: chunk q = j * 256 + tid of the tile image = (row q / CPR, physical chunk q % CPR), which holds
+    // the row's logical chunk (q % CPR) ^ (row & 15)
+    int drow[NDMA], dcol[NDMA];
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) {
+        const int q = j * 256 + tid;
+        drow[j] = q / CPR;
+        dcol[j] = (((q % CPR) ^ (drow[j] & 15))) * 8;
+    }
+#define ROW_DMA_A(tile_, slot_)                                                                                   \
+    {                                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < NDMA; ++j) {                                                        \
+            long r_ = (long)(tile_) * ROW_TM + drow[j];                                                           \
+            if (r_ > g.M - 1) r_ = g.M - 1;                                                                       \
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(g.A + r_ * g.lda + dcol[j]),                               \
+                                             (lds_ptr)(smem + (slot_) * SLOT + (j * 256 + wave * 64) * 16), 16, 0, 0); \
+        }                                                                                                         \
+    }
+#define ROW_DMA_S(tile_, slot_)                                                                                   \
+    {                                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
+            if (j < nsd) {      /* (uniform) */                                                                   \
+                int q_ = j * 256 + tid;                                                                           \
+                if (q_ > spieces - 1) q_ = spieces - 1;      /* surplus lanes re-fetch the last piece */          \
+                const int sr_ = q_ / spr;                                                                         \
+                long r_ = (long)(tile_) * ROW_TM + sr_;                                                           \
+                if (r_ > g.M - 1) r_ = g.M - 1;                                                                   \
+                __builtin_amdgcn_global_load_lds((gbl_ptr)(sptr + (r_ * sld) * sel + (q_ - sr_ * spr) * 16),      \
+                                                 (lds_ptr)(smem + SIDE0 + (slot_) * SSLOT + (j * 256 + wave * 64) * 16), 16, 0, 0); \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+    if (nmy > 0) { ROW_DMA_A(blockIdx.x, 0); ROW_DMA_S(blockIdx.x, 0); }
+    if (nmy > 1) ROW_DMA_A(blockIdx.x + G, 1);
+
+    // stationary weights: B fragments (16 columns x 32 k: lane = column l15, k group q16) of this wave's 64 columns, whole K
+    const int cw = wave * 64;
+    const bool has_cols = cw < g.N;
+    f16x8 wf[4][KS];
+    if (has_cols) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            int n = cw + cb * 16 + l15;
+            if (n > g.N - 1) n = g.N - 1;
+            const __half* wp = g.W + (long)n * g.ldw + q16 * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) wf[cb][ks] = *reinterpret_cast<const f16x8*>(wp + ks * 32);
+        }
+    }
+    // column constants in LDS (bias, column scale, two LayerNorm gamma / beta sets): as registers they would not fit beside
+    // the 128 weight registers, as global loads inside the row phase their waits would drain the stores issued before them
+    {
+        const int n = tid < g.N ? tid : g.N - 1;
+        Ct[tid] = g.bias ? g.bias[n] : 0.f;
+        Ct[256 + tid] = g.cscale ? g.cscale[n] : 1.f;
+        Ct[512 + tid] = g.ln_o[0] ? g.ln_g[0][n] : 0.f;
+        Ct[768 + tid] = g.ln_o[0] ? g.ln_b[0][n] : 0.f;
+        Ct[1024 + tid] = g.ln_o[1] ? g.ln_g[1][n] : 0.f;
+        Ct[1280 + tid] = g.ln_o[1] ? g.ln_b[1][n] : 0.f;
+    }
+    const bool has_res = g.resid != nullptr;
+    const int c4 = lane * 4;                           // row phase: lane l owns columns 4l .. 4l+3
+    const bool cact = c4 < g.N;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const unsigned aoff = lbase + l15 * (K * 2);
+    const unsigned x4 = (unsigned)(q16 ^ l15);         // chunk (ks * 4 + q16) ^ l15 = (ks * 4) ^ x4: the two terms share no bit
+    const unsigned cwr = lbase + CB0 + ((4 * q16) * 256 + cw + l15) * 4;       // C-tile address of accumulator element 0, block 0
+    const unsigned crd = lbase + CB0 + (wave * 4 * 256 + c4) * 4;              // C-tile address of this wave's first row
+    const unsigned ctc = lbase + CT0 + c4 * 4;
+    int sa = 0;                                        // A slot of tile i (i % 3)
+    for (int i = 0; i < nmy; ++i) {
+        const int t = blockIdx.x + i * G;
+        const int ss = i & 1;
+        ROW_BAR();                                   // tile i (A and side) is in LDS for all waves; the C tile and the slots refilled below are free
+        const bool full = i + 2 < nmy;
+        if (full) ROW_DMA_A(t + 2 * G, sa == 0 ? 2 : sa - 1);
+        if (i + 1 < nmy) ROW_DMA_S(t + G, ss ^ 1);
+        if (has_cols) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const unsigned ab = aoff + sa * SLOT;
+            f16x8 fa[2];
+            ROW_LD128(fa[0], ab + (x4 << 4));
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) {
+                    ROW_LD128(fa[(ks + 1) & 1], ab + ((((ks + 1) * 4) ^ x4) << 4));
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fa[ks & 1]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[ks & 1]));
+                }
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ks & 1], wf[cb][ks], acc[cb], 0, 0, 0);
+            }
+            // accumulators -> C tile: element e of block cb = row 4 q16 + e, column cw + 16 cb + l15
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ROW_ST32(cwr + (e * 256 + cb * 16) * 4, acc[cb][e]);
+        }
+        ROW_BAR();
+        // ---- the iteration's one vmcnt wait, in front of the row phase's stores.  Steady state: leave the DMA batch issued at the
+        // top of THIS iteration (A of tile i + 2, side of tile i + 1: NDMA + nsd instructions per thread) in flight; everything
+        // older -- the batch of the previous iteration (this tile's side input, the next tile's A) and the previous row phase's
+        // stores -- has then completed.  The last two iterations drain.
+        if (full) {
+            switch (NDMA + nsd) {
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        rf32x4 bias4, cs4;
+        ROW_LD128(bias4, ctc);
+        ROW_LD128(cs4, ctc + 1024);
+        const unsigned srd = lbase + SIDE0 + ss * SSLOT + ((wave * 4 * g.N + (cact ? c4 : 0)) * sel);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rl = wave * 4 + j;
+            const long grow = (long)t * ROW_TM + rl;
+            if (grow >= g.M) continue;                                       // (wave-uniform: ragged last tile only)
+            rf32x4 c, sd = {0.f, 0.f, 0.f, 0.f};
+            u32x2 sh = {0u, 0u};
+            ROW_LD128(c, crd + j * 1024);
+            if (sel == 4 && sptr) ROW_LD128(sd, srd + j * g.N * 4);
+            if (sel == 2) ROW_LD64(sh, srd + j * g.N * 2);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c), "+v"(sd), "+v"(sh), "+v"(bias4), "+v"(cs4));
+            float v[4] = {(c[0] + bias4[0]) * cs4[0], (c[1] + bias4[1]) * cs4[1], (c[2] + bias4[2]) * cs4[2], (c[3] + bias4[3]) * cs4[3]};
+            if (g.P32 && cact) *reinterpret_cast<float4*>(g.P32 + grow * g.ldc + c4) = make_float4(v[0], v[1], v[2], v[3]);
+            if (act == 2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+            } else if (act == 5) {
+                const __half* hp = reinterpret_cast<const __half*>(&sh);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] *= __half2float(hp[k]) > 0.f ? 1.f : 0.f;
+            } else if (ERF && act == 6) {
+                // one erff live at a time (a rotating non-unrolled loop over the four values): four interleaved copies of its
+                // polynomial cost ~60 registers on top of the 128 weight registers
+#pragma unroll 1
+                for (int k = 0; k < 4; ++k) {
+                    const float r = 0.5f * v[0] * (1.0f + erff(v[0] * 0.70710678118654752f));
+                    v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = r;
+                }
+            } else if (ERF && act == 7) {
+                float u[4] = {sd[0], sd[1], sd[2], sd[3]};
+#pragma unroll 1
+                for (int k = 0; k < 4; ++k) {      // d/du [u * Phi(u)] = Phi(u) + u * phi(u)
+                    const float r = v[0] * (0.5f * (1.0f + erff(u[0] * 0.70710678118654752f)) + u[0] * 0.3989422804014327f * __expf(-0.5f * u[0] * u[0]));
+                    v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = r;
+                    u[0] = u[1]; u[1] = u[2]; u[2] = u[3];
+                }
+            }
+            if (has_res) { v[0] += sd[0]; v[1] += sd[1]; v[2] += sd[2]; v[3] += sd[3]; }
+            if (cact) {
+                if (g.C32) *reinterpret_cast<float4*>(g.C32 + grow * g.ldc + c4) = make_float4(v[0], v[1], v[2], v[3]);
+                if (g.C16) {
+                    __half h[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) h[k] = __float2half(v[k]);
+                    *reinterpret_cast<u32x2*>(g.C16 + grow * g.ldc16 + c4) = *reinterpret_cast<u32x2*>(h);
+                }
+            }
+            if (g.ln_o[0]) {      // N == 256: all 64 lanes hold 4 columns; same arithmetic as layernorm_kernel<1> (norm.hip)
+                const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) / 256.f;
+                const float a0 = v[0] - mean, a1 = v[1] - mean, a2 = v[2] - mean, a3 = v[3] - mean;
+                const float rstd = rsqrtf(wave_sum((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) / 256.f + g.eps);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (!g.ln_o[s]) continue;
+                    rf32x4 ww, bb;
+                    ROW_LD128(ww, ctc + 2048 + s * 2048);
+                    ROW_LD128(bb, ctc + 3072 + s * 2048);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ww), "+v"(bb));
+                    __half h[4] = {__float2half(a0 * rstd * ww[0] + bb[0]), __float2half(a1 * rstd * ww[1] + bb[1]),
+                                   __float2half(a2 * rstd * ww[2] + bb[2]), __float2half(a3 * rstd * ww[3] + bb[3])};
+                    *reinterpret_cast<u32x2*>(g.ln_o[s] + grow * 256 + c4) = *reinterpret_cast<u32x2*>(h);
+                }
+            }
+        }
+        sa = sa == 2 ? 0 : sa + 1;
+    }
+#undef ROW_DMA_A
+#undef ROW_DMA_S
+}
+
+static int g_row_cus = 0;
+
+// C ABI: see include/weclip_hip.h
+extern "C" int wc_gemm_row_supported(int M, int N, int K) {
+    return (M > 0 && N > 0 && N <= 256 && N % 4 == 0 && (K == 128 || K == 256)) ? 1 : 0;
+}
+
+extern "C" int wc_gemm_row_f16(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias,
+                               const float* cscale, int act, const float* aux, const void* auxh, long ldaux, const float* resid,
+                               long ldr, float* C32, void* C16, float* P32, long ldc, long ldc16, const float* ln_g0, const float* ln_b0,
+                               void* ln_o0, const float* ln_g1, const float* ln_b1, void* ln_o1, float eps, void* stream) {
+    WC_CHECK_ARG(A && W && wc_gemm_row_supported(M, N, K), "wc_gemm_row_f16: need N <= 256, N %% 4 == 0, K = 128 | 256 (got M=%d N=%d K=%d)", M, N, K);
+    WC_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K && ((uintptr_t)A | (uintptr_t)W) % 16 == 0,
+                 "wc_gemm_row_f16: operand rows must be 16-byte aligned");
+    WC_CHECK_ARG((C32 || C16 || P32 || ln_o0) && ldc >= N && ldc % 4 == 0 && (!C16 || (ldc16 >= N && ldc16 % 4 == 0)),
+                 "wc_gemm_row_f16: bad output / ldc, ldc16 %% 4 != 0");
+    WC_CHECK_ARG(((uintptr_t)C32 | (uintptr_t)P32 | (uintptr_t)resid | (uintptr_t)aux | (uintptr_t)bias | (uintptr_t)cscale) % 16 == 0 &&
+                 ((uintptr_t)C16 | (uintptr_t)auxh | (uintptr_t)ln_o0 | (uintptr_t)ln_o1) % 8 == 0, "wc_gemm_row_f16: misaligned buffer");
+    WC_CHECK_ARG(act == 0 || act == 2 || act == 5 || act == 6 || act == 7, "wc_gemm_row_f16: act must be 0, 2, 5, 6 or 7");
+    WC_CHECK_ARG(act != 5 || (auxh && ldaux >= N && ldaux % 8 == 0 && N % 8 == 0 && (uintptr_t)auxh % 16 == 0 && !resid), "wc_gemm_row_f16: act 5 needs auxh, ldaux %% 4 == 0, and takes no residual (one side input per launch)");
+    WC_CHECK_ARG(act != 7 || (aux && ldaux >= N && ldaux % 4 == 0 && !resid), "wc_gemm_row_f16: act 7 needs aux, ldaux %% 4 == 0, and takes no residual (one fp32 side input per launch)");
+    WC_CHECK_ARG(!resid || (ldr >= N && ldr % 4 == 0), "wc_gemm_row_f16: ldr %% 4 != 0");
+    WC_CHECK_ARG((!ln_o0 && !ln_o1) || (N == 256 && ln_o0 && ln_g0 && ln_b0 && (!ln_o1 || (ln_g1 && ln_b1))),
+                 "wc_gemm_row_f16: fused LayerNorm needs N == 256 and gamma / beta (slot 0 first)");
+    if (!g_row_cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&g_row_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_row_cus <= 0)
+            g_row_cus = 256;
+        WC_CHECK_ARG(hipFuncSetAttribute((const void*)gemm_row_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 79872) == hipSuccess &&
+                     hipFuncSetAttribute((const void*)gemm_row_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 79872) == hipSuccess,
+                     "wc_gemm_row_f16: cannot reserve 78 KiB of LDS");
+    }
+    RowArgs g;
+    g.A = (const __half*)A; g.W = (const __half*)W; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw;
+    g.bias = bias; g.cscale = cscale; g.act = act; g.aux = aux; g.auxh = (const __half*)auxh; g.ldaux = ldaux;
+    g.resid = resid; g.ldr = ldr; g.C32 = C32; g.C16 = (__half*)C16; g.P32 = P32; g.ldc = ldc; g.ldc16 = ldc16;
+    g.ln_g[0] = ln_g0; g.ln_b[0] = ln_b0; g.ln_o[0] = (__half*)ln_o0;
+    g.ln_g[1] = ln_g1; g.ln_b[1] = ln_b1; g.ln_o[1] = (__half*)ln_o1;
+    g.eps = eps;
+    g.ntiles = wc_cdiv(M, ROW_TM);
+    const int grid = g.ntiles < 2 * g_row_cus ? g.ntiles : 2 * g_row_cus;
+    const bool erf = act == 6 || act == 7;
+    const size_t lds = 3 * (size_t)ROW_TM * K * 2 + 3 * ROW_TM * 256 * 4 + 6 * 256 * 4;
+    const int pr = wc_prof_begin(stream);
+    const int sl = shape_log_begin(stream);
+    if (K == 256) {
+        if (erf) hipLaunchKernelGGL((gemm_row_kernel<4, true>), dim3(grid), dim3(256), lds, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((gemm_row_kernel<4, false>), dim3(grid), dim3(256), lds, (hipStream_t)stream, g);
+    } else {
+        if (erf) hipLaunchKernelGGL((gemm_row_kernel<2, true>), dim3(grid), dim3(256), lds, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((gemm_row_kernel<2, false>), dim3(grid), dim3(256), lds, (hipStream_t)stream, g);
+    }
+    shape_log_end(sl, "row", M, N, K, 1, 1, 9, act, stream);
+    // algorithmic bytes: A once, the side input once, every output once
+    const double nb = (double)M * K * 2 + (double)M * N * ((resid || act == 7 ? 4 : 0) + (act == 5 ? 2 : 0) + (C32 ? 4 : 0) + (P32 ? 4 : 0) +
+                                                           (C16 ? 2 : 0) + (ln_o0 ? 2 : 0) + (ln_o1 ? 2 : 0));
+    wc_prof_end2(pr, K == 256 ? (erf ? "gemm_row_kernel<4, true>" : "gemm_row_kernel<4, false>")
+                              : (erf ? "gemm_row_kernel<2, true>" : "gemm_row_kernel<2, false>"), 2.0 * M * N * K, nb, stream);
+    WC_LAUNCH_CHECK("gemm_row_kernel");
+    return WC_OK;
+}

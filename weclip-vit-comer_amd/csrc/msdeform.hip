@@ -618,8 +618,14 @@ static int msda_bwd_value(const float* loc, const float* attn, const GT* gout, f
     hipLaunchKernelGGL(msda_bucket_kernel, dim3(n_levels, M, N), dim3(MSDA_VT), (size_t)maxhw * 2 * sizeof(int), st, loc, (int*)ws, sh,
                        S, Lq, M, P, N);
     WC_LAUNCH_CHECK("msda_bucket_kernel");
+    const int prg = wc_prof_begin(st);
     hipLaunchKernelGGL(msda_gather_kernel<GT>, dim3(wc_cdiv(S, 256 / D), M, N), dim3(256), 0, st, loc, attn, gout,
                        (const unsigned int*)gmax, (const int*)ws, gvalue, (__half*)gvalue16, sh, S, Lq, M, D, P, N);
+    // one dh-row of the output gradient per (sample, corner) pair (all corners inside: the upper bound) + the pair id, its
+    // location / weight (12 B) + the value-gradient rows written
+    wc_prof_end2(prg, "msda_gather_kernel", 0.0,
+                 (double)N * Lq * M * n_levels * P * 4 * ((double)D * sizeof(GT) + 16) +
+                     (double)N * S * M * D * ((gvalue ? 4 : 0) + (gvalue16 ? 2 : 0)), st);
     WC_LAUNCH_CHECK("msda_gather_kernel");
     return WC_OK;
 }
@@ -679,12 +685,18 @@ extern "C" int wc_msda_fwd_f(const void* value, int value_is_f16, const int* h_s
     const long NQ = (long)N * Lq;
     const dim3 gd((unsigned)wc_cdiv(NQ, 256 / (M * D / 4)));
     hipStream_t st = (hipStream_t)stream;
+    const int prf = wc_prof_begin(stream);
 #define MSDA_F(VT, NL_)                                                                                                    \
     hipLaunchKernelGGL((msda_fwd4f_kernel<VT, NL_, 4>), gd, dim3(256), 0, st, (const VT*)value, ow, bias_off, bias_aw, ref, loc, attn, \
                        out, (__half*)out16, sh, S, NQ, Lq, M, D, ld, nl_ref)
     if (value_is_f16) { if (n_levels == 3) MSDA_F(__half, 3); else MSDA_F(__half, 1); }
     else { if (n_levels == 3) MSDA_F(float, 3); else MSDA_F(float, 1); }
 #undef MSDA_F
+    // algorithmic bytes (SURVEY.md section 8 row a-9 / VERDICT r03: nL * nP * 4 corner reads of dh values per (query, head)):
+    // the corner rows + the offset / weight logits read + the fp16 / fp32 output row written
+    wc_prof_end2(prf, n_levels == 3 ? "msda_fwd4f_kernel<3>" : "msda_fwd4f_kernel<1>", 0.0,
+                 (double)NQ * M * ((double)n_levels * P * 4 * D * (value_is_f16 ? 2 : 4) + D * ((out16 ? 2 : 0) + (out ? 4 : 0))) +
+                     (double)NQ * 3 * M * n_levels * P * 4, stream);
     WC_LAUNCH_CHECK("msda_fwd4f_kernel");
     return WC_OK;
 }
@@ -702,6 +714,7 @@ extern "C" int wc_msda_bwd_f(const void* value, int value_is_f16, const int* h_s
     const long NQ = (long)N * Lq;
     const dim3 gd((unsigned)wc_cdiv(NQ, 256 / (M * D / 4)));
     hipStream_t st = (hipStream_t)stream;
+    const int prb = wc_prof_begin(stream);
 #define MSDA_B(VT, GT, NL_)                                                                                                \
     hipLaunchKernelGGL((msda_bwd4f_kernel<VT, GT, NL_, 4>), gd, dim3(256), 0, st, (const VT*)value, loc, attn, (const GT*)gout, \
                        (__half*)dow16, sh, S, NQ, Lq, M, D, ld)
@@ -710,6 +723,9 @@ extern "C" int wc_msda_bwd_f(const void* value, int value_is_f16, const int* h_s
     else { if (gout_is_f16) MSDA_B2(float, __half) else MSDA_B2(float, float) }
 #undef MSDA_B2
 #undef MSDA_B
+    // the same corner rows + the output-gradient row read + the fp16 offset / weight gradient row written
+    wc_prof_end2(prb, n_levels == 3 ? "msda_bwd4f_kernel<3>" : "msda_bwd4f_kernel<1>", 0.0,
+                 (double)NQ * M * ((double)n_levels * P * 4 * D * (value_is_f16 ? 2 : 4) + D * (gout_is_f16 ? 2 : 4)) + (double)NQ * ld * 2, stream);
     WC_LAUNCH_CHECK("msda_bwd4f_kernel");
     if (gout_is_f16)
         return msda_bwd_value<__half>(loc, attn, (const __half*)gout, gvalue, gvalue16, gmax, ws, sh, n_levels, S, N, Lq, M, D, P, st);

@@ -179,117 +179,12 @@ __global__ __launch_bounds__(256) void par_affinity_reg_kernel(const float* __re
     for (int t = 0; t < T; ++t) A[t * ts] = v0[t] * inv + taps.pi[t];
 }
 
-// Round 3: the same set-up (H16 output) with the 3 x 48 neighbour values taken from an LDS tile instead of 144 four-byte
-// gathers per pixel: a workgroup of 512 threads owns 64 x 8 pixels and first stages the three image planes of its block +
-// a halo of PAR_AHALO pixels, ALREADY CLAMPED (replicate padding), with coalesced row reads (37 loads per thread); a tap is
-// then one ds_read at the thread's tile position + a wave-uniform offset.  Same arithmetic in the same order as
-// par_affinity_reg_kernel (bit-identical affinities); 73.5 KiB of LDS.  MEASURED SLOWER than the register kernel (see
-// launch_affinity): kept behind WECLIP_PAR_AFF_LDS=1 as the record of the experiment.
-#define PAR_AHALO 24
-template <int ND>
-__global__ __launch_bounds__(512) void par_affinity_lds_kernel(const float* __restrict__ img, float* __restrict__ aff, int H, int W,
-                                                                float w1, ParTaps taps) {
-    constexpr int T = 8 * ND, ROWS = 8;
-    constexpr int TW = 64 + 2 * PAR_AHALO, TH = ROWS + 2 * PAR_AHALO;
-    extern __shared__ float atile[];                       // [3][TH][TW]
-    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-    const long HW = (long)H * W;
-    const float* I = img + (long)blockIdx.z * 3 * HW;
-    for (int ty = ly; ty < TH; ty += ROWS) {
-        const int ro = clampi(blockIdx.y * ROWS + ty - PAR_AHALO, H - 1) * W;
-        for (int tx = lx; tx < TW; tx += 64) {
-            const int o = ro + clampi(blockIdx.x * 64 + tx - PAR_AHALO, W - 1);
-            atile[(0 * TH + ty) * TW + tx] = I[o];
-            atile[(1 * TH + ty) * TW + tx] = I[HW + o];
-            atile[(2 * TH + ty) * TW + tx] = I[2 * HW + o];
-        }
-    }
-    __syncthreads();
-    const int x = blockIdx.x * 64 + lx, y = blockIdx.y * ROWS + ly;
-    if (x >= W || y >= H) return;
-    const int tb = (ly + PAR_AHALO) * TW + lx + PAR_AHALO;
-    const float c0 = atile[tb], c1 = atile[TH * TW + tb], c2 = atile[2 * TH * TW + tb];
-    float v0[T], v1[T], v2[T];
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int o = tb + taps.dy[t] * TW + taps.dx[t];
-        v0[t] = atile[o]; v1[t] = atile[TH * TW + o]; v2[t] = atile[2 * TH * TW + o];
-        s0 += v0[t]; s1 += v1[t]; s2 += v2[t];
-    }
-    const float m0 = s0 / T, m1 = s1 / T, m2 = s2 / T;
-    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const float a = v0[t] - m0, b = v1[t] - m1, c = v2[t] - m2;
-        q0 += a * a; q1 += b * b; q2 += c * c;
-    }
-    const float d0 = sqrtf(q0 / (T - 1)) + 1e-8f, d1 = sqrtf(q1 / (T - 1)) + 1e-8f, d2 = sqrtf(q2 / (T - 1)) + 1e-8f;
-    const float r0 = 1.0f / (d0 * w1), r1 = 1.0f / (d1 * w1), r2 = 1.0f / (d2 * w1);
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const float a = fabsf(v0[t] - c0) * r0, b = fabsf(v1[t] - c1) * r1, c = fabsf(v2[t] - c2) * r2;
-        v0[t] = -(a * a + b * b + c * c) * (1.0f / 3.0f);
-        mx = fmaxf(mx, v0[t]);
-    }
-    float sum = 0.f;
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        v0[t] = __expf(v0[t] - mx);
-        sum += v0[t];
-    }
-    const float inv = 1.0f / sum;
-    const int XT = (W + 63) >> 6;
-    unsigned* A2 = reinterpret_cast<unsigned*>(aff) + (((long)blockIdx.z * H + y) * XT + (x >> 6)) * (long)PAR_Q_SLOTS(T) * 64 + (x & 63);
-    float amax = 0.f;
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        v0[t] = v0[t] * inv + taps.pi[t];
-        amax = fmaxf(amax, v0[t]);
-    }
-    const float scale = amax * (1.0f / 65535.0f), rs = 65535.0f / amax;
-    float carry = 0.f;
-#pragma unroll
-    for (int j = 0; j < T / 2; ++j) {
-        const float a0 = v0[2 * j] + carry;
-        const float qa = fminf(fmaxf(rintf(a0 * rs), 0.f), 65535.f);
-        carry = a0 - qa * scale;
-        const float a1 = v0[2 * j + 1] + carry;
-        const float qb = fminf(fmaxf(rintf(a1 * rs), 0.f), 65535.f);
-        carry = a1 - qb * scale;
-        A2[j * 64] = (unsigned)qa | ((unsigned)qb << 16);
-    }
-    A2[(T / 2) * 64] = __float_as_uint(scale);
-}
-
 static void launch_affinity(const float* img, float* aff, int nb, int H, int W, const ParTaps& tp,
                             hipStream_t st, bool tiled, bool h16 = false) {
     dim3 grid(wc_cdiv(W, 64), wc_cdiv(H, 4), nb);
     const int pr = wc_prof_begin(st);
     if (tp.n == 48 && tiled && h16) {
-        // measured (tools/par_aff_ab.py, 16 images 512x512, whole PAR.forward, interleaved processes): 2.19 / 2.25 ms with the
-        // register kernel, 2.34 / 2.40 ms with the LDS tile (bit-identical output): the 73.5-KiB tile fill and one workgroup per
-        // CU cost more than the 144 L1-served gathers per pixel they replace.  Off by default.
-        static const int lds_env = getenv("WECLIP_PAR_AFF_LDS") ? atoi(getenv("WECLIP_PAR_AFF_LDS")) : 0;
-        int dmax = 0;
-        for (int t = 0; t < tp.n; ++t) {
-            const int a = tp.dy[t] < 0 ? -tp.dy[t] : tp.dy[t], b = tp.dx[t] < 0 ? -tp.dx[t] : tp.dx[t];
-            dmax = a > dmax ? a : dmax;
-            dmax = b > dmax ? b : dmax;
-        }
-        if (lds_env && dmax <= PAR_AHALO) {          // neighbour values from an LDS tile (halo = the largest dilation)
-            constexpr size_t lds = 3 * (8 + 2 * PAR_AHALO) * (64 + 2 * PAR_AHALO) * sizeof(float);
-            static bool attr = false;
-            if (!attr) {
-                hipFuncSetAttribute((const void*)par_affinity_lds_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr = true;
-            }
-            hipLaunchKernelGGL((par_affinity_lds_kernel<6>), dim3(wc_cdiv(W, 64), wc_cdiv(H, 8), nb), dim3(512), lds, st, img, aff, H, W,
-                               0.3f, tp);
-            wc_prof_end(pr, "par_affinity_lds_kernel<6>", 4.0 * nb * (double)H * W * 3 + nb * (double)H * W * (2.0 * tp.n + 4.0), st);
-            return;
-        }
+        // (an LDS-tile variant of this set-up was measured slower in round 3: tools/probes/rejected_r03/)
         hipLaunchKernelGGL((par_affinity_reg_kernel<6, true, true>), grid, dim3(256), 0, st, img, aff, H, W, 0.3f, tp);
         wc_prof_end(pr, "par_affinity_reg_kernel<6, true, true>", 4.0 * nb * (double)H * W * 3 + nb * (double)H * W * (2.0 * tp.n + 4.0), st);
         return;

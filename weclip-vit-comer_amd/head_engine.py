@@ -21,7 +21,7 @@ from .clip import vit_engine as VE
 from .ops import F16, F32, Split
 
 GRAD_SCALE = 4096.0
-_WGRAD_WGS = int(os.environ.get("WECLIP_WGRAD_WGS", "512"))   # workgroups a split-K weight-gradient GEMM may use
+_WGRAD_WGS = 512   # workgroups a split-K weight-gradient GEMM may use
 
 
 def _f(p):
@@ -200,39 +200,16 @@ class HeadEngine:
         The split-K reductions of all weight gradients are collected and run as ONE launch at the end
         (wc_sum_slices_wb_multi; 16 launches of 5-7 us at the launch floor otherwise)."""
         self._pending = []
-        # the weight-gradient GEMMs (few 128x128 output tiles, long contraction: low occupancy) and their reduction depend on
-        # nothing downstream: they run on a second stream beside the data-gradient chain and join at the end
-        side = None
-        if _FORK_WGRAD and (dseg if dseg is not None else dap).is_cuda:
-            dev = (dseg if dseg is not None else dap).device
-            side = _WG_STREAMS.get(dev.index)
-            if side is None:
-                side = _WG_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
-        self._wg_side, self._keep = side, []
+        # (the weight-gradient GEMMs on a second stream beside the data-gradient chain were measured neutral in round 3: one stream)
         try:
             grads = self._backward_impl(ctx, dseg, dap)
-            if side is not None:
-                main = torch.cuda.current_stream()
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    self._flush_reductions()
-                main.wait_stream(side)
-            else:
-                self._flush_reductions()
+            self._flush_reductions()
         finally:
             self._pending = None
-            self._wg_side, self._keep = None, None
         return grads
 
     def _partials(self, *a, **kw):
-        """ops.wgrad_partials on the weight-gradient stream (operands kept alive until the join)."""
-        side = getattr(self, "_wg_side", None)
-        if side is None:
-            return ops.wgrad_partials(*a, **kw)
-        side.wait_stream(torch.cuda.current_stream())
-        self._keep.extend(t for t in a if isinstance(t, torch.Tensor))
-        with torch.cuda.stream(side):
-            return ops.wgrad_partials(*a, **kw)
+        return ops.wgrad_partials(*a, **kw)
 
     def _reduce(self, part, gw, gb, ns, N_, K_, alpha, groups=1, sw=0, sb=0):
         """dW / db = alpha * sum of the `ns` split-K slices of `part`: queued while a backward pass is collecting,
@@ -444,8 +421,6 @@ class HeadEngine:
         return dx
 
 
-_FORK_WGRAD = os.environ.get("WECLIP_FORK_WGRAD", "0") != "0"      # measured neutral (12.74-12.80 vs 12.75-12.84 ms per step): off
-_WG_STREAMS = {}
 
 
 class HeadFunction(torch.autograd.Function):

@@ -42,8 +42,8 @@ class KernelTimer:
         L.lib().cdll.wc_prof_report(buf, len(buf))
         out = {}
         for line in buf.value.decode().splitlines():
-            name, n, ms, work, est = line.split("\t")
-            out[name] = {"ms": float(ms), "launches": int(n), "work": float(work), "est_ms": float(est)}
+            name, n, ms, work, est, nbytes = line.split("\t")
+            out[name] = {"ms": float(ms), "launches": int(n), "work": float(work), "est_ms": float(est), "bytes": float(nbytes)}
         return out
 
 
@@ -97,6 +97,28 @@ def gemm(a, w, M, N, K, *, lda=None, ldw=None, bias=None, resid=None, ldr=None, 
                                 sX2, L.stream())
 
 
+def gemm_row_ok(M, N, K):
+    """Shapes of the row-streaming kernel (csrc/gemm_row.hip): N <= 256, N % 4 == 0, K = 128 | 256."""
+    return N <= 256 and N % 4 == 0 and K in (128, 256) and M > 0
+
+
+def gemm_row(a16, w16, M, N, K, *, lda=None, ldw=None, bias=None, cscale=None, act=0, aux=None, auxh=None, ldaux=0, resid=None,
+             ldr=None, out32=None, out16=None, pre32=None, ldc=None, ldc16=None, ln=(), eps=1e-5):
+    """C = epilogue(A W^T) on the row-streaming kernel; `ln`: up to two (gamma, beta, out16 (M, 256)) fused LayerNorm outputs."""
+    lda = K if lda is None else lda
+    ldw = K if ldw is None else ldw
+    ldc = N if ldc is None else ldc
+    ldr = ldc if ldr is None else ldr
+    ldc16 = ldc if ldc16 is None else ldc16
+    lnp = [None] * 6
+    for i, (gam, bet, out) in enumerate(ln):
+        lnp[3 * i:3 * i + 3] = [L.ptr(gam, F32, "ln.weight"), L.ptr(bet, F32, "ln.bias"), L.ptr(out, F16, "ln.out")]
+    L.lib().wc_gemm_row_f16(L.ptr(a16, F16, "A"), lda, L.ptr(w16, F16, "W"), ldw, M, N, K, L.ptr(bias, F32, "bias"),
+                            L.ptr(cscale, F32, "cscale"), act, L.ptr(aux, F32, "aux"), L.ptr(auxh, F16, "auxh"), ldaux,
+                            L.ptr(resid, F32, "resid"), ldr, L.ptr(out32, F32, "out32"), L.ptr(out16, F16, "out16"),
+                            L.ptr(pre32, F32, "pre32"), ldc, ldc16, lnp[0], lnp[1], lnp[2], lnp[3], lnp[4], lnp[5], float(eps), L.stream())
+
+
 def layernorm(x, weight, bias, *, eps=1e-5, want32=False, want16=True, with_lo=False, rows=None,
               D=None, ldx=None):
     """Row LayerNorm of fp32 x (rows, D).  Returns (y32 or None, Split or None)."""
@@ -113,11 +135,9 @@ def layernorm(x, weight, bias, *, eps=1e-5, want32=False, want16=True, with_lo=F
     return y32, (Split(hi, lo) if want16 else None)
 
 
-def attention(qkv16, B, Lq, H, DH, want_mean=True, want_o32=False, mean_side=None):
+def attention(qkv16, B, Lq, H, DH, want_mean=True, want_o32=False):
     """qkv16 (B*L, 3E) fp16 with q pre-scaled by log2(e)/sqrt(DH).
-    Returns (o16 (B*L, E) fp16, lse (B,H,L) f32, mean (B,L,L) f32 or None).
-    mean_side = (stream, keep list): the head-mean kernel goes to that stream (behind the forward kernel); the caller joins
-    the stream before it reads the map and drops `keep` (the kernel's inputs) only after the join."""
+    Returns (o16 (B*L, E) fp16, lse (B,H,L) f32, mean (B,L,L) f32 or None)."""
     E = H * DH
     dev = qkv16.device
     lib = L.lib()
@@ -126,14 +146,7 @@ def attention(qkv16, B, Lq, H, DH, want_mean=True, want_o32=False, mean_side=Non
     o32 = torch.empty(B * Lq, E, device=dev, dtype=F32) if want_o32 else None
     lib.wc_attn_fwd(L.ptr(qkv16, F16, "qkv"), L.ptr(o16), L.ptr(o32), L.ptr(lse), B, Lq, H, DH, L.stream())
     mean = None
-    if want_mean and mean_side is not None:
-        side, keep = mean_side
-        side.wait_stream(torch.cuda.current_stream())
-        keep.extend((qkv16, lse))
-        with torch.cuda.stream(side):
-            mean = torch.empty(B, Lq, Lq, device=dev, dtype=F32)
-            lib.wc_attn_mean(L.ptr(qkv16), L.ptr(lse), L.ptr(mean), B, Lq, H, DH, L.stream())
-    elif want_mean:
+    if want_mean:
         mean = torch.empty(B, Lq, Lq, device=dev, dtype=F32)
         lib.wc_attn_mean(L.ptr(qkv16), L.ptr(lse), L.ptr(mean), B, Lq, H, DH, L.stream())
     if want_o32:

@@ -217,8 +217,8 @@ def linear_bwd(dy: Tensor, x: Tensor, weight: Tensor, y: Tensor, act: int, need_
         dy = pad
     _, dS = ops.colscale_split(dy, None, M, alpha=GRAD_SCALE, want32=False, with_lo=ex)
     w2 = weight.detach().float().reshape(N, K).contiguous()
-    none = dy.new_empty((0,))
-    dx = dw = db = none
+    # one placeholder PER slot: outputs of a custom op may not alias each other
+    dx, dw, db = (torch.empty((0,), device=dev, dtype=F32) for _ in range(3))
     if need_dx:
         wT, Kp = ops.transpose_f16(w2, N, K, with_lo=ex)          # (K, Np) fp16: W^T with the N columns zero padded
         dx = torch.empty(M, K, device=dev, dtype=F32)
@@ -239,9 +239,10 @@ def linear_bwd(dy: Tensor, x: Tensor, weight: Tensor, y: Tensor, act: int, need_
 @linear_bwd.register_fake
 def _(dy, x, weight, y, act, need_dx, need_dw):
     N, K = weight.shape[0], x.shape[1]
-    e = dy.new_empty((0,), dtype=F32)
-    return (x.new_empty(x.shape, dtype=F32) if need_dx else e, x.new_empty((N, K), dtype=F32) if need_dw else e,
-            x.new_empty((N,), dtype=F32) if need_dw else e)
+    def e():
+        return dy.new_empty((0,), dtype=F32)
+    return (x.new_empty(x.shape, dtype=F32) if need_dx else e(), x.new_empty((N, K), dtype=F32) if need_dw else e(),
+            x.new_empty((N,), dtype=F32) if need_dw else e())
 
 
 def _linear_setup(ctx, inputs, output):

@@ -87,8 +87,15 @@ class TrainStep:
             # (the bucket is zeroed each step and each gradient is written exactly once per backward)
             eng.direct_grads = {n: p.grad for n, p in zip(eng.param_names(), eng.params()) if p.grad is not None}
         comer = getattr(model, "comer", None)
-        if self.bucket is not None and comer is not None and os.environ.get("WECLIP_DIRECT_GRADS", "1") != "0":
-            comer.direct_grads = True          # the insert engine writes its parameter gradients into the bucket views too
+        if comer is not None:
+            # the insert engine writes its parameter gradients into the views of THIS bucket (address range recorded: a .grad
+            # that lies elsewhere is accumulated through autograd as usual); a TrainStep without a bucket clears the opt-in
+            comer.direct_grads = False
+            if self.bucket is not None and os.environ.get("WECLIP_DIRECT_GRADS", "1") != "0":
+                lo = self.bucket.flat.data_ptr()
+                comer.direct_grads = (lo, lo + 4 * self.bucket.flat.numel())
+        if eng is not None and self.bucket is None:
+            eng.direct_grads = None
 
     def mask(self, h, w, device):
         key = (h, w, str(device))
