@@ -65,13 +65,16 @@ def test_whole_forward_backward_matches_reference(golden, seg_trans, head):
             # gradients pass twice through fp16 tensors (forced-fp16 out-projection of the decoder,
             # myAtt.py:321): values ~1e-5 are fp16-subnormal there, so CPU-vs-GPU half GEMMs differ
             # by a few % of the largest entry on the 48-token tiny case.
-            assert np.abs(got - ref).max() <= 5e-2 * np.abs(ref).max() + 1e-7, k
+            # measured worst entry: 2.1e-2 of its tensor's largest (hip and torch head alike, both affinity branches)
+            assert np.abs(got - ref).max() <= 3e-2 * np.abs(ref).max() + 1e-7, k
     print(f"[{head} seg_trans={seg_trans}] worst gradient entry error {worst_entry:.2e} of the tensor's largest entry")
     names = [str(n) for n in g["grad_names"]]
     norms = np.array([float(grads[n].grad.norm()) for n in names])
     worst = np.abs(norms - g["grad_norms"]).max() / g["grad_norms"].max()
     print(f"[{head} seg_trans={seg_trans}] worst grad-norm deviation {worst:.2e} of the largest norm")
-    np.testing.assert_allclose(norms, g["grad_norms"], rtol=3e-2, atol=1e-6)
+    # measured: 3.5e-5 of the largest norm; per tensor within 1 % (small-norm tensors carry the fp16-subnormal effect above)
+    assert worst < 2e-4, worst
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=1e-2, atol=1e-6)
     assert all(p.grad is None for p in m.encoder.parameters())
 
 

@@ -286,7 +286,7 @@ class ComerEngine:
 
     def _wgrad(self, dy16, x16, M, N, K, grads, pw, pb, lda=None, xmap=None):
         """pw.grad / pb.grad (unscaled) of y = x W^T + b from the fp16 operands dy16 (M, lda >= N) [x GS] and x16 (M, K)."""
-        tiles = ((N + 127) // 128) * ((K + 1 + 127) // 128)
+        tiles = ops.wgrad_tiles(N, K)
         ns = 1
         while ns * 2 * tiles <= 512 and M // (ns * 2) >= 256:
             ns *= 2

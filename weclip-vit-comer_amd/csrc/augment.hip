@@ -96,9 +96,11 @@ __global__ __launch_bounds__(256) void augment_normalize_kernel(const unsigned c
     const int* ex = tab + (((long)b * 2 + 1) * crop + x) * AUG_ENT;
     const int ymin = ey[0], ny = ey[1], xmin = ex[0], nx = ex[1];
     float v0 = 0.f, v1 = 0.f, v2 = 0.f;                                    // canvas padding (mean_rgb = [0, 0, 0])
-    if (ny < 0 || nx < 0) {                                                // precondition in/out <= 4 violated (aug_coeff_kernel)
+    if (ny == 0 || nx == 0) {
+        // outside the rescaled image on either axis: canvas padding, whatever the other axis' table says
+    } else if (ny < 0 || nx < 0) {                                         // precondition in/out <= 4 violated (aug_coeff_kernel)
         v0 = v1 = v2 = __builtin_nanf("");
-    } else if (ny > 0 && nx > 0) {
+    } else {
         const unsigned char* S = src + ((long)b * Hs * Ws + (long)ymin * Ws + xmin) * 3;
         int a0 = 1 << (AUG_PREC - 1), a1 = a0, a2 = a0;
         for (int j = 0; j < ny; ++j) {

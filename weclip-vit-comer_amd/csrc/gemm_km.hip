@@ -24,6 +24,8 @@ struct KmArgs {
     int x_rpg, x_gs, x_off;   // X row of token m = (m / x_rpg) * x_gs + m % x_rpg + x_off  (skips CLS rows)
     int mslice;           // tokens per slice (multiple of 64)
     int bias;
+    int bias_edge;        // K % 128 == 0: the bias column K lies just past the last column tile; that tile's right-hand waves
+                          // accumulate it and store it themselves (no third column tile that re-reads dY for one column)
     int gx;
     int tiles, ns, units; // output tiles per (group, slice) unit, slices per group, units = groups * ns
     int xcd;              // XCD-aware workgroup order (units % 8 == 0)
@@ -131,7 +133,8 @@ __global__ __launch_bounds__(256, 2) void gemm_km_kernel(KmArgs g) {
     }
     // the wave whose 64 output columns contain column K (the bias column) also accumulates dY^T 1
     const int kb = g.K - (k0 + wc * 64);
-    const bool own_bias = g.bias && kb >= 0 && kb < 64;
+    const bool edge_bias = g.bias_edge && tx == g.gx - 1 && wc == 1;
+    const bool own_bias = (g.bias && kb >= 0 && kb < 64) || edge_bias;
     f16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
@@ -187,7 +190,18 @@ __global__ __launch_bounds__(256, 2) void gemm_km_kernel(KmArgs g) {
 #undef KM_TR
 #undef KM_JOIN
 #undef KM_LOAD
-    if (own_bias) {      // every column of bacc holds the row sums: drop them into output column K
+    if (edge_bias) {     // every column of bacc holds the row sums: one lane per row group stores them into output column K
+        if ((lane & 31) == 0) {
+            float* pb = g.e.C32 + (long)z * g.e.sC + (long)grp * g.gP + g.K;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = n0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < g.N) pb[(long)row * g.e.ldc] = bacc[mi][r];
+                }
+        }
+    } else if (own_bias) {      // ... or drop them into output column K inside this wave's block
         const int ni = kb >> 5, cl = kb & 31;
         if ((lane & 31) == cl) {
 #pragma unroll
@@ -231,7 +245,8 @@ extern "C" int wc_gemm_km_f16_grouped(const void* dY, long lda, const void* X, l
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldx = ldx;
     g.x_rpg = x_rpg; g.x_gs = x_gs; g.x_off = x_off; g.mslice = mslice; g.bias = bias ? 1 : 0;
     const int K1 = K + g.bias;
-    g.gx = wc_cdiv(K1, 128);
+    g.bias_edge = (g.bias && K % 128 == 0) ? 1 : 0;
+    g.gx = g.bias_edge ? K / 128 : wc_cdiv(K1, 128);
     GemmArgs& e = g.e;
     e.A[0] = e.A[1] = e.A[2] = nullptr; e.W[0] = e.W[1] = e.W[2] = nullptr;
     e.nseg = 1; e.M = N; e.N = K1; e.K = 0; e.lda = e.ldw = 0; e.sA = e.sW = 0;

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_row_kernel(RowArgs g) {
         Ct[1280 + tid] = g.ln_o[1] ? g.ln_b[1][n] : 0.f;
     }
     const bool has_res = g.resid != nullptr;
+    const int nout = (g.P32 ? 1 : 0) + (g.C32 ? 1 : 0) + (g.C16 ? 1 : 0) + (g.ln_o[0] ? 1 : 0) + (g.ln_o[1] ? 1 : 0);   // stores per row
     const int c4 = lane * 4;                           // row phase: lane l owns columns 4l .. 4l+3
     const bool cact = c4 < g.N;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -183,110 +184,177 @@ __global__ __launch_bounds__(256, 2) void gemm_row_kernel(RowArgs g) {
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
             const unsigned ab = aoff + sa * SLOT;
-            f16x8 fa[2];
-            ROW_LD128(fa[0], ab + (x4 << 4));
+            f16x8 fa[4];      // the fragments of three k-steps are in flight ahead of the MFMAs (an LDS read takes longer than 4 MFMAs)
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) ROW_LD128(fa[ks], ab + (((ks * 4) ^ x4) << 4));
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                if (ks + 1 < KS) {
-                    ROW_LD128(fa[(ks + 1) & 1], ab + ((((ks + 1) * 4) ^ x4) << 4));
-                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fa[ks & 1]));
+                if (ks + 3 < KS) {
+                    ROW_LD128(fa[(ks + 3) & 3], ab + ((((ks + 3) * 4) ^ x4) << 4));
+                    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[ks & 3]));
+                } else if (ks + 2 < KS) {
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[ks & 3]));
+                } else if (ks + 1 < KS) {
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fa[ks & 3]));
                 } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[ks & 1]));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[ks & 3]));
                 }
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb)
-                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ks & 1], wf[cb][ks], acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ks & 3], wf[cb][ks], acc[cb], 0, 0, 0);
             }
-            // accumulators -> C tile: element e of block cb = row 4 q16 + e, column cw + 16 cb + l15
+            // accumulators -> C tile: element e of block cb = row 4 q16 + e, column cw + 16 cb + l15.
+            // The stores are inline asm, which the compiler's hazard recognizer does not see: an LDS store may read an MFMA
+            // result only a number of wait states after the MFMA issued (software-managed on CDNA), so all MFMAs are retired
+            // behind explicit s_nops first (the "+v" ties make every accumulator final before the nops).
+            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ROW_ST32(cwr + (e * 256 + cb * 16) * 4, acc[cb][e]);
         }
         ROW_BAR();
-        // ---- the iteration's one vmcnt wait, in front of the row phase's stores.  Steady state: leave the DMA batch issued at the
-        // top of THIS iteration (A of tile i + 2, side of tile i + 1: NDMA + nsd instructions per thread) in flight; everything
-        // older -- the batch of the previous iteration (this tile's side input, the next tile's A) and the previous row phase's
-        // stores -- has then completed.  The last two iterations drain.
+        // ---- the iteration's one vmcnt wait, in front of the row phase's stores.  The in-order queue holds, oldest first:
+        //   [DMA batch of iteration i - 1: this tile's side input, the next tile's A] [stores of row phase i - 1] [DMA batch of
+        //   iteration i: A of tile i + 2, side of tile i + 1].
+        // Only the first group must have landed: the wait leaves the other two in flight -- 4 rows x (outputs) store instructions
+        // + NDMA + nsd DMA instructions per wave, both uniform.  (Waiting for the previous row phase's stores as well, i.e.
+        // vmcnt(NDMA + nsd), made every iteration as long as a store round trip: ~2 us per 16-row tile, a floor of ~30 us under
+        // the 86 016-row launches whatever their HBM traffic.)  A ragged tile issues fewer stores, but it is the last tile of its
+        // workgroup and the last two iterations drain.
         if (full) {
-            switch (NDMA + nsd) {
-                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            switch (NDMA + nsd + 4 * nout) {
+#define ROW_W(n_) case n_: asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory"); break;
+                ROW_W(1) ROW_W(2) ROW_W(3) ROW_W(4) ROW_W(5) ROW_W(6) ROW_W(7) ROW_W(8) ROW_W(9) ROW_W(10) ROW_W(11) ROW_W(12)
+                ROW_W(13) ROW_W(14) ROW_W(15) ROW_W(16) ROW_W(17) ROW_W(18) ROW_W(19) ROW_W(20) ROW_W(21) ROW_W(22) ROW_W(23)
+                ROW_W(24) ROW_W(25) ROW_W(26)
+#undef ROW_W
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
             }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        // ---- row phase: this wave's 4 rows TOGETHER (one LDS round trip, one uniform branch per feature instead of one per row
+        // and feature: the per-row form spent ~3 us per tile on LDS latencies and taken scalar branches, a floor of ~30 us
+        // under the 86 016-row launches whatever their HBM traffic)
+        constexpr int RB = ERF ? 2 : 4;      // rows per batch (the erf builds carry more live values per row)
         rf32x4 bias4, cs4;
         ROW_LD128(bias4, ctc);
         ROW_LD128(cs4, ctc + 1024);
-        const unsigned srd = lbase + SIDE0 + ss * SSLOT + ((wave * 4 * g.N + (cact ? c4 : 0)) * sel);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rl = wave * 4 + j;
-            const long grow = (long)t * ROW_TM + rl;
-            if (grow >= g.M) continue;                                       // (wave-uniform: ragged last tile only)
-            rf32x4 c, sd = {0.f, 0.f, 0.f, 0.f};
-            u32x2 sh = {0u, 0u};
-            ROW_LD128(c, crd + j * 1024);
-            if (sel == 4 && sptr) ROW_LD128(sd, srd + j * g.N * 4);
-            if (sel == 2) ROW_LD64(sh, srd + j * g.N * 2);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c), "+v"(sd), "+v"(sh), "+v"(bias4), "+v"(cs4));
-            float v[4] = {(c[0] + bias4[0]) * cs4[0], (c[1] + bias4[1]) * cs4[1], (c[2] + bias4[2]) * cs4[2], (c[3] + bias4[3]) * cs4[3]};
-            if (g.P32 && cact) *reinterpret_cast<float4*>(g.P32 + grow * g.ldc + c4) = make_float4(v[0], v[1], v[2], v[3]);
-            if (act == 2) {
+        for (int hb = 0; hb < 4 / RB; ++hb) {
+        rf32x4 c[RB], sd[RB];
+        u32x2 sh[RB];
+        const unsigned srd = lbase + SIDE0 + ss * SSLOT + (((wave * 4 + hb * RB) * g.N + (cact ? c4 : 0)) * sel);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-            } else if (act == 5) {
-                const __half* hp = reinterpret_cast<const __half*>(&sh);
+        for (int j = 0; j < RB; ++j) {
+            ROW_LD128(c[j], crd + (hb * RB + j) * 1024);
+            sd[j] = rf32x4{0.f, 0.f, 0.f, 0.f};
+            sh[j] = u32x2{0u, 0u};
+        }
+        if (sptr && sel == 4) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] *= __half2float(hp[k]) > 0.f ? 1.f : 0.f;
-            } else if (ERF && act == 6) {
-                // one erff live at a time (a rotating non-unrolled loop over the four values): four interleaved copies of its
-                // polynomial cost ~60 registers on top of the 128 weight registers
-#pragma unroll 1
-                for (int k = 0; k < 4; ++k) {
-                    const float r = 0.5f * v[0] * (1.0f + erff(v[0] * 0.70710678118654752f));
-                    v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = r;
-                }
-            } else if (ERF && act == 7) {
-                float u[4] = {sd[0], sd[1], sd[2], sd[3]};
-#pragma unroll 1
-                for (int k = 0; k < 4; ++k) {      // d/du [u * Phi(u)] = Phi(u) + u * phi(u)
-                    const float r = v[0] * (0.5f * (1.0f + erff(u[0] * 0.70710678118654752f)) + u[0] * 0.3989422804014327f * __expf(-0.5f * u[0] * u[0]));
-                    v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = r;
-                    u[0] = u[1]; u[1] = u[2]; u[2] = u[3];
-                }
+            for (int j = 0; j < RB; ++j) ROW_LD128(sd[j], srd + j * g.N * 4);
+        }
+        if (sel == 2) {
+#pragma unroll
+            for (int j = 0; j < RB; ++j) ROW_LD64(sh[j], srd + j * g.N * 2);
+        }
+        if constexpr (RB == 4)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(bias4), "+v"(cs4), "+v"(c[0]), "+v"(c[1]), "+v"(c[RB - 2]), "+v"(c[RB - 1]), "+v"(sd[0]), "+v"(sd[1]),
+                           "+v"(sd[RB - 2]), "+v"(sd[RB - 1]), "+v"(sh[0]), "+v"(sh[1]), "+v"(sh[RB - 2]), "+v"(sh[RB - 1]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bias4), "+v"(cs4), "+v"(c[0]), "+v"(c[1]), "+v"(sd[0]), "+v"(sd[1]), "+v"(sh[0]), "+v"(sh[1]));
+        const long grow0 = (long)t * ROW_TM + wave * 4 + hb * RB;
+        const int nrow = g.M - grow0 >= RB ? RB : (int)(g.M - grow0);      // < RB (or <= 0) in the ragged last tile only
+        float v[RB][4];
+#pragma unroll
+        for (int j = 0; j < RB; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[j][k] = (c[j][k] + bias4[k]) * cs4[k];
+        if (g.P32) {
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+                if (cact && j < nrow) *reinterpret_cast<float4*>(g.P32 + (grow0 + j) * g.ldc + c4) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+        }
+        if (act == 2) {
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[j][k] = fmaxf(v[j][k], 0.f);
+        } else if (act == 5) {
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const __half* hp = reinterpret_cast<const __half*>(&sh[j]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[j][k] *= __half2float(hp[k]) > 0.f ? 1.f : 0.f;
             }
-            if (has_res) { v[0] += sd[0]; v[1] += sd[1]; v[2] += sd[2]; v[3] += sd[3]; }
-            if (cact) {
-                if (g.C32) *reinterpret_cast<float4*>(g.C32 + grow * g.ldc + c4) = make_float4(v[0], v[1], v[2], v[3]);
-                if (g.C16) {
+        } else if (ERF && (act == 6 || act == 7)) {
+            // one erff live at a time: a non-unrolled loop over the 16 values that rotates them through v[0][0] (four interleaved
+            // copies of erff's polynomial cost ~60 registers on top of the 128 weight registers).  act 7: u = the saved
+            // pre-activation, d/du [u * Phi(u)] = Phi(u) + u * phi(u)
+            const bool d7 = act == 7;
+#pragma unroll 1
+            for (int n = 0; n < RB * 4; ++n) {
+                const float x = d7 ? sd[0][0] : v[0][0];
+                const float ph = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+                const float r = d7 ? v[0][0] * (ph + x * 0.3989422804014327f * __expf(-0.5f * x * x)) : x * ph;
+#pragma unroll
+                for (int j = 0; j < RB; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (j == RB - 1 && k == 3) { v[RB - 1][3] = r; sd[RB - 1][3] = x; }
+                        else { v[j][k] = v[k == 3 ? j + 1 : j][k == 3 ? 0 : k + 1]; sd[j][k] = sd[k == 3 ? j + 1 : j][k == 3 ? 0 : k + 1]; }
+                    }
+            }
+        }
+        if (has_res) {
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[j][k] += sd[j][k];
+        }
+        if (g.C32) {
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+                if (cact && j < nrow) *reinterpret_cast<float4*>(g.C32 + (grow0 + j) * g.ldc + c4) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+        }
+        if (g.C16) {
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                __half h[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) h[k] = __float2half(v[j][k]);
+                if (cact && j < nrow) *reinterpret_cast<u32x2*>(g.C16 + (grow0 + j) * g.ldc16 + c4) = *reinterpret_cast<u32x2*>(h);
+            }
+        }
+        if (g.ln_o[0]) {      // N == 256: all 64 lanes hold 4 columns; same arithmetic as layernorm_kernel<1> (norm.hip)
+            float mean[RB], rstd[RB];
+#pragma unroll
+            for (int j = 0; j < RB; ++j) mean[j] = wave_sum((v[j][0] + v[j][1]) + (v[j][2] + v[j][3])) / 256.f;
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[j][k] -= mean[j];
+                rstd[j] = rsqrtf(wave_sum((v[j][0] * v[j][0] + v[j][1] * v[j][1]) + (v[j][2] * v[j][2] + v[j][3] * v[j][3])) / 256.f + g.eps);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (!g.ln_o[s]) continue;
+                rf32x4 ww, bb;
+                ROW_LD128(ww, ctc + 2048 + s * 2048);
+                ROW_LD128(bb, ctc + 3072 + s * 2048);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ww), "+v"(bb));
+#pragma unroll
+                for (int j = 0; j < RB; ++j) {
                     __half h[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) h[k] = __float2half(v[k]);
-                    *reinterpret_cast<u32x2*>(g.C16 + grow * g.ldc16 + c4) = *reinterpret_cast<u32x2*>(h);
+                    for (int k = 0; k < 4; ++k) h[k] = __float2half(v[j][k] * rstd[j] * ww[k] + bb[k]);
+                    if (j < nrow) *reinterpret_cast<u32x2*>(g.ln_o[s] + (grow0 + j) * 256 + c4) = *reinterpret_cast<u32x2*>(h);
                 }
             }
-            if (g.ln_o[0]) {      // N == 256: all 64 lanes hold 4 columns; same arithmetic as layernorm_kernel<1> (norm.hip)
-                const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) / 256.f;
-                const float a0 = v[0] - mean, a1 = v[1] - mean, a2 = v[2] - mean, a3 = v[3] - mean;
-                const float rstd = rsqrtf(wave_sum((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) / 256.f + g.eps);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    if (!g.ln_o[s]) continue;
-                    rf32x4 ww, bb;
-                    ROW_LD128(ww, ctc + 2048 + s * 2048);
-                    ROW_LD128(bb, ctc + 3072 + s * 2048);
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ww), "+v"(bb));
-                    __half h[4] = {__float2half(a0 * rstd * ww[0] + bb[0]), __float2half(a1 * rstd * ww[1] + bb[1]),
-                                   __float2half(a2 * rstd * ww[2] + bb[2]), __float2half(a3 * rstd * ww[3] + bb[3])};
-                    *reinterpret_cast<u32x2*>(g.ln_o[s] + grow * 256 + c4) = *reinterpret_cast<u32x2*>(h);
-                }
-            }
+        }
         }
         sa = sa == 2 ? 0 : sa + 1;
     }

@@ -351,7 +351,7 @@ class HeadEngine:
         from . import _lib as L
 
         def run(dy, lda, gA, x, ldx, gX, N_, K_, xmap, gw, gb, sw, sb):
-            tiles = ((N_ + 127) // 128) * ((K_ + 1 + 127) // 128) * n
+            tiles = ops.wgrad_tiles(N_, K_) * n
             ns = max(1, min(_WGRAD_WGS // tiles, M // 256))       # one round of workgroups (2 per CU), few partials
             part, ns = self._partials(dy, x, M, N_, K_, lda=lda, ldx=ldx, slices=ns, bias=True, xmap=xmap, groups=n, gA=gA, gX=gX)
             self._reduce(part, gw, gb, ns, N_, K_, inv, groups=n, sw=sw, sb=sb)
@@ -378,7 +378,7 @@ class HeadEngine:
         in memory (csrc/gemm.hip gemm_km_kernel: transposing LDS reads, no operand transposes).  The output has
         few 128x128 tiles and a long contraction (all tokens), so the tokens are split over `ns` slices
         (blockIdx.z); wc_sum_slices_wb sums them straight into the dense weight / bias gradient buffers."""
-        tiles = ((N_ + 127) // 128) * ((K_ + 1 + 127) // 128)
+        tiles = ops.wgrad_tiles(N_, K_)
         ns = 1
         while ns * 2 * tiles <= _WGRAD_WGS and M // (ns * 2) >= 256:
             ns *= 2

@@ -203,6 +203,13 @@ def transpose_f16(src, R, C, *, ld=None, batch=1, sSrc=0, with_lo=False, scale=1
 _ZEROS = {}
 
 
+def wgrad_tiles(N, K, bias=True):
+    """128x128 output tiles of a weight-gradient GEMM (csrc/gemm_km.hip): the bias column K takes a column tile of its own only
+    when K is not a multiple of 128 (otherwise the last column tile's waves store it)."""
+    kt = K // 128 if (bias and K % 128 == 0) else (K + (1 if bias else 0) + 127) // 128
+    return ((N + 127) // 128) * kt
+
+
 def wgrad_partials(dy16, x16, M, N, K, *, lda=None, ldx=None, slices=1, bias=True, xmap=None, groups=1, gA=0, gX=0):
     """Split-K partials of dW = dY^T X (and db = dY^T 1 as column K) from ROW-MAJOR fp16 operands
     dy16 (M, lda), x16 (rows, ldx): -> (part (ns, N, K + bias) fp32, ns).  xmap = (rows_per_group, group_stride,

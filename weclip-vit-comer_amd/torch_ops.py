@@ -225,7 +225,7 @@ def linear_bwd(dy: Tensor, x: Tensor, weight: Tensor, y: Tensor, act: int, need_
         ops.gemm(dS, wT, M, K, Kp, out32=dx, scale=1.0 / GRAD_SCALE, scale_cols=K)
     if need_dw:
         xhi = ops.split_f16(x.detach().float().contiguous()).hi
-        tiles = ((N + 127) // 128) * ((K + 1 + 127) // 128)
+        tiles = ops.wgrad_tiles(N, K)
         ns = 1
         while ns * 2 * tiles <= 512 and M // (ns * 2) >= 256:
             ns *= 2
