@@ -197,8 +197,9 @@ int wc_sum_slices_wb(const float* part, float* out_w, float* out_b, int nslices,
  * out_w + i*gW and out_b + i*gB (elements) -- the per-adapter gradient views of a flat gradient bucket. */
 int wc_sum_slices_wb_grouped(const float* part, float* out_w, float* out_b, int nslices, int rows, int cols,
                              float alpha, int groups, long gW, long gB, void* stream);
-/* Many split-K reductions in one launch.  jobs: HOST array of count x 7 int64 {part, out_w, out_b (device pointers), nslices,
- * rows, cols, alpha as IEEE float bits}; each job = one wc_sum_slices_wb (same summation order).  The jobs travel by value
+/* Many split-K reductions in one launch.  jobs: HOST array of count x 8 int64 {part, out_w, out_b (device pointers), nslices,
+ * rows, cols, alpha as IEEE float bits, slice stride in elements (0 = rows * (cols + 1); larger when the job reduces a row
+ * range of a wider partial matrix)}; each job = one wc_sum_slices_wb (same summation order).  The jobs travel by value
  * in the kernel arguments (graph-capturable, no device table). */
 int wc_sum_slices_wb_multi(const int64_t* jobs, int count, void* stream);
 
@@ -362,6 +363,10 @@ int wc_colsum(const void* src, int src_f32, long ld, float* part, float* out, lo
 int wc_layernorm_bwd(const float* dy, const float* x, const float* w, const float* add, float eps,
                      float* dx32, void* dx16, float out_scale, float* part, float* dgb, float alpha,
                      long rows, int D, void* stream);
+/* the same with the incoming gradient as fp16 rows dy16 (rows, D) */
+int wc_layernorm_bwd_h(const void* dy16, const float* x, const float* w, const float* add, float eps,
+                       float* dx32, void* dx16, float out_scale, float* part, float* dgb, float alpha,
+                       long rows, int D, void* stream);
 int wc_sigmoid_gram_bwd(const float* dAP, const float* AP, void* hi, void* lo, int B, int n, int ldo,
                         float scale, void* stream);
 int wc_colscale_split(const float* x, const float* cs, float* out32, void* hi, void* lo, long rows, int C,
@@ -375,7 +380,7 @@ int wc_colscale_split(const float* x, const float* cs, float* out32, void* hi, v
  * wc_msda_bwd: gvalue (every element written once: no initialisation needed), gloc, gattn.  grad_value is a bucketed
  *              gather (count / scan / fill per pixel, then a per-pixel sum in 64-bit fixed point, scale 2^40 / max|gout|):
  *              no float atomics anywhere, the result is independent of the execution order.  gmax: workspace of one
- *              uint32; ws: workspace of N*M*S*2 + N*M*n_levels*Lq*P*4 int32; a level may have at most 16384 pixels. */
+ *              uint32; ws: workspace of N*M*S*2 + N*M*n_levels*Lq*P*8 int32; a level may have at most 16384 pixels. */
 int wc_msda_fwd(const float* value, const int* h_shapes, int n_levels, const float* loc, const float* attn,
                 float* out, int N, int Lq, int M, int D, int P, void* stream);
 /* The same with the value tensor as f32 or f16 (value_is_f16: half the gather traffic; needs D % 4 == 0 and M*D/4 dividing
@@ -475,6 +480,12 @@ int wc_rows_copy_f16(const void* src, int src_is_f32, void* dst, int B, int R, i
 /* dst[b][r][0:C] (f32, dense rows of C, batch stride s_dst) += alpha * src[b][r][0:C] (f32; ld_src, s_src). */
 int wc_rows_add_f32(const float* src, float* dst, int B, int R, int C, long ld_src, long s_src, long s_dst, float alpha,
                     void* stream);
+
+/* Gradients of the gated CTI output projection v1 = v + gamma * (o1 Wop^T + bop) from the un-gated weight-gradient products
+ * G (C, K) = dv1^T o1 and gs (C) = dv1^T 1:  dWop = diag(gamma) G, dbop = gamma * gs, dgamma = rowsum(Wop * G) + bop * gs
+ * (all f32; no reference code: ViT_CoMer.pdf section 3.3, the gate of the CNN -> ViT injection). */
+int wc_cti_gate_grads(const float* G, const float* gs, const float* gamma, const float* Wop, const float* bop, float* dWop,
+                      float* dbop, float* dgamma, int C, int K, void* stream);
 
 /* ---- device-side input pipeline ------------------------------------------------------------ */
 /* datasets/transforms.py:26-49 (random_scaling), :70-84 (random_fliplr), :119-176 (random_crop, zero padding),

@@ -54,7 +54,7 @@ class _MSDAFunction(torch.autograd.Function):
         Lq, nL, P = loc.shape[1], loc.shape[3], loc.shape[4]
         gv, gl, ga = torch.empty_like(value), torch.empty_like(loc), torch.empty_like(attn)
         gmax = torch.empty(1, device=value.device, dtype=torch.int32)
-        ws = torch.empty(N * M * (2 * S + nL * Lq * P * 4), device=value.device, dtype=torch.int32)   # bucket starts / sizes / pair ids
+        ws = torch.empty(N * M * (2 * S + nL * Lq * P * 8), device=value.device, dtype=torch.int32)   # bucket starts / sizes / (row, weight) entries
         hs = L.int_array([v for hw in ctx.shapes for v in hw])
         L.lib().wc_msda_bwd(L.ptr(value), hs, nL, L.ptr(loc), L.ptr(attn), L.ptr(gout.float().contiguous(), F32, "gout"),
                             L.ptr(gv), L.ptr(gl), L.ptr(ga), L.ptr(gmax), L.ptr(ws), N, Lq, M, D, P, L.stream())

@@ -127,7 +127,7 @@ class ComerEngine:
         dev = value.device
         gv = torch.empty(value.shape, device=dev, dtype=F16)          # (value is f16 already)
         gmax = torch.empty(1, device=dev, dtype=torch.int32)
-        ws = torch.empty(B * M * (2 * S + nL * Lq * P * 4), device=dev, dtype=torch.int32)
+        ws = torch.empty(B * M * (2 * S + nL * Lq * P * 8), device=dev, dtype=torch.int32)
         hs = _shape_array(shapes)
         lib = L.lib()
         dow16 = torch.empty(B * Lq, ld, device=dev, dtype=F16)
@@ -147,7 +147,10 @@ class ComerEngine:
         fp16 out (M, N))] of the finished fp32 row; `cscale`: (N,) column scale after the bias."""
         a16 = a.hi if isinstance(a, Split) else a
         w16 = w.hi if isinstance(w, Split) else w
-        if self.row_gemm and ops.gemm_row_ok(M, N, K) and (not ln or N == 256) and kw.get("lda", K) % 8 == 0:
+        # (the row kernel streams at the HBM rate -- +8 192 rows per 1.7 us -- behind a fixed ~10 us (every workgroup first loads the
+        #  whole weight matrix into its registers): at 16 384 rows the tile kernels win unless a LayerNorm launch is saved)
+        big = M >= 32768 or bool(ln) or ldc16 is not None
+        if self.row_gemm and big and ops.gemm_row_ok(M, N, K) and (not ln or N == 256) and kw.get("lda", K) % 8 == 0:
             kw.pop("rpg", None)
             ops.gemm_row(a16, w16, M, N, K, cscale=cscale, ldc16=ldc16, eps=ln[0][0].eps if ln else 1e-5,
                          ln=[(self._b(m.weight), self._b(m.bias), o) for m, o in ln], **kw)
@@ -294,7 +297,7 @@ class ComerEngine:
         gw, gb = self._direct(pw), self._direct(pb)
         dw = gw.view(N, K) if gw is not None else torch.empty(N, K, device=dy16.device, dtype=F32)
         db = gb if gb is not None else torch.empty(N, device=dy16.device, dtype=F32)
-        self._pending.append((part, dw, db, ns, N, K))
+        self._pending.append((part, dw, db, ns, N, K, 0, N))
         if pw is not None:
             grads[id(pw)] = dw.view(pw.shape)
         if pb is not None:
@@ -308,8 +311,8 @@ class ComerEngine:
             return
         abits = struct.unpack("<I", struct.pack("<f", INV))[0]
         flat = []
-        for part, dw, db, ns, N, K in jobs:
-            flat += [part.data_ptr(), dw.data_ptr(), db.data_ptr(), ns, N, K, abits]
+        for part, dw, db, ns, N, K, r0, Ntot in jobs:          # rows [r0, r0 + N) of a (ns, Ntot, K + 1) partial matrix
+            flat += [part.data_ptr() + 4 * r0 * (K + 1), dw.data_ptr(), db.data_ptr(), ns, N, K, abits, Ntot * (K + 1)]
         arr = (ctypes.c_int64 * len(flat))(*flat)
         L.lib().wc_sum_slices_wb_multi(arr, len(jobs), L.stream())
 
@@ -369,8 +372,8 @@ class ComerEngine:
             du16 = torch.empty(Mc, C, device=dev, dtype=F16)
             self._mm(dc3_16, WT(f"f{i}.2"), Mc, C, C, out16=du16, act=7, aux=s["u"], ldaux=C, rpg=1)
             self._wgrad(dc3_16, s["g2"], Mc, C, C, grads, t.ffn[2].weight, t.ffn[2].bias)
-            dn3 = torch.empty(Mc, C, device=dev, dtype=F32)
-            self._mm(du16, WT(f"f{i}.0"), Mc, C, C, out32=dn3)
+            dn3 = torch.empty(Mc, C, device=dev, dtype=F16)            # (gradients that only feed a LayerNorm backward travel as fp16)
+            self._mm(du16, WT(f"f{i}.0"), Mc, C, C, out16=dn3)
             self._wgrad(du16, s["n3"], Mc, C, C, grads, t.ffn[0].weight, t.ffn[0].bias)
             dc2, dc2_16 = self._ln_bwd(dn3, s["c2"], t.ffn_norm, dc3, grads, want16=True)
             # ---- CTI-toC
@@ -378,12 +381,12 @@ class ComerEngine:
             self._mm(dc2_16, WT(f"c{i}.op"), Mc, C, C, out16=do2)
             self._wgrad(dc2_16, s["o2"], Mc, C, C, grads, t.to_c.output_proj.weight, t.to_c.output_proj.bias)
             dval2_16, dow2 = self._msda_bwd(s["val2"], [(h, w)], s["loc2"], s["at2"], do2, t.to_c, B, S, s["ld2"])
-            dq2 = torch.empty(Mc, C, device=dev, dtype=F32)
-            self._mm(dow2, WT(f"c{i}.ow"), Mc, C, s["ld2"], out32=dq2)
+            dq2 = torch.empty(Mc, C, device=dev, dtype=F16)
+            self._mm(dow2, WT(f"c{i}.ow"), Mc, C, s["ld2"], out16=dq2)
             self._ow_grads(dow2, s["q2"], Mc, s["n2"], s["ld2"], t.to_c, grads)
             dc1 = self._ln_bwd(dq2, s["c1"], t.nc_q, dc2, grads)
-            df2 = torch.empty(Mv, C, device=dev, dtype=F32)
-            self._mm(dval2_16, WT(f"c{i}.vp"), Mv, C, C, out32=df2)
+            df2 = torch.empty(Mv, C, device=dev, dtype=F16)
+            self._mm(dval2_16, WT(f"c{i}.vp"), Mv, C, C, out16=df2)
             self._wgrad(dval2_16, s["f2"], Mv, C, C, grads, t.to_c.value_proj.weight, t.to_c.value_proj.bias)
             dv1, dv1_16 = self._ln_bwd(df2, s["v1"], t.nc_f, pieces[2 * i], grads, want16=True)
             # ---- CTI-toV: v1 = v + gamma * (o1 Wop^T + bop)
@@ -394,8 +397,8 @@ class ComerEngine:
             G, gsum = self._wgrad(dv1_16, s["o1"], Mv, C, C, grads, None, None)          # G = dv1^T o1, gsum = dv1^T 1 (unscaled)
             self._gamma_jobs.append((t, G, gsum))
             dval1_16, dow1 = self._msda_bwd(s["val1"], shapes, s["loc1"], s["at1"], do1, t.to_v, B, nhw, s["ld1"])
-            dq1 = torch.empty(Mv, C, device=dev, dtype=F32)
-            self._mm(dow1, WT(f"v{i}.ow"), Mv, C, s["ld1"], out32=dq1)
+            dq1 = torch.empty(Mv, C, device=dev, dtype=F16)
+            self._mm(dow1, WT(f"v{i}.ow"), Mv, C, s["ld1"], out16=dq1)
             self._ow_grads(dow1, s["q1"], Mv, s["n1"], s["ld1"], t.to_v, grads)
             dvs[i] = self._ln_bwd(dq1, s["v"], t.nv_q, dv1, grads)
             if "t1" in s:              # the adapter MLP behind v: v = t1 W2^T + b2, t1 = relu(x W1^T + b1); x is frozen
@@ -406,8 +409,8 @@ class ComerEngine:
                 self._mm(dv16, WT(f"a{i}.p2"), Mv, C, C, out16=dt1, act=5, auxh=s["t1"], ldaux=C)
                 self._wgrad(dt1, s["x16"], Mv, C, s["x16"].shape[1], grads, ad.proj.weight, ad.proj.bias, xmap=(nhw, s["Lq"], 1))
                 dvs[i] = None
-            df1 = torch.empty(Mc, C, device=dev, dtype=F32)
-            self._mm(dval1_16, WT(f"v{i}.vp"), Mc, C, C, out32=df1)
+            df1 = torch.empty(Mc, C, device=dev, dtype=F16)
+            self._mm(dval1_16, WT(f"v{i}.vp"), Mc, C, C, out16=df1)
             self._wgrad(dval1_16, s["f1"], Mc, C, C, grads, t.to_v.value_proj.weight, t.to_v.value_proj.bias)
             dc1, dc1_16 = self._ln_bwd(df1, s["c1"], t.nv_f, dc1, grads, want16=True)
             # ---- MRFP
@@ -436,26 +439,42 @@ class ComerEngine:
         return dc3, dvs, grads
 
     def _ow_grads(self, dow16, q16, M, n, ld, att, grads):
-        """Weight / bias gradients of the stacked sampling_offsets | attention_weights GEMM."""
-        dw, db = self._wgrad(dow16, q16, M, n, att.d_model, grads, None, None, lda=ld)
-        self._ow_jobs.append((att, dw, db))
+        """Weight / bias gradients of the stacked sampling_offsets | attention_weights GEMM: ONE split-K weight-gradient GEMM over
+        the stacked columns, then one reduction job per Linear over its row range of the partials, written straight into that
+        parameter's gradient (the bucket view when TrainStep opted in) -- no slicing / accumulate launches afterwards."""
+        K = att.d_model
+        tiles = ops.wgrad_tiles(n, K)
+        ns = 1
+        while ns * 2 * tiles <= 512 and M // (ns * 2) >= 256:
+            ns *= 2
+        part, ns = ops.wgrad_partials(dow16, q16, M, n, K, lda=ld, slices=ns, bias=True)
+        r0 = 0
+        for lin in (att.sampling_offsets, att.attention_weights):
+            rows = lin.weight.shape[0]
+            gw, gb = self._direct(lin.weight), self._direct(lin.bias)
+            dw = gw.view(rows, K) if gw is not None else torch.empty(rows, K, device=dow16.device, dtype=F32)
+            db = gb if gb is not None else torch.empty(rows, device=dow16.device, dtype=F32)
+            self._pending.append((part, dw, db, ns, rows, K, r0, n))
+            grads[id(lin.weight)], grads[id(lin.bias)] = dw.view(lin.weight.shape), db
+            r0 += rows
 
     def run_backward(self, ctx, dy):
         """backward() plus the tiny post-processing that needs the reduced partials: the stacked gradients are split into
         their two Linears, and gamma's gradient comes out of the output projection's un-gated weight gradient
         G = dv1^T o1:  dWop = diag(gamma) G,  dbop = gamma * s,  dgamma = rowsum(Wop * G) + bop * s  (s = dv1^T 1)."""
-        self._ow_jobs, self._gamma_jobs = [], []
+        self._gamma_jobs = []
         dc0, dvs, grads = self.backward(ctx, dy)
-        for att, dw, db in self._ow_jobs:
-            n_off = att.sampling_offsets.weight.shape[0]
-            grads[id(att.sampling_offsets.weight)], grads[id(att.attention_weights.weight)] = dw[:n_off], dw[n_off:]
-            grads[id(att.sampling_offsets.bias)], grads[id(att.attention_weights.bias)] = db[:n_off], db[n_off:]
         for t, G, gsum in self._gamma_jobs:
-            gam, Wop, bop = t.gamma.detach().float(), t.to_v.output_proj.weight.detach().float(), t.to_v.output_proj.bias.detach().float()
-            grads[id(t.to_v.output_proj.weight)] = gam[:, None] * G
-            grads[id(t.to_v.output_proj.bias)] = gam * gsum
-            grads[id(t.gamma)] = (Wop * G).sum(1) + bop * gsum
-        self._ow_jobs, self._gamma_jobs = None, None
+            op = t.to_v.output_proj
+            dst = [self._direct(q) for q in (op.weight, op.bias, t.gamma)]
+            dW = dst[0] if dst[0] is not None else torch.empty_like(G)
+            db = dst[1] if dst[1] is not None else torch.empty_like(gsum)
+            dg = dst[2] if dst[2] is not None else torch.empty_like(gsum)
+            L.lib().wc_cti_gate_grads(L.ptr(G, F32), L.ptr(gsum, F32), L.ptr(self._b(t.gamma), F32), L.ptr(self._b(op.weight), F32),
+                                      L.ptr(self._b(op.bias), F32), L.ptr(dW, F32), L.ptr(db, F32), L.ptr(dg, F32), G.shape[0], G.shape[1],
+                                      L.stream())
+            grads[id(op.weight)], grads[id(op.bias)], grads[id(t.gamma)] = dW.view(op.weight.shape), db, dg
+        self._gamma_jobs = None
         B, S, C = ctx["B"], ctx["S"], ctx["C"]
         return (dc0 * INV).view(B, S, C), [d * INV if d is not None else None for d in dvs], grads
 

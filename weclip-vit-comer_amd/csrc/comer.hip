@@ -423,3 +423,36 @@ extern "C" int wc_rows_add_f32(const float* src, float* dst, int B, int R, int C
     WC_LAUNCH_CHECK("rows_add_f32_kernel");
     return WC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Gradients of the gated output projection of CTI-toV, v1 = v + gamma * (o1 Wop^T + bop), from the UN-GATED products the
+// weight-gradient GEMM delivers (G = dv1^T o1 (C x K), s = dv1^T 1 (C)):
+//   dWop = diag(gamma) G,   dbop = gamma * s,   dgamma = rowsum(Wop * G) + bop * s.
+// One workgroup per output channel (row); replaces ~9 element-wise / reduction launches of torch glue per stage.
+__global__ __launch_bounds__(256) void cti_gate_grads_kernel(const float* __restrict__ G, const float* __restrict__ gs,
+                                                              const float* __restrict__ gam, const float* __restrict__ Wop,
+                                                              const float* __restrict__ bop, float* __restrict__ dWop,
+                                                              float* __restrict__ dbop, float* __restrict__ dgam, int K) {
+    __shared__ float red[16];
+    const int r = blockIdx.x;
+    const float gr = gam[r];
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < K; c += 256) {
+        const float g = G[(long)r * K + c];
+        dWop[(long)r * K + c] = gr * g;
+        acc += Wop[(long)r * K + c] * g;
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+        dbop[r] = gr * gs[r];
+        dgam[r] = acc + bop[r] * gs[r];
+    }
+}
+
+extern "C" int wc_cti_gate_grads(const float* G, const float* gs, const float* gamma, const float* Wop, const float* bop,
+                                 float* dWop, float* dbop, float* dgamma, int C, int K, void* stream) {
+    WC_CHECK_ARG(G && gs && gamma && Wop && bop && dWop && dbop && dgamma && C > 0 && K > 0, "wc_cti_gate_grads: bad argument");
+    hipLaunchKernelGGL(cti_gate_grads_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, G, gs, gamma, Wop, bop, dWop, dbop, dgamma, K);
+    WC_LAUNCH_CHECK("cti_gate_grads_kernel");
+    return WC_OK;
+}

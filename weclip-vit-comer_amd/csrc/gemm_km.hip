@@ -342,6 +342,7 @@ struct SumJobs {
     float* out_b[SUMJ_MAX];
     int nslices[SUMJ_MAX], rows[SUMJ_MAX], cols[SUMJ_MAX];
     float alpha[SUMJ_MAX];
+    long sstride[SUMJ_MAX];      // elements between two slices (a job may reduce a ROW RANGE of a wider partial matrix)
 };
 __global__ __launch_bounds__(256) void sum_slices_wb_multi_kernel(SumJobs j) {
     const int q = blockIdx.y;
@@ -351,16 +352,17 @@ __global__ __launch_bounds__(256) void sum_slices_wb_multi_kernel(SumJobs j) {
     const int nslices = j.nslices[q], cols = j.cols[q];
     const float alpha = j.alpha[q];
     const long n = (long)j.rows[q] * (cols + 1);
+    const long ss = j.sstride[q];
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // 4 slice loads in flight
         int k = 0;
         for (; k + 4 <= nslices; k += 4) {
-            s0 += part[(long)k * n + i];
-            s1 += part[(long)(k + 1) * n + i];
-            s2 += part[(long)(k + 2) * n + i];
-            s3 += part[(long)(k + 3) * n + i];
+            s0 += part[(long)k * ss + i];
+            s1 += part[(long)(k + 1) * ss + i];
+            s2 += part[(long)(k + 2) * ss + i];
+            s3 += part[(long)(k + 3) * ss + i];
         }
-        for (; k < nslices; ++k) s0 += part[(long)k * n + i];
+        for (; k < nslices; ++k) s0 += part[(long)k * ss + i];
         const float s = (s0 + s1) + (s2 + s3);
         const int r = (int)(i / (cols + 1)), c = (int)(i - (long)r * (cols + 1));
         if (c < cols) out_w[(long)r * cols + c] = s * alpha;
@@ -368,7 +370,8 @@ __global__ __launch_bounds__(256) void sum_slices_wb_multi_kernel(SumJobs j) {
     }
 }
 
-// jobs: count x 7 host int64 {part, out_w, out_b (device pointers), nslices, rows, cols, alpha as float bits}
+// jobs: count x 8 host int64 {part, out_w, out_b (device pointers), nslices, rows, cols, alpha as float bits,
+// slice stride in elements (0 = rows * (cols + 1): the job covers the whole partial matrix)}
 extern "C" int wc_sum_slices_wb_multi(const int64_t* jobs, int count, void* stream) {
     WC_CHECK_ARG(jobs && count > 0, "wc_sum_slices_wb_multi: bad argument");
     for (int base = 0; base < count; base += SUMJ_MAX) {
@@ -376,7 +379,7 @@ extern "C" int wc_sum_slices_wb_multi(const int64_t* jobs, int count, void* stre
         const int m = count - base < SUMJ_MAX ? count - base : SUMJ_MAX;
         long nmax = 0;
         for (int q = 0; q < SUMJ_MAX; ++q) {
-            const int64_t* e = jobs + (long)(base + (q < m ? q : 0)) * 7;
+            const int64_t* e = jobs + (long)(base + (q < m ? q : 0)) * 8;
             j.part[q] = reinterpret_cast<const float*>(e[0]);
             j.out_w[q] = reinterpret_cast<float*>(e[1]);
             j.out_b[q] = reinterpret_cast<float*>(e[2]);
@@ -386,6 +389,8 @@ extern "C" int wc_sum_slices_wb_multi(const int64_t* jobs, int count, void* stre
             WC_CHECK_ARG(j.part[q] && j.out_w[q] && j.out_b[q] && j.nslices[q] > 0 && j.rows[q] > 0 && j.cols[q] > 0,
                          "wc_sum_slices_wb_multi: bad job");
             const long n = (long)j.rows[q] * (j.cols[q] + 1);
+            j.sstride[q] = e[7] > 0 ? (long)e[7] : n;
+            WC_CHECK_ARG(j.sstride[q] >= n, "wc_sum_slices_wb_multi: slice stride smaller than the job");
             if (q < m && n > nmax) nmax = n;
         }
         long bx = wc_cdiv(nmax, 256 * 4);          // <= 4 elements per thread of the largest job

@@ -161,7 +161,6 @@ __global__ __launch_bounds__(256, 2) void gemm_row_kernel(RowArgs g) {
         Ct[1280 + tid] = g.ln_o[1] ? g.ln_b[1][n] : 0.f;
     }
     const bool has_res = g.resid != nullptr;
-    const int nout = (g.P32 ? 1 : 0) + (g.C32 ? 1 : 0) + (g.C16 ? 1 : 0) + (g.ln_o[0] ? 1 : 0) + (g.ln_o[1] ? 1 : 0);   // stores per row
     const int c4 = lane * 4;                           // row phase: lane l owns columns 4l .. 4l+3
     const bool cact = c4 < g.N;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -214,22 +213,22 @@ __global__ __launch_bounds__(256, 2) void gemm_row_kernel(RowArgs g) {
                 for (int e = 0; e < 4; ++e) ROW_ST32(cwr + (e * 256 + cb * 16) * 4, acc[cb][e]);
         }
         ROW_BAR();
-        // ---- the iteration's one vmcnt wait, in front of the row phase's stores.  The in-order queue holds, oldest first:
-        //   [DMA batch of iteration i - 1: this tile's side input, the next tile's A] [stores of row phase i - 1] [DMA batch of
-        //   iteration i: A of tile i + 2, side of tile i + 1].
-        // Only the first group must have landed: the wait leaves the other two in flight -- 4 rows x (outputs) store instructions
-        // + NDMA + nsd DMA instructions per wave, both uniform.  (Waiting for the previous row phase's stores as well, i.e.
-        // vmcnt(NDMA + nsd), made every iteration as long as a store round trip: ~2 us per 16-row tile, a floor of ~30 us under
-        // the 86 016-row launches whatever their HBM traffic.)  A ragged tile issues fewer stores, but it is the last tile of its
-        // workgroup and the last two iterations drain.
+        // ---- the iteration's one vmcnt wait, in front of the row phase's stores.  Steady state: leave the DMA batch issued at the
+        // top of THIS iteration (A of tile i + 2, side of tile i + 1: NDMA + nsd instructions per wave, uniform) in flight.
+        // LDS-DMA / loads complete in issue order among themselves, so "at most that many operations outstanding" implies that
+        // the previous iteration's batch (this tile's side input, the next tile's A) has landed.
+        // NOT vmcnt(NDMA + nsd + stores of the previous row phase): stores do not complete in order with older loads -- with
+        // that count the wait could pass on completed stores while a piece of the previous batch was still in flight (built in
+        // round 4: same speed, and the full-size reproducibility test caught the race as 1e-6 differences of the loss).
+        // The last two iterations drain.
         if (full) {
-            switch (NDMA + nsd + 4 * nout) {
-#define ROW_W(n_) case n_: asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory"); break;
-                ROW_W(1) ROW_W(2) ROW_W(3) ROW_W(4) ROW_W(5) ROW_W(6) ROW_W(7) ROW_W(8) ROW_W(9) ROW_W(10) ROW_W(11) ROW_W(12)
-                ROW_W(13) ROW_W(14) ROW_W(15) ROW_W(16) ROW_W(17) ROW_W(18) ROW_W(19) ROW_W(20) ROW_W(21) ROW_W(22) ROW_W(23)
-                ROW_W(24) ROW_W(25) ROW_W(26)
-#undef ROW_W
-                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            switch (NDMA + nsd) {
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
             }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -403,6 +402,7 @@ extern "C" int wc_gemm_row_f16(const void* A, long lda, const void* W, long ldw,
     g.ln_g[1] = ln_g1; g.ln_b[1] = ln_b1; g.ln_o[1] = (__half*)ln_o1;
     g.eps = eps;
     g.ntiles = wc_cdiv(M, ROW_TM);
+    // two persistent workgroups per CU (measured at 86 016 x 256 x 256, fp16 out: 35.8 / 29.8 / 34.4 / 34.9 us with 1 / 2 / 3 / 4 per CU)
     const int grid = g.ntiles < 2 * g_row_cus ? g.ntiles : 2 * g_row_cus;
     const bool erf = act == 6 || act == 7;
     const size_t lds = 3 * (size_t)ROW_TM * K * 2 + 3 * ROW_TM * 256 * 4 + 6 * 256 * 4;

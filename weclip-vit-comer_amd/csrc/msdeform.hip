@@ -406,10 +406,12 @@ __global__ __launch_bounds__(256) void msda_absmax_kernel(const GT* __restrict__
 //     order of the bucket, so the result is bit-reproducible, and every element of grad_value is written exactly once
 //     (no atomics on HBM at all).
 // LDS of the bucket kernel: 2 * H_l*W_l ints -> levels up to 16384 pixels.
-// ws (ints): [N*M*S] bucket starts | [N*M*S] bucket sizes | per (image, head, level) Lq*P*4 pair ids.
+// ws (ints): [N*M*S] bucket starts | [N*M*S] bucket sizes | per (image, head, level) Lq*P*4 bucket entries of TWO ints:
+// {row of grad_out = query * M + head, bit pattern of bilinear weight * attention weight}.  (Round 4: the entries were pair ids,
+// and the gather re-derived row and weight from loc / attn with two dependent random loads per pair.)
 #define MSDA_VT 1024
-__global__ __launch_bounds__(MSDA_VT) void msda_bucket_kernel(const float* __restrict__ loc, int* __restrict__ ws, MsdaShapes sh,
-                                                           int S, int Lq, int M, int P, int N) {
+__global__ __launch_bounds__(MSDA_VT) void msda_bucket_kernel(const float* __restrict__ loc, const float* __restrict__ attn,
+                                                           int* __restrict__ ws, MsdaShapes sh, int S, int Lq, int M, int P, int N) {
     extern __shared__ int sm[];
     const int l = blockIdx.x, m = blockIdx.y, n = blockIdx.z;
     const int H = sh.H[l], W = sh.W[l], HW = H * W;
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(MSDA_VT) void msda_bucket_kernel(const float* __res
     const long NMS = (long)N * M * S;
     int* gstart = ws + ((long)n * M + m) * S + sh.start[l];
     int* gsize = gstart + NMS;
-    int* list = ws + 2 * NMS + (((long)n * M + m) * sh.n_levels + l) * nsamp * 4;
+    int* list = ws + 2 * NMS + (((long)n * M + m) * sh.n_levels + l) * nsamp * 8;
     for (int i = tid; i < HW; i += MSDA_VT) { cnt[i] = 0; cur[i] = 0; }
     __syncthreads();
     for (long e = tid; e < nsamp; e += MSDA_VT) {
@@ -461,75 +463,108 @@ __global__ __launch_bounds__(MSDA_VT) void msda_bucket_kernel(const float* __res
         const float x = lb[0] * W - 0.5f, y = lb[1] * H - 0.5f;
         if (!(y > -1.f && x > -1.f && y < H && x < W)) continue;
         const int y0 = (int)floorf(y), x0 = (int)floorf(x);
+        const float lx = x - floorf(x), ly = y - floorf(y);
+        const long qm = ((long)n * Lq + q) * M + m;
+        const float aw = attn[(qm * sh.n_levels + l) * P + p];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int px = x0 + (c & 1), py = y0 + (c >> 1);
             if (px >= 0 && px < W && py >= 0 && py < H) {
                 const int pix = py * W + px;
-                list[cnt[pix] + atomicAdd(&cur[pix], 1)] = (int)(e * 4 + c);
+                const int pos = cnt[pix] + atomicAdd(&cur[pix], 1);
+                const float wgt = ((c & 1) ? lx : 1.f - lx) * ((c >> 1) ? ly : 1.f - ly) * aw;
+                *reinterpret_cast<int2*>(list + 2 * (long)pos) = make_int2((int)qm, __float_as_int(wgt));
             }
         }
     }
 }
 
-// grid: ceil(S / (256 / D)) x M x N workgroups of 256 threads = 256 / D pixels x D channels
+// grid: ceil(S / (256 / D)) x M x N workgroups of 256 threads = 256 / D pixels x D lanes.
+// The D lanes of a pixel work as SL = 16 / sizeof(GT) pair SLOTS of CL = D / SL lanes: a slot fetches one pair's grad_out row
+// (D values) as 16 bytes per lane, so a wave instruction moves SL rows per pixel group -- 512 B per 32 lanes at fp16 -- where
+// the round-3 form (one value per lane, one pair per group and instruction) moved 64 B; the bucket entries already hold the
+// row and the weight (no dependent loads).  A lane accumulates its 16 / sizeof(GT) channels over its slot's pairs in 64-bit
+// FIXED POINT (2^40 / max|grad_out|); the SL slots are added at the end -- integer sums, so the result does not depend on the
+// bucket order or on the slot a pair falls into (bit-reproducible, and bit-identical to the round-3 kernel).
 template <typename GT>
-__global__ __launch_bounds__(256) void msda_gather_kernel(const float* __restrict__ loc, const float* __restrict__ attn,
-                                                           const GT* __restrict__ gout, const unsigned int* __restrict__ gmax,
+__global__ __launch_bounds__(256) void msda_gather_kernel(const GT* __restrict__ gout, const unsigned int* __restrict__ gmax,
                                                            const int* __restrict__ ws, float* __restrict__ gvalue,
                                                            __half* __restrict__ gvalue16, MsdaShapes sh,
                                                            int S, int Lq, int M, int D, int P, int N) {
+    constexpr int VEC = 16 / sizeof(GT);                 // channels per lane = pair slots per pixel group
     const int m = blockIdx.y, n = blockIdx.z;
     const int grp = threadIdx.x / D, d = threadIdx.x - grp * D;
     const int s = blockIdx.x * (256 / D) + grp;              // pixel index over all levels
-    if (s >= S) return;
+    if (s >= S) return;                                      // (a whole group leaves together: D divides 64)
+    const int CL = D / VEC;                                  // lanes per pair
+    const int slot = d / CL, ch = (d - slot * CL) * VEC;     // this lane's pair slot and first channel
     int l = 0;
     while (l + 1 < sh.n_levels && s >= sh.start[l + 1]) ++l;
-    const int H = sh.H[l], W = sh.W[l];
     const long nsamp = (long)Lq * P;
     const long NMS = (long)N * M * S;
     const long pm = ((long)n * M + m) * S + s;
     const int b0 = ws[pm], nb = ws[NMS + pm];
-    const int* list = ws + 2 * NMS + (((long)n * M + m) * sh.n_levels + l) * nsamp * 4 + b0;
+    const int2* list = reinterpret_cast<const int2*>(ws + 2 * NMS + (((long)n * M + m) * sh.n_levels + l) * nsamp * 8) + b0;
     const float gm = __uint_as_float(*gmax);
     const float scale = gm > 0.f ? 1099511627776.0f / gm : 0.f;       // 2^40 / max|gout|
-    // The D lanes of the pixel's group work in two roles: lane j first prepares pair j of the next D pairs of the bucket
-    // (id, bilinear weight * attention weight, row of grad_out -- three dependent loads done ONCE, D pairs in parallel),
-    // then every lane, as channel d, adds the D pairs' contributions with the rows' addresses broadcast by shuffles: the
-    // D loads of grad_out are independent of one another and stay in flight together.
-    long long acc = 0;
+    long long acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0;
     for (int k0 = 0; k0 < nb; k0 += D) {
+        // lane j holds entry k0 + j of the bucket (coalesced 8-byte reads); rows / weights travel to their slots by shuffles
+        int rowj = 0;
         float wj = 0.f;
-        long rowj = 0;
         if (k0 + d < nb) {
-            const int id = list[k0 + d];
-            const int c = id & 3;
-            const long e = id >> 2;
-            const int q = (int)(e / P), p = (int)(e - (long)q * P);
-            const long qm = ((long)n * Lq + q) * M + m;
-            const float* lb = loc + (qm * sh.n_levels + l) * P * 2 + p * 2;
-            const float x = lb[0] * W - 0.5f, y = lb[1] * H - 0.5f;
-            const float lx = x - floorf(x), ly = y - floorf(y);
-            wj = ((c & 1) ? lx : 1.f - lx) * ((c >> 1) ? ly : 1.f - ly) * attn[(qm * sh.n_levels + l) * P + p] * scale;
-            rowj = qm * D;
+            const int2 e = list[k0 + d];
+            rowj = e.x;
+            wj = __int_as_float(e.y) * scale;
         }
         const int cntk = min(D, nb - k0);
-        for (int k = 0; k < cntk; k += 4) {
-            float gk[4], wk[4];
+        for (int k = 0; k < cntk; k += 4 * VEC) {            // 4 rounds of SL pairs: four 16-byte loads in flight per lane
+            GT gk[4][VEC];
+            float wk[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int kk = k + u < cntk ? k + u : k;                    // (clamped: the weight of a padded slot is zeroed below)
-                const long row = __shfl(rowj, kk, D);
-                wk[u] = k + u < cntk ? __shfl(wj, kk, D) : 0.f;
-                gk[u] = (float)gout[row + d];
+                const int kk = k + u * VEC + slot;
+                const int kc = kk < cntk ? kk : 0;            // (clamped: the weight of a padded slot is zeroed)
+                const long row = (long)__shfl(rowj, kc, D) * D;
+                wk[u] = kk < cntk ? __shfl(wj, kc, D) : 0.f;
+                *reinterpret_cast<u32x4*>(gk[u]) = *reinterpret_cast<const u32x4*>(gout + row + ch);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc += (long long)rintf(gk[u] * wk[u]);
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] += (long long)rintf((float)gk[u][v] * wk[u]);
         }
     }
-    const float gvv = gm > 0.f ? (float)acc * (gm / 1099511627776.0f) : 0.f;
-    if (gvalue) gvalue[(((long)n * S + s) * M + m) * D + d] = gvv;
-    if (gvalue16) gvalue16[(((long)n * S + s) * M + m) * D + d] = __float2half(gvv);      // the value projection's gradient operand
+    // add the SL slots: lanes d, d + CL, d + 2 CL, ... hold the same channels
+    for (int o = CL; o < D; o <<= 1) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const int lo = __shfl_xor((int)(acc[v] & 0xffffffffLL), o, D);
+            const int hi = __shfl_xor((int)(acc[v] >> 32), o, D);
+            acc[v] += ((long long)hi << 32) | (unsigned int)lo;
+        }
+    }
+    if (slot == 0) {
+        const float inv = gm > 0.f ? gm / 1099511627776.0f : 0.f;
+        const long o = (((long)n * S + s) * M + m) * D + ch;
+        float gv[VEC];
+        __half hv[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            gv[v] = gm > 0.f ? (float)acc[v] * inv : 0.f;
+            hv[v] = __float2half(gv[v]);
+        }
+        if (gvalue) {
+#pragma unroll
+            for (int v = 0; v < VEC; v += 4) *reinterpret_cast<float4*>(gvalue + o + v) = make_float4(gv[v], gv[v + 1], gv[v + 2], gv[v + 3]);
+        }
+        if (gvalue16) {      // the value projection's gradient operand
+            if constexpr (VEC == 8) *reinterpret_cast<u32x4*>(gvalue16 + o) = *reinterpret_cast<u32x4*>(hv);
+            else *reinterpret_cast<u32x2*>(gvalue16 + o) = *reinterpret_cast<u32x2*>(hv);
+        }
+    }
 }
 
 static int fill_shapes(MsdaShapes* sh, const int* h_shapes, int n_levels, int* S) {
@@ -609,22 +644,24 @@ static int msda_bwd_value(const float* loc, const float* attn, const GT* gout, f
     int maxhw = 0;
     for (int l = 0; l < n_levels; ++l) maxhw = sh.H[l] * sh.W[l] > maxhw ? sh.H[l] * sh.W[l] : maxhw;
     WC_CHECK_ARG(maxhw <= 16384 && ws, "wc_msda_bwd: a level may have at most 16384 pixels; ws workspace missing");
+    WC_CHECK_ARG(((uintptr_t)gout | (uintptr_t)gvalue | (uintptr_t)gvalue16 | (uintptr_t)ws) % 16 == 0 && D % (16 / (int)sizeof(GT)) == 0,
+                 "wc_msda_bwd: grad_out / grad_value / ws must be 16-byte aligned (16-byte gathers)");
     static bool attr_set = false;
     if (!attr_set) {
         WC_CHECK_ARG(hipFuncSetAttribute((const void*)msda_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess,
                      "wc_msda_bwd: cannot reserve 128 KiB of LDS");
         attr_set = true;
     }
-    hipLaunchKernelGGL(msda_bucket_kernel, dim3(n_levels, M, N), dim3(MSDA_VT), (size_t)maxhw * 2 * sizeof(int), st, loc, (int*)ws, sh,
-                       S, Lq, M, P, N);
+    hipLaunchKernelGGL(msda_bucket_kernel, dim3(n_levels, M, N), dim3(MSDA_VT), (size_t)maxhw * 2 * sizeof(int), st, loc, attn, (int*)ws,
+                       sh, S, Lq, M, P, N);
     WC_LAUNCH_CHECK("msda_bucket_kernel");
     const int prg = wc_prof_begin(st);
-    hipLaunchKernelGGL(msda_gather_kernel<GT>, dim3(wc_cdiv(S, 256 / D), M, N), dim3(256), 0, st, loc, attn, gout,
+    hipLaunchKernelGGL(msda_gather_kernel<GT>, dim3(wc_cdiv(S, 256 / D), M, N), dim3(256), 0, st, gout,
                        (const unsigned int*)gmax, (const int*)ws, gvalue, (__half*)gvalue16, sh, S, Lq, M, D, P, N);
     // one dh-row of the output gradient per (sample, corner) pair (all corners inside: the upper bound) + the pair id, its
     // location / weight (12 B) + the value-gradient rows written
     wc_prof_end2(prg, "msda_gather_kernel", 0.0,
-                 (double)N * Lq * M * n_levels * P * 4 * ((double)D * sizeof(GT) + 16) +
+                 (double)N * Lq * M * n_levels * P * 4 * ((double)D * sizeof(GT) + 8) +
                      (double)N * S * M * D * ((gvalue ? 4 : 0) + (gvalue16 ? 2 : 0)), st);
     WC_LAUNCH_CHECK("msda_gather_kernel");
     return WC_OK;

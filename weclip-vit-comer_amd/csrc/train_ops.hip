@@ -78,22 +78,28 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
 // (few rows per wave = many waves: the three dependent wave reductions per row are latency, hidden by occupancy).
 #define LNB_ROWS 4
 template <int NV>   // D <= 64*NV
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const __half* __restrict__ dy16,
+                                                      const float* __restrict__ x,
                                                       const float* __restrict__ w, const float* __restrict__ add,
                                                       float eps, float* __restrict__ dx32, __half* __restrict__ dx16,
-                                                      float out_scale, float* __restrict__ part, long rows, int D) {
+                                                      float out_scale, float* __restrict__ part, long rows, int D, long ngroups) {
     extern __shared__ float sm[];   // [4][2][D]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float ag[NV], ab[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) ag[i] = ab[i] = 0.f;
-    // the LNB_ROWS rows of a wave are processed TOGETHER: all their loads in flight at once and their four reduction
-    // chains interleaved (the row-after-row loop exposed one load latency and four shuffle chains per row: 29 us for
-    // 16 384 x 256 at two waves per SIMD)
-    const long r0 = ((long)blockIdx.x * 4 + wv) * LNB_ROWS;
     // slot i of a lane = element ((i >> 2) * 64 + lane) * 4 + (i & 3): four consecutive elements per lane, 16-byte IO
     // (D % 4 == 0, so a group of four slots is inside the row or outside it as a whole)
 #define LN_E(i_) ((((i_) >> 2) * 64 + lane) * 4 + ((i_) & 3))
+    // A block walks its groups of 16 rows (grid-stride): the dgamma / dbeta partial sums stay in registers over all of them, so
+    // the partial-sum matrix the final column reduction reads has gridDim.x rows instead of rows / 16 (86 016 rows: 11 MB ->
+    // 2 MB; colsum_final 19.8 -> ~6 us).  dy may arrive as fp16 (dy16: the producing GEMM then writes and this kernel reads
+    // half the bytes).
+    for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    // the LNB_ROWS rows of a wave are processed TOGETHER: all their loads in flight at once and their four reduction
+    // chains interleaved (the row-after-row loop exposed one load latency and four shuffle chains per row: 29 us for
+    // 16 384 x 256 at two waves per SIMD)
+    const long r0 = (grp * 4 + wv) * LNB_ROWS;
     float xv[LNB_ROWS][NV], dv[LNB_ROWS][NV], s[LNB_ROWS];
     bool live[LNB_ROWS];
 #pragma unroll
@@ -101,7 +107,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         live[r] = r0 + r < rows;
         const long row = live[r] ? r0 + r : rows - 1;
         const float* xr = x + row * D;
-        const float* dr = dy + row * D;
         s[r] = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; i += 4) {
@@ -109,7 +114,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), da = xa;
             if (e < D) {
                 xa = *reinterpret_cast<const float4*>(xr + e);
-                if (live[r]) da = *reinterpret_cast<const float4*>(dr + e);
+                if (live[r]) {
+                    if (dy16) {
+                        const uint2 hq = *reinterpret_cast<const uint2*>(dy16 + row * D + e);
+                        const __half* hp = reinterpret_cast<const __half*>(&hq);
+                        da = make_float4(__half2float(hp[0]), __half2float(hp[1]), __half2float(hp[2]), __half2float(hp[3]));
+                    } else {
+                        da = *reinterpret_cast<const float4*>(dy + row * D + e);
+                    }
+                }
             }
             xv[r][i] = xa.x; xv[r][i + 1] = xa.y; xv[r][i + 2] = xa.z; xv[r][i + 3] = xa.w;
             dv[r][i] = da.x; dv[r][i + 1] = da.y; dv[r][i + 2] = da.z; dv[r][i + 3] = da.w;
@@ -188,6 +201,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             }
         }
     }
+    }      // groups of this block
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int e = LN_E(i);
@@ -359,22 +373,42 @@ extern "C" int wc_colsum(const void* src, int src_f32, long ld, float* part, flo
 }
 
 // part: workspace ceil(rows/16)*2*D floats; dgb (2,D) = alpha * [dgamma ; dbeta].
+static int layernorm_bwd_impl(const float* dy, const void* dy16, const float* x, const float* w, const float* add, float eps,
+                              float* dx32, void* dx16, float out_scale, float* part, float* dgb, float alpha,
+                              long rows, int D, void* stream);
+
 extern "C" int wc_layernorm_bwd(const float* dy, const float* x, const float* w, const float* add, float eps,
                                 float* dx32, void* dx16, float out_scale, float* part, float* dgb, float alpha,
                                 long rows, int D, void* stream) {
-    WC_CHECK_ARG(dy && x && w && part && dgb && rows > 0 && D > 0 && D <= 1024 && D % 4 == 0 && (dx32 || dx16),
+    WC_CHECK_ARG(dy, "wc_layernorm_bwd: bad argument (dy)");
+    return layernorm_bwd_impl(dy, nullptr, x, w, add, eps, dx32, dx16, out_scale, part, dgb, alpha, rows, D, stream);
+}
+
+// the same with the incoming gradient as fp16 rows (dy16 (rows, D)): the producing GEMM writes, and this kernel reads, half the bytes
+extern "C" int wc_layernorm_bwd_h(const void* dy16, const float* x, const float* w, const float* add, float eps,
+                                  float* dx32, void* dx16, float out_scale, float* part, float* dgb, float alpha,
+                                  long rows, int D, void* stream) {
+    WC_CHECK_ARG(dy16 && (uintptr_t)dy16 % 8 == 0, "wc_layernorm_bwd_h: bad argument (dy16)");
+    return layernorm_bwd_impl(nullptr, dy16, x, w, add, eps, dx32, dx16, out_scale, part, dgb, alpha, rows, D, stream);
+}
+
+static int layernorm_bwd_impl(const float* dy, const void* dy16, const float* x, const float* w, const float* add, float eps,
+                              float* dx32, void* dx16, float out_scale, float* part, float* dgb, float alpha,
+                              long rows, int D, void* stream) {
+    WC_CHECK_ARG(x && w && part && dgb && rows > 0 && D > 0 && D <= 1024 && D % 4 == 0 && (dx32 || dx16),
                  "wc_layernorm_bwd: bad argument (D <= 1024, D %% 4 == 0)");
     WC_CHECK_ARG(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)w | (uintptr_t)add | (uintptr_t)dx32) % 16 == 0 && (uintptr_t)dx16 % 8 == 0,
                  "wc_layernorm_bwd: operands must be 16-byte aligned");
-    const int nblk = wc_cdiv(rows, 4 * LNB_ROWS);
+    const long ngroups = (rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS);
+    const int nblk = ngroups < 2048 ? (int)ngroups : 2048;      // (8 blocks per CU; the workspace holds >= ngroups rows)
     hipStream_t st = (hipStream_t)stream;
     const size_t sm = 8 * (size_t)D * sizeof(float);
     if (D <= 256)
-        hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nblk), dim3(256), sm, st, dy, x, w, add, eps, dx32, (__half*)dx16,
-                           out_scale, part, rows, D);
+        hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nblk), dim3(256), sm, st, dy, (const __half*)dy16, x, w, add, eps, dx32, (__half*)dx16,
+                           out_scale, part, rows, D, ngroups);
     else
-        hipLaunchKernelGGL(ln_bwd_kernel<16>, dim3(nblk), dim3(256), sm, st, dy, x, w, add, eps, dx32, (__half*)dx16,
-                           out_scale, part, rows, D);
+        hipLaunchKernelGGL(ln_bwd_kernel<16>, dim3(nblk), dim3(256), sm, st, dy, (const __half*)dy16, x, w, add, eps, dx32, (__half*)dx16,
+                           out_scale, part, rows, D, ngroups);
     WC_LAUNCH_CHECK("ln_bwd_kernel");
     hipLaunchKernelGGL(colsum_final_kernel, dim3(wc_cdiv(2 * D, 64)), dim3(1024), 0, st, part, dgb, nblk, 2 * D, alpha, 0);
     WC_LAUNCH_CHECK("colsum_final_kernel");

@@ -227,7 +227,7 @@ class HeadEngine:
         per = ns * N_ * (K_ + 1)
         for g in range(groups):
             self._pending.append((part, part.data_ptr() + 4 * g * per, gw.data_ptr() + 4 * g * sw, gb.data_ptr() + 4 * g * sb,
-                                  ns, N_, K_, abits))
+                                  ns, N_, K_, abits, 0))
 
     def _flush_reductions(self):
         jobs = self._pending

@@ -254,9 +254,9 @@ def layernorm_bwd(dy, x, w, *, add=None, want32=True, want16=False, out_scale=1.
     part = torch.empty(((rows + 15) // 16) * 2 * D, device=dev, dtype=F32)
     if dgb is None:
         dgb = torch.empty(2, D, device=dev, dtype=F32)
-    L.lib().wc_layernorm_bwd(L.ptr(dy, F32, "dy"), L.ptr(x, F32, "x"), L.ptr(w, F32, "w"), L.ptr(add, F32, "add"), eps,
-                             L.ptr(dx32), L.ptr(dx16), float(out_scale), L.ptr(part), L.ptr(dgb), float(alpha), rows,
-                             D, L.stream())
+    fn = L.lib().wc_layernorm_bwd_h if dy.dtype == F16 else L.lib().wc_layernorm_bwd      # dy may arrive as fp16 rows
+    fn(L.ptr(dy, dy.dtype, "dy"), L.ptr(x, F32, "x"), L.ptr(w, F32, "w"), L.ptr(add, F32, "add"), eps,
+       L.ptr(dx32), L.ptr(dx16), float(out_scale), L.ptr(part), L.ptr(dgb), float(alpha), rows, D, L.stream())
     return dx32, dx16, dgb
 
 
