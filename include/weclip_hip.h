@@ -177,6 +177,14 @@ int wc_gemm_row_f16(const void* A, long lda, const void* W, long ldw, int M, int
                     float* C32, void* C16, float* P32, long ldc, long ldc16, const float* ln_g0, const float* ln_b0, void* ln_o0,
                     const float* ln_g1, const float* ln_b1, void* ln_o1, float eps, void* stream);
 
+/* `groups` products of one shape in one launch of the row-streaming kernel (the eleven adapter MLPs' second Linear and its input
+ * gradient, WeCLIP_model/segformer_head.py:22-28,69-80): group i reads A + i*gA, W + i*gW, bias + i*gB, auxh + i*gX and writes
+ * C32 / C16 + i*gC (element offsets; e.g. gC = 256 with ldc16 = 11*256 drops every adapter's output into its column slice of the
+ * fuse input).  act 0 | 2 | 5. */
+int wc_gemm_row_f16_grouped(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias, int act,
+                            const void* auxh, long ldaux, float* C32, void* C16, long ldc, long ldc16, int groups, long gA,
+                            long gW, long gB, long gC, long gX, void* stream);
+
 /* Which kernel wc_gemm_f16 runs for a shape (for profiling / roofline bookkeeping only):
  * 0 = 128x128x64 kernel, 1 = 256x256x64 ping-pong kernel, 2 = ping-pong kernel + 128x128 kernel on the ragged
  * last M % 256 rows (two launches). */

@@ -335,3 +335,25 @@ def test_gemm_row_kernel_every_epilogue(ops, M, N, K):
     o2 = z32()
     ops.gemm_row(a, w, M, N, K, out32=o2)
     assert torch.equal(o2, o32)
+
+
+def test_gemm_row_grouped_matches_per_group_products(ops):
+    """wc_gemm_row_f16_grouped (the eleven adapters' second Linear and its input gradient in one launch each): every group against
+    the fp64 product of its own operands -- outputs dropped into column slices of a wider buffer (forward), ReLU' from the saved
+    fp16 activations with the A operand read from column slices (backward)."""
+    G, M, E = 5, 4100, 256
+    g = torch.Generator().manual_seed(7)
+    t1 = torch.randn(G, M, E, generator=g).half().cuda()
+    w = (torch.randn(G, E, E, generator=g) * 0.06).half().cuda()
+    b = torch.randn(G, E, generator=g).cuda()
+    cat = torch.zeros(M, G * E, device="cuda", dtype=torch.float16)
+    ops.gemm_row_grouped(t1, w, M, E, E, G, bias=b, out16=cat, ldc16=G * E, gA=M * E, gW=E * E, gB=E, gC=E)
+    for i in range(G):
+        ref = t1[i].double().cpu() @ w[i].double().cpu().t() + b[i].double().cpu()
+        assert _rel(cat[:, i * E:(i + 1) * E].float().cpu().double(), ref) < 1e-3, i
+    dcat = torch.randn(M, G * E, generator=g).half().cuda()
+    dt1 = torch.zeros(G, M, E, device="cuda", dtype=torch.float16)
+    ops.gemm_row_grouped(dcat, w, M, E, E, G, lda=G * E, out16=dt1, act=5, auxh=t1, ldaux=E, gA=E, gW=E * E, gC=M * E, gX=M * E)
+    for i in range(G):
+        ref = (dcat[:, i * E:(i + 1) * E].double().cpu() @ w[i].double().cpu().t()) * (t1[i].double().cpu() > 0)
+        assert _rel(dt1[i].float().cpu().double(), ref) < 1e-3, i

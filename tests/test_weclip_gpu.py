@@ -205,9 +205,10 @@ def test_train_step_bucket_gradients_match_autograd_path():
 
 @pytest.mark.parametrize("precision", ["fast", "exact"])
 def test_grouped_adapter_launches_equal_per_adapter_launches(monkeypatch, precision):
-    """The adapters run as grouped GEMM launches (wc_gemm_f16_grouped: all blocks x images in one launch) when the
-    encoder stacked its fp16 block outputs; same tiles and accumulation order, so loss and every gradient must be
-    bit-identical to the per-adapter launches."""
+    """The adapters run as grouped GEMM launches (all blocks x images in one launch) when the encoder stacked its fp16 block
+    outputs.  `exact`: wc_gemm_f16_grouped, same tiles and accumulation order as the per-adapter launches: loss and every
+    non-adapter gradient bit-identical.  `fast` (round 4): the second Linear and its input gradient run on the row-streaming
+    kernel (wc_gemm_row_f16_grouped: v_mfma_f32_16x16x32_f16, another fp32 summation order): equal to fp32 rounding."""
     from weclip_vit_comer_amd import config
     from weclip_vit_comer_amd.train_step import TrainStep
     img = synth.make_images(3, H, W, seed=5).cuda()
@@ -223,6 +224,14 @@ def test_grouped_adapter_launches_equal_per_adapter_launches(monkeypatch, precis
         return real_gemm(*a, **kw)
 
     monkeypatch.setattr(HE.ops, "gemm", spy)
+    real_row = HE.ops.gemm_row_grouped
+    row_calls = []
+
+    def spy_row(*a, **kw):
+        row_calls.append(a[5])
+        return real_row(*a, **kw)
+
+    monkeypatch.setattr(HE.ops, "gemm_row_grouped", spy_row)
 
     def run(grouped):
         monkeypatch.setenv("WECLIP_GROUPED_ADAPTERS", "1" if grouped else "0")
@@ -249,17 +258,24 @@ def test_grouped_adapter_launches_equal_per_adapter_launches(monkeypatch, precis
 
     monkeypatch.setattr(HE.ops, "wgrad_partials", spy_wg)
     l0, g0, _ = run(False)
-    assert not grouped_calls and not grouped_wg
+    assert not grouped_calls and not grouped_wg and not row_calls
     l1, g1, is_adapter = run(True)
-    assert len(grouped_calls) == 3          # proj (blocks x images), proj_2 and the ReLU-backward GEMM (blocks)
+    # proj (blocks x images), proj_2 and the ReLU-backward GEMM (blocks): the last two on the row-streaming kernel in `fast`
+    assert (len(grouped_calls), len(row_calls)) == ((3, 0) if precision == "exact" else (1, 2)), (grouped_calls, row_calls)
     assert len(grouped_wg) == 2             # the proj and proj_2 weight gradients of all blocks
-    assert l0 == l1 and g0.abs().max().item() > 0
-    # forward / dX launches: same tiles and accumulation order -> bit-identical; the grouped weight gradients split the
-    # tokens into fewer slices than the per-adapter launches (another fp32 summation order)
+    assert g0.abs().max().item() > 0
+    # the grouped weight gradients split the tokens into fewer slices than the per-adapter launches (another fp32 summation order)
     assert is_adapter.any() and not is_adapter.all()
-    assert torch.equal(g0[~is_adapter], g1[~is_adapter])
+    if precision == "exact":       # forward / dX launches: same tiles and accumulation order -> bit-identical
+        assert l0 == l1
+        assert torch.equal(g0[~is_adapter], g1[~is_adapter])
+    else:
+        assert abs(l0 - l1) <= 2e-5 * abs(l0), (l0, l1)
+        rest = (g0 - g1)[~is_adapter].abs().max().item()
+        assert rest <= 1e-3 * g0[~is_adapter].abs().max().item(), rest
     err = (g0 - g1)[is_adapter].abs().max().item()
-    assert err <= 2e-5 * g0[is_adapter].abs().max().item(), err
+    # (`fast`: an fp16 output of the row kernel may land one fp16 ulp from the tile kernel's)
+    assert err <= (2e-5 if precision == "exact" else 1e-3) * g0[is_adapter].abs().max().item(), err
 
 
 @pytest.mark.parametrize("hw,labels", [((80, 112), [[1], [2, 5, 9], [0, 3]]), ((48, 64), [[4, 11, 17, 19]])])

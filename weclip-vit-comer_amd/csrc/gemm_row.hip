@@ -50,6 +50,11 @@ struct RowArgs {
     __half* ln_o[2];
     float eps;
     int ntiles;
+    // grouped launch: `groups` products of one shape (the eleven adapters of WeCLIP_model/segformer_head.py:69-80); group i reads
+    // A + i*gA, W + i*gW, bias + i*gB, the side input + i*gX and writes its outputs at + i*gC (all in elements); `wpg`
+    // persistent workgroups per group (blockIdx.x = group * wpg + member)
+    int groups, wpg;
+    long gA, gW, gB, gC, gX;
 };
 
 #define ROW_TM 16
@@ -85,8 +90,19 @@ __global__ __launch_bounds__(256, 2) void gemm_row_kernel(RowArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, q16 = lane >> 4;
-    const int G = gridDim.x;
-    const int nmy = (g.ntiles - (int)blockIdx.x + G - 1) / G;
+    const int G = g.wpg;                                     // workgroups walking this group's tiles
+    const int grp = __builtin_amdgcn_readfirstlane((int)blockIdx.x / g.wpg);
+    const int wg0 = (int)blockIdx.x - grp * g.wpg;           // this workgroup's first tile
+    const int nmy = (g.ntiles - wg0 + G - 1) / G;
+    g.A += (long)grp * g.gA;
+    g.W += (long)grp * g.gW;
+    if (g.bias) g.bias += (long)grp * g.gB;
+    if (g.C32) g.C32 += (long)grp * g.gC;
+    if (g.C16) g.C16 += (long)grp * g.gC;
+    if (g.P32) g.P32 += (long)grp * g.gC;
+    if (g.resid) g.resid += (long)grp * g.gX;
+    if (g.aux) g.aux += (long)grp * g.gX;
+    if (g.auxh) g.auxh += (long)grp * g.gX;
     const int act = g.act;
     // the ONE side input of the launch (checked by the host): fp32 rows (the residual, or the saved pre-activation of act 7)
     // or fp16 rows (the saved output of act 5); it arrives by LDS-DMA like A, as a dense [16][N] image, so that the row phase
@@ -132,8 +148,8 @@ __global__ __launch_bounds__(256, 2) void gemm_row_kernel(RowArgs g) {
             }                                                                                                     \
         }                                                                                                         \
     }
-    if (nmy > 0) { ROW_DMA_A(blockIdx.x, 0); ROW_DMA_S(blockIdx.x, 0); }
-    if (nmy > 1) ROW_DMA_A(blockIdx.x + G, 1);
+    if (nmy > 0) { ROW_DMA_A(wg0, 0); ROW_DMA_S(wg0, 0); }
+    if (nmy > 1) ROW_DMA_A(wg0 + G, 1);
 
     // stationary weights: B fragments (16 columns x 32 k: lane = column l15, k group q16) of this wave's 64 columns, whole K
     const int cw = wave * 64;
@@ -172,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void gemm_row_kernel(RowArgs g) {
     const unsigned ctc = lbase + CT0 + c4 * 4;
     int sa = 0;                                        // A slot of tile i (i % 3)
     for (int i = 0; i < nmy; ++i) {
-        const int t = blockIdx.x + i * G;
+        const int t = wg0 + i * G;
         const int ss = i & 1;
         ROW_BAR();                                   // tile i (A and side) is in LDS for all waves; the C tile and the slots refilled below are free
         const bool full = i + 2 < nmy;
@@ -368,10 +384,34 @@ extern "C" int wc_gemm_row_supported(int M, int N, int K) {
     return (M > 0 && N > 0 && N <= 256 && N % 4 == 0 && (K == 128 || K == 256)) ? 1 : 0;
 }
 
+static int gemm_row_impl(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias,
+                         const float* cscale, int act, const float* aux, const void* auxh, long ldaux, const float* resid,
+                         long ldr, float* C32, void* C16, float* P32, long ldc, long ldc16, const float* ln_g0, const float* ln_b0,
+                         void* ln_o0, const float* ln_g1, const float* ln_b1, void* ln_o1, float eps, int groups, long gA, long gW,
+                         long gB, long gC, long gX, void* stream);
+
 extern "C" int wc_gemm_row_f16(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias,
                                const float* cscale, int act, const float* aux, const void* auxh, long ldaux, const float* resid,
                                long ldr, float* C32, void* C16, float* P32, long ldc, long ldc16, const float* ln_g0, const float* ln_b0,
                                void* ln_o0, const float* ln_g1, const float* ln_b1, void* ln_o1, float eps, void* stream) {
+    return gemm_row_impl(A, lda, W, ldw, M, N, K, bias, cscale, act, aux, auxh, ldaux, resid, ldr, C32, C16, P32, ldc, ldc16, ln_g0,
+                         ln_b0, ln_o0, ln_g1, ln_b1, ln_o1, eps, 1, 0, 0, 0, 0, 0, stream);
+}
+
+extern "C" int wc_gemm_row_f16_grouped(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias,
+                                       int act, const void* auxh, long ldaux, float* C32, void* C16, long ldc, long ldc16, int groups,
+                                       long gA, long gW, long gB, long gC, long gX, void* stream) {
+    WC_CHECK_ARG(groups >= 1 && groups <= 256 && gA % 8 == 0 && gW % 8 == 0 && gB % 4 == 0 && gC % 4 == 0 && gX % 8 == 0,
+                 "wc_gemm_row_f16_grouped: 1..256 groups, group strides that keep every row 16-byte aligned");
+    return gemm_row_impl(A, lda, W, ldw, M, N, K, bias, nullptr, act, nullptr, auxh, ldaux, nullptr, 0, C32, C16, nullptr, ldc, ldc16,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1e-5f, groups, gA, gW, gB, gC, gX, stream);
+}
+
+static int gemm_row_impl(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias,
+                         const float* cscale, int act, const float* aux, const void* auxh, long ldaux, const float* resid,
+                         long ldr, float* C32, void* C16, float* P32, long ldc, long ldc16, const float* ln_g0, const float* ln_b0,
+                         void* ln_o0, const float* ln_g1, const float* ln_b1, void* ln_o1, float eps, int groups, long gA, long gW,
+                         long gB, long gC, long gX, void* stream) {
     WC_CHECK_ARG(A && W && wc_gemm_row_supported(M, N, K), "wc_gemm_row_f16: need N <= 256, N %% 4 == 0, K = 128 | 256 (got M=%d N=%d K=%d)", M, N, K);
     WC_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K && ((uintptr_t)A | (uintptr_t)W) % 16 == 0,
                  "wc_gemm_row_f16: operand rows must be 16-byte aligned");
@@ -402,8 +442,14 @@ extern "C" int wc_gemm_row_f16(const void* A, long lda, const void* W, long ldw,
     g.ln_g[1] = ln_g1; g.ln_b[1] = ln_b1; g.ln_o[1] = (__half*)ln_o1;
     g.eps = eps;
     g.ntiles = wc_cdiv(M, ROW_TM);
-    // two persistent workgroups per CU (measured at 86 016 x 256 x 256, fp16 out: 35.8 / 29.8 / 34.4 / 34.9 us with 1 / 2 / 3 / 4 per CU)
-    const int grid = g.ntiles < 2 * g_row_cus ? g.ntiles : 2 * g_row_cus;
+    g.groups = groups; g.gA = gA; g.gW = gW; g.gB = gB; g.gC = gC; g.gX = gX;
+    // two persistent workgroups per CU (measured at 86 016 x 256 x 256, fp16 out: 35.8 / 29.8 / 34.4 / 34.9 us with 1 / 2 / 3 / 4 per CU),
+    // dealt evenly over the groups
+    int wpg = 2 * g_row_cus / groups;
+    if (wpg < 1) wpg = 1;
+    if (wpg > g.ntiles) wpg = g.ntiles;
+    g.wpg = wpg;
+    const int grid = wpg * groups;
     const bool erf = act == 6 || act == 7;
     const size_t lds = 3 * (size_t)ROW_TM * K * 2 + 3 * ROW_TM * 256 * 4 + 6 * 256 * 4;
     const int pr = wc_prof_begin(stream);
@@ -415,12 +461,12 @@ extern "C" int wc_gemm_row_f16(const void* A, long lda, const void* W, long ldw,
         if (erf) hipLaunchKernelGGL((gemm_row_kernel<2, true>), dim3(grid), dim3(256), lds, (hipStream_t)stream, g);
         else hipLaunchKernelGGL((gemm_row_kernel<2, false>), dim3(grid), dim3(256), lds, (hipStream_t)stream, g);
     }
-    shape_log_end(sl, "row", M, N, K, 1, 1, 9, act, stream);
+    shape_log_end(sl, "row", M, N, K, 1, groups, 9, act, stream);
     // algorithmic bytes: A once, the side input once, every output once
-    const double nb = (double)M * K * 2 + (double)M * N * ((resid || act == 7 ? 4 : 0) + (act == 5 ? 2 : 0) + (C32 ? 4 : 0) + (P32 ? 4 : 0) +
+    const double nb = (double)groups * M * K * 2 + (double)groups * M * N * ((resid || act == 7 ? 4 : 0) + (act == 5 ? 2 : 0) + (C32 ? 4 : 0) + (P32 ? 4 : 0) +
                                                            (C16 ? 2 : 0) + (ln_o0 ? 2 : 0) + (ln_o1 ? 2 : 0));
     wc_prof_end2(pr, K == 256 ? (erf ? "gemm_row_kernel<4, true>" : "gemm_row_kernel<4, false>")
-                              : (erf ? "gemm_row_kernel<2, true>" : "gemm_row_kernel<2, false>"), 2.0 * M * N * K, nb, stream);
+                              : (erf ? "gemm_row_kernel<2, true>" : "gemm_row_kernel<2, false>"), 2.0 * groups * M * N * K, nb, stream);
     WC_LAUNCH_CHECK("gemm_row_kernel");
     return WC_OK;
 }

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void msda_absmax_kernel(const GT* __restrict__
 //     pass 2  writes every pair's id into its pixel's bucket (the order inside a bucket depends on the wave scheduling);
 //   msda_gather_kernel (one group of D lanes per pixel, all pixels of all levels / heads / images in parallel):
 //     walks the pixel's bucket, recomputes the bilinear weight of each pair and accumulates
-//     attn * weight * grad_out[q, m, d] in 64-bit FIXED POINT (2^40 / max|grad_out|): integer sums do not depend on the
+//     attn * weight * grad_out[q, m, d] in 64-bit FIXED POINT (2^24 / max|grad_out| per product): integer sums do not depend on the
 //     order of the bucket, so the result is bit-reproducible, and every element of grad_value is written exactly once
 //     (no atomics on HBM at all).
 // LDS of the bucket kernel: 2 * H_l*W_l ints -> levels up to 16384 pixels.
@@ -484,8 +484,8 @@ __global__ __launch_bounds__(MSDA_VT) void msda_bucket_kernel(const float* __res
 // (D values) as 16 bytes per lane, so a wave instruction moves SL rows per pixel group -- 512 B per 32 lanes at fp16 -- where
 // the round-3 form (one value per lane, one pair per group and instruction) moved 64 B; the bucket entries already hold the
 // row and the weight (no dependent loads).  A lane accumulates its 16 / sizeof(GT) channels over its slot's pairs in 64-bit
-// FIXED POINT (2^40 / max|grad_out|); the SL slots are added at the end -- integer sums, so the result does not depend on the
-// bucket order or on the slot a pair falls into (bit-reproducible, and bit-identical to the round-3 kernel).
+// FIXED POINT (2^24 / max|grad_out| per product, 64-bit sums); the SL slots are added at the end -- integer sums, so the result
+// does not depend on the bucket order or on the slot a pair falls into (bit-reproducible).
 template <typename GT>
 __global__ __launch_bounds__(256) void msda_gather_kernel(const GT* __restrict__ gout, const unsigned int* __restrict__ gmax,
                                                            const int* __restrict__ ws, float* __restrict__ gvalue,
@@ -506,11 +506,18 @@ __global__ __launch_bounds__(256) void msda_gather_kernel(const GT* __restrict__
     const int b0 = ws[pm], nb = ws[NMS + pm];
     const int2* list = reinterpret_cast<const int2*>(ws + 2 * NMS + (((long)n * M + m) * sh.n_levels + l) * nsamp * 8) + b0;
     const float gm = __uint_as_float(*gmax);
-    const float scale = gm > 0.f ? 1099511627776.0f / gm : 0.f;       // 2^40 / max|gout|
+    // fixed point with 2^24 / max|gout| per unit: |weight| <= 1, so a product is at most 2^24 and a lane's <= 4 * 16 / VEC
+    // products of one round of D bucket entries fit an int32 (v_rndne + v_cvt_i32 + one 32-bit add per product; the float ->
+    // int64 conversion of the round-3 form was ~10 instructions and made the kernel VALU-bound: 235 us for 6-11 M pairs); the
+    // int32 partial sums are widened into the 64-bit accumulators once per round.  Quantum = max|gout| * 2^-24 per product.
+    const float scale = gm > 0.f ? 16777216.0f / gm : 0.f;
     long long acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = 0;
     for (int k0 = 0; k0 < nb; k0 += D) {
+        int part[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) part[v] = 0;
         // lane j holds entry k0 + j of the bucket (coalesced 8-byte reads); rows / weights travel to their slots by shuffles
         int rowj = 0;
         float wj = 0.f;
@@ -528,14 +535,17 @@ __global__ __launch_bounds__(256) void msda_gather_kernel(const GT* __restrict__
                 const int kk = k + u * VEC + slot;
                 const int kc = kk < cntk ? kk : 0;            // (clamped: the weight of a padded slot is zeroed)
                 const long row = (long)__shfl(rowj, kc, D) * D;
-                wk[u] = kk < cntk ? __shfl(wj, kc, D) : 0.f;
+                const float wsh = __shfl(wj, kc, D);      // (every lane of the group takes part: the condition below differs per slot,
+                wk[u] = kk < cntk ? wsh : 0.f;            //  and a lane skipped by a conditional shuffle cannot serve as a source)
                 *reinterpret_cast<u32x4*>(gk[u]) = *reinterpret_cast<const u32x4*>(gout + row + ch);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) acc[v] += (long long)rintf((float)gk[u][v] * wk[u]);
+                for (int v = 0; v < VEC; ++v) part[v] += __float2int_rn((float)gk[u][v] * wk[u]);
         }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += part[v];
     }
     // add the SL slots: lanes d, d + CL, d + 2 CL, ... hold the same channels
     for (int o = CL; o < D; o <<= 1) {
@@ -547,7 +557,7 @@ __global__ __launch_bounds__(256) void msda_gather_kernel(const GT* __restrict__
         }
     }
     if (slot == 0) {
-        const float inv = gm > 0.f ? gm / 1099511627776.0f : 0.f;
+        const float inv = gm > 0.f ? gm / 16777216.0f : 0.f;
         const long o = (((long)n * S + s) * M + m) * D + ch;
         float gv[VEC];
         __half hv[VEC];

@@ -51,6 +51,7 @@ class HeadEngine:
         # set by TrainStep to views of its flat all-reduce bucket so no per-parameter copy/add kernels run
         self.direct_grads = None
         self.fwd_stream = None          # set by WeCLIP.forward while the head forward runs beside the CAM chain
+        self.row_gemm = True            # K = N = 256 Linears on the row-streaming GEMM kernel (False: tile kernels, for A/B)
         self.wcache = ops.WeightCache()     # fp16 (row-major + transposed) copies of every weight matrix, one launch per step
 
     def params(self):
@@ -126,8 +127,14 @@ class HeadEngine:
             a = Split(xb.hi.view(-1)[C:], xb.lo.view(-1)[C:] if (xlo and xb.lo is not None) else None)
             ops.gemm(a, wc.w("ad0.proj"), hw, E, C, bias=b1, out16=t1b.hi, out16lo=t1b.lo, act=2, batch=n * B, zdiv=B,
                      sA=Lq * C, sA2=B * Lq * C, sW=0, sW2=sw1, sC=hw * E, sC2=M * E, sB2=E)
-            ops.gemm(t1b, wc.w("ad0.proj_2"), M, E, E, bias=b2, out16=cat.hi, out16lo=cat.lo, ldc=n * E, batch=n, zdiv=1,
-                     sA2=M * E, sW2=sw2, sC2=E, sB2=E)
+            if self.row_gemm and not ex and cat.lo is None and t1b.lo is None and ops.gemm_row_ok(M, E, E):
+                # all n second Linears on the row-streaming kernel (weights stationary in registers, A read once, whole 512-byte
+                # output rows into the adapters' column slices of the fuse input): the product is HBM-bound, 185 MB per launch
+                ops.gemm_row_grouped(t1b.hi, wc.w("ad0.proj_2").hi, M, E, E, n, bias=b2, out16=cat.hi, ldc16=n * E, gA=M * E, gW=sw2,
+                                     gB=E, gC=E)
+            else:
+                ops.gemm(t1b, wc.w("ad0.proj_2"), M, E, E, bias=b2, out16=cat.hi, out16lo=cat.lo, ldc=n * E, batch=n, zdiv=1,
+                         sA2=M * E, sW2=sw2, sC2=E, sB2=E)
         else:
             for l, mlp in enumerate(self.fuse.linears_modulelist):
                 a = Split(xs[l].hi.view(-1)[C:], xs[l].lo.view(-1)[C:] if (xlo and xs[l].lo is not None) else None)
@@ -289,7 +296,10 @@ class HeadEngine:
         dt1b = torch.empty(n, M, E, device=dev, dtype=F16)
         swT = _uniform_stride([self.wcache.wT(f"ad{l}.proj_2")[0].hi for l in range(n)])
         grouped = ctx.get("t1b") is not None and swT is not None and os.environ.get("WECLIP_GROUPED_ADAPTERS", "1") != "0"
-        if grouped:       # dt1[l] = (dcat[:, l] W2[l]) * relu'(t1[l]) for all adapters in one grouped launch
+        if grouped and self.row_gemm and not ex and ops.gemm_row_ok(M, E, E):
+            ops.gemm_row_grouped(dcat.hi, self.wcache.wT("ad0.proj_2")[0].hi, M, E, E, n, lda=n * E, out16=dt1b, act=5,
+                                 auxh=ctx["t1b"].hi, ldaux=E, gA=E, gW=swT, gC=M * E, gX=M * E)
+        elif grouped:       # dt1[l] = (dcat[:, l] W2[l]) * relu'(t1[l]) for all adapters in one grouped launch
             ops.gemm(dcat, self.wcache.wT("ad0.proj_2")[0], M, E, E, lda=n * E, out16=dt1b, act=5, auxh=ctx["t1b"].hi,
                      ldaux=E, batch=n, zdiv=1, sA2=E, sW2=swT, sC2=M * E, sX2=M * E)
         if grouped and self._adapter_wgrads_grouped(ctx, dcat, dt1b, xs, B, Lq, C, M, inv, grads):

@@ -80,12 +80,18 @@ class _Conv3x3Fn(torch.autograd.Function):
         N, H, W, C, O, stride, Kp, M, ex, wshape = ctx.meta
         dev = dy.device
         dy = dy.float().contiguous()
-        Op = (O + 63) // 64 * 64
-        if Op != O:
-            pad = torch.zeros(M, Op, device=dev, dtype=F32)
-            pad[:, :O] = dy
-            dy = pad
+        # fp16 operand of both gradient GEMMs (scaled into fp16's normal range).  The input gradient contracts over the O output
+        # channels, which must then be padded to a multiple of 64; the weight gradient reads the O columns as they are.  The first
+        # stem layer (O = 32, 1 048 576 rows at 512^2) has no input gradient: no padding, no 268 MB zero fill + strided copy.
+        need_dx = ctx.needs_input_grad[0]
+        Op = (O + 63) // 64 * 64 if need_dx else O
         _, dS = ops.colscale_split(dy, None, M, alpha=GRAD_SCALE, want32=False, with_lo=ex)
+        if Op != O:
+            pad = Split(torch.zeros(M, Op, device=dev, dtype=F16), torch.zeros(M, Op, device=dev, dtype=F16) if ex else None)
+            for src, dst in ((dS.hi, pad.hi), (dS.lo, pad.lo)):
+                if src is not None:
+                    L.lib().wc_rows_copy_f16(L.ptr(src, F16), 0, L.ptr(dst, F16), 1, M, O, O, 0, Op, 0, L.stream())
+            dS = pad
         dx = dw = None
         if ctx.needs_input_grad[0]:
             wT, Kc = ops.transpose_f16(wmat, O, Kp, with_lo=ex)                   # (Kp, Op)

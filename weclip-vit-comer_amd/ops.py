@@ -119,6 +119,19 @@ def gemm_row(a16, w16, M, N, K, *, lda=None, ldw=None, bias=None, cscale=None, a
                             L.ptr(pre32, F32, "pre32"), ldc, ldc16, lnp[0], lnp[1], lnp[2], lnp[3], lnp[4], lnp[5], float(eps), L.stream())
 
 
+def gemm_row_grouped(a16, w16, M, N, K, groups, *, lda=None, ldw=None, bias=None, act=0, auxh=None, ldaux=0, out32=None, out16=None,
+                     ldc=None, ldc16=None, gA=0, gW=0, gB=0, gC=0, gX=0):
+    """`groups` products of one shape on the row-streaming kernel: group i reads a16 + i*gA, w16 + i*gW, bias + i*gB, auxh + i*gX
+    and writes out32 / out16 + i*gC (element offsets)."""
+    lda = K if lda is None else lda
+    ldw = K if ldw is None else ldw
+    ldc = N if ldc is None else ldc
+    ldc16 = ldc if ldc16 is None else ldc16
+    L.lib().wc_gemm_row_f16_grouped(L.ptr(a16, F16, "A"), lda, L.ptr(w16, F16, "W"), ldw, M, N, K, L.ptr(bias, F32, "bias"), act,
+                                    L.ptr(auxh, F16, "auxh"), ldaux, L.ptr(out32, F32, "out32"), L.ptr(out16, F16, "out16"), ldc, ldc16,
+                                    groups, gA, gW, gB, gC, gX, L.stream())
+
+
 def layernorm(x, weight, bias, *, eps=1e-5, want32=False, want16=True, with_lo=False, rows=None,
               D=None, ldx=None):
     """Row LayerNorm of fp32 x (rows, D).  Returns (y32 or None, Split or None)."""
