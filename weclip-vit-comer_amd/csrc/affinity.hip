@@ -276,12 +276,10 @@ __global__ __launch_bounds__(256) void aff_sweep_kernel(const float* __restrict_
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 ca[ch][q][k] = 0.f;
-                float v = 0.f;
-                if (okc[ch]) {
-                    v = cb[j + q];
-                    if (MODE == 2) v *= X[((long)b * hw + j + q) * K + k];
-                }
-                cx[ch][q][k] = v;
+                const int jc = okc[ch] ? j + q : 0;          // (unconditional loads, masked: see the row loads below)
+                float v = cb[jc];
+                if (MODE == 2) v *= X[((long)b * hw + jc) * K + k];
+                cx[ch][q][k] = okc[ch] ? v : 0.f;
             }
     }
     int buf = 0;
@@ -291,9 +289,22 @@ __global__ __launch_bounds__(256) void aff_sweep_kernel(const float* __restrict_
         for (int r = 0; r < AF_RG; ++r)
 #pragma unroll
             for (int ch = 0; ch < AF_MAXCH; ++ch) {
-                w[r][ch] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (okc[ch] && ig + r < i1) w[r][ch] = *reinterpret_cast<const float4*>(Wb + (long)(ig + r) * hw + ch * 1024 + tid * 4);
+                // (unconditional load from a clamped address, masked afterwards: behind a bounds branch hipcc waits for every
+                //  load before it issues the next one)
+                const bool ok = okc[ch] && ig + r < i1;
+                const float4 t = *reinterpret_cast<const float4*>(Wb + (long)min(ig + r, i1 - 1) * hw + (okc[ch] ? ch * 1024 + tid * 4 : 0));
+                w[r][ch] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        float rix[AF_RG], xix[AF_RG][K];          // MODE 2: r_i and X[i, k] of the group's rows, requested with the rows of W
+        if (MODE == 2) {
+#pragma unroll
+            for (int r = 0; r < AF_RG; ++r) {
+                const long i = (long)b * hw + min(ig + r, i1 - 1);
+                rix[r] = rin[i];
+#pragma unroll
+                for (int k = 0; k < K; ++k) xix[r][k] = X[i * K + k];
+            }
+        }
         float p[AF_RG][K];
 #pragma unroll
         for (int r = 0; r < AF_RG; ++r)
@@ -321,9 +332,9 @@ __global__ __launch_bounds__(256) void aff_sweep_kernel(const float* __restrict_
             for (int k = 0; k < K; ++k) {
                 const float dot = red[buf][0][r][k] + red[buf][1][r][k] + red[buf][2][r][k] + red[buf][3][r][k];
                 if (MODE == 2) {
-                    const float ri = rin[(long)b * hw + i];
+                    const float ri = rix[r];
                     if (tid == 0) y1[((long)b * hw + i) * K + k] = ri * dot;
-                    rv[k] = ri * X[((long)b * hw + i) * K + k];
+                    rv[k] = ri * xix[r][k];
                 } else {
                     rv[k] = 1.0f / dot;
                     if (tid == 0) rout[(long)b * hw + i] = rv[k];

@@ -47,13 +47,17 @@ __device__ __forceinline__ void cm_conv_strip(const T* __restrict__ xb, const fl
     for (int i = 0; i < K * K; ++i) wr[i] = wc[FLIP ? K * K - 1 - i : i];
 #pragma unroll
     for (int dy = -R; dy <= R; ++dy) {
+        // (every load is issued unconditionally from a clamped address and masked afterwards: a bounds BRANCH per load made hipcc
+        //  wait for each load before the next one -- up to 60 dependent-latency loads per thread, 57 us for a 44-MB pass)
         const int yy = py + dy;
-        if (yy < 0 || yy >= H) continue;
+        const bool rok = yy >= 0 && yy < H;
+        const long rb = (long)min(max(yy, 0), H - 1) * W;
         float xs[CM_SW + K - 1];
 #pragma unroll
         for (int j = 0; j < CM_SW + K - 1; ++j) {
             const int xx = x0 + j - R;
-            xs[j] = (xx >= 0 && xx < W) ? cm_ld(xb + ((long)yy * W + xx) * C) : 0.f;
+            const float v = cm_ld(xb + (rb + min(max(xx, 0), W - 1)) * C);
+            xs[j] = (rok && xx >= 0 && xx < W) ? v : 0.f;
         }
 #pragma unroll
         for (int dx = 0; dx < K; ++dx)
@@ -122,18 +126,21 @@ __device__ __forceinline__ void cm_wgrad_strip(const float* __restrict__ xb, con
     float g[CM_SW];
 #pragma unroll
     for (int o = 0; o < CM_SW; ++o) {
-        g[o] = (x0 + o < W) ? cm_ld(gb + ((long)py * W + x0 + o) * C) : 0.f;
+        // (masked by a MULTIPLICATION: a select lets hipcc sink the load back into a branch, and behind a branch it waits for
+        //  every load before issuing the next one)
+        g[o] = cm_ld(gb + ((long)py * W + min(x0 + o, W - 1)) * C) * (x0 + o < W ? 1.f : 0.f);
         acc[25] += g[o];
     }
 #pragma unroll
     for (int dy = -R; dy <= R; ++dy) {
         const int yy = py + dy;
-        if (yy < 0 || yy >= H) continue;
+        const bool rok = yy >= 0 && yy < H;
+        const long rb = (long)min(max(yy, 0), H - 1) * W;
         float xs[CM_SW + K - 1];
 #pragma unroll
         for (int j = 0; j < CM_SW + K - 1; ++j) {
             const int xx = x0 + j - R;
-            xs[j] = (xx >= 0 && xx < W) ? xb[((long)yy * W + xx) * C] : 0.f;
+            xs[j] = xb[(rb + min(max(xx, 0), W - 1)) * C] * ((rok && xx >= 0 && xx < W) ? 1.f : 0.f);
         }
 #pragma unroll
         for (int dx = 0; dx < K; ++dx) {
@@ -145,10 +152,10 @@ __device__ __forceinline__ void cm_wgrad_strip(const float* __restrict__ xb, con
     }
 }
 
-// filter / bias gradients, stage 1: workgroup (chunk of CM_WST strips per strip lane, image) -> part[(n * nchunk + chunk)][c][26]
+// filter / bias gradients, stage 1: workgroup (chunk of CM_WST strips per strip lane, image) -> part[(n * nchunk + chunk)][26][c]
 // (taps 0..24 [3x3 filters use 0..8] and the bias sum at 25).  256 threads = 256 / C strip lanes x C channels; the lanes are
 // combined through LDS in a fixed order.
-#define CM_WST 8
+#define CM_WST 4
 template <typename T>
 __global__ __launch_bounds__(256) void mrfp_dwconv_bwd_w_kernel(const T* __restrict__ dy, const float* __restrict__ x,
                                                                  float* __restrict__ part, CmLevels lv, int S, int C) {
@@ -174,34 +181,46 @@ __global__ __launch_bounds__(256) void mrfp_dwconv_bwd_w_kernel(const T* __restr
     for (int t = 0; t < 26; ++t) red[t * 256 + threadIdx.x] = acc[t];
     __syncthreads();
     if (pl == 0) {
-        float* out = part + (((long)n * gridDim.x + blockIdx.x) * C + c) * 26;
+        float* out = part + ((long)n * gridDim.x + blockIdx.x) * C * 26 + c;      // [part][26][C]: 4*C-byte rows per store
 #pragma unroll
         for (int t = 0; t < 26; ++t) {
             float sum = 0.f;
             for (int q = 0; q < npl; ++q) sum += red[t * 256 + q * C + c];
-            out[t] = sum;
+            out[(long)t * C] = sum;
         }
     }
 }
 
-// stage 2: out[c][t] = alpha * sum over the nparts partial rows (fixed order); dw3 (C/2, 9), db3, dw5 (C/2, 25), db5
+// stage 2: out[c][t] = alpha * sum over the nparts partial rows (fixed order); dw3 (C/2, 9), db3, dw5 (C/2, 25), db5.
+// A workgroup owns 16 consecutive (t, c) entries (64 contiguous bytes of every partial row); its 16 thread groups walk the partial
+// rows interleaved, eight loads in flight each, and meet in LDS -- a thread per entry walking all rows alone was one long chain of
+// dependent-latency loads (54 us for 336 rows).
 __global__ __launch_bounds__(256) void mrfp_dwconv_bwd_w_final_kernel(const float* __restrict__ part, float* __restrict__ dw3,
                                                                        float* __restrict__ db3, float* __restrict__ dw5,
                                                                        float* __restrict__ db5, int nparts, int C, float alpha) {
-    const int i = blockIdx.x * 256 + threadIdx.x;       // (c, t)
-    if (i >= C * 26) return;
-    const int c = i / 26, t = i - c * 26, half = C >> 1;
-    if (c < half && t >= 9 && t < 25) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int q = 0;
-    for (; q + 4 <= nparts; q += 4) {
-        s0 += part[((long)q * C + c) * 26 + t];
-        s1 += part[((long)(q + 1) * C + c) * 26 + t];
-        s2 += part[((long)(q + 2) * C + c) * 26 + t];
-        s3 += part[((long)(q + 3) * C + c) * 26 + t];
+    __shared__ float red[16][17];
+    const int j = threadIdx.x & 15, pg = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + j;                   // t * C + c
+    const long stride = (long)C * 26;
+    float s[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] = 0.f;
+    if (i < C * 26) {
+        int q = pg;
+        for (; q + 7 * 16 < nparts; q += 8 * 16)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += part[(long)(q + u * 16) * stride + i];
+        for (; q < nparts; q += 16) s[0] += part[(long)q * stride + i];
     }
-    for (; q < nparts; ++q) s0 += part[((long)q * C + c) * 26 + t];
-    const float v = ((s0 + s1) + (s2 + s3)) * alpha;
+    red[pg][j] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (pg != 0 || i >= C * 26) return;
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v += red[g][j];
+    v *= alpha;
+    const int t = i / C, c = i - t * C, half = C >> 1;
+    if (c < half && t >= 9 && t < 25) return;
     if (c < half) {
         if (t == 25) db3[c] = v; else dw3[c * 9 + t] = v;
     } else {
@@ -360,7 +379,7 @@ extern "C" int wc_mrfp_dwconv_bwd(const void* dy, int dy_is_f16, const float* x,
         hipLaunchKernelGGL(mrfp_dwconv_bwd_w_kernel<float>, dim3(nchunk, N), dim3(256), 0, st, (const float*)dy, x, part, lv, S, C);
     }
     WC_LAUNCH_CHECK("mrfp_dwconv_bwd kernels");
-    hipLaunchKernelGGL(mrfp_dwconv_bwd_w_final_kernel, dim3(wc_cdiv(C * 26, 256)), dim3(256), 0, st, part, dw3, db3, dw5, db5,
+    hipLaunchKernelGGL(mrfp_dwconv_bwd_w_final_kernel, dim3(wc_cdiv(C * 26, 16)), dim3(256), 0, st, part, dw3, db3, dw5, db5,
                        N * nchunk, C, alpha);
     WC_LAUNCH_CHECK("mrfp_dwconv_bwd_w_final_kernel");
     return WC_OK;

@@ -116,31 +116,38 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
 #define GN_ROWS 256      // rows of one partial block (the callers size their buffers for 64: more than enough)
 
 // part[(n*nblk + blk)*G + g] = (sum, sumsq) of rows [blk*GN_ROWS, ...) of image n, group g       (grid: nblk, N)
+// Round 4: a thread owns FOUR consecutive channels (16-byte loads, four rows in flight per thread) -- one 4-byte load per
+// thread and iteration left the kernels at a third of the HBM rate (27 / 80 us per launch forward / backward partials).
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, float2* __restrict__ part, int HW,
                                                           int C, int G) {
-    __shared__ float2 red[256];
+    __shared__ float2 red[4][256];
     const int blk = blockIdx.x, n = blockIdx.y, nblk = gridDim.x;
-    const int Cg = C / G, c = threadIdx.x % C, rl = threadIdx.x / C, nrl = 256 / C;
+    const int Cq = C >> 2, Cg = C / G, cq = threadIdx.x % Cq, rl = threadIdx.x / Cq, nrl = 256 / Cq;
     const int r0 = blk * GN_ROWS, r1 = min(r0 + GN_ROWS, HW);
-    float s = 0.f, q = 0.f;
-    const float* xp = x + (long)n * HW * C + c;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* xp = x + (long)n * HW * C + 4 * cq;
+#pragma unroll 4
     for (int r = r0 + rl; r < r1; r += nrl) {
-        const float v = xp[(long)r * C];
-        s += v;
-        q += v * v;
+        const float4 v = *reinterpret_cast<const float4*>(xp + (long)r * C);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
     }
-    red[threadIdx.x] = make_float2(s, q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = make_float2(s[k], q[k]);
     __syncthreads();
+    float2 t = make_float2(0.f, 0.f);
     if (threadIdx.x < C) {                    // channel sums: the row lanes in a fixed order
-        float2 t = red[threadIdx.x];
-        for (int k = 1; k < nrl; ++k) { t.x += red[k * C + threadIdx.x].x; t.y += red[k * C + threadIdx.x].y; }
-        red[threadIdx.x] = t;
+        const int k = threadIdx.x & 3, cq2 = threadIdx.x >> 2;
+        t = red[k][cq2];
+        for (int j = 1; j < nrl; ++j) { t.x += red[k][j * Cq + cq2].x; t.y += red[k][j * Cq + cq2].y; }
     }
+    __syncthreads();
+    if (threadIdx.x < C) red[0][threadIdx.x] = t;
     __syncthreads();
     if (threadIdx.x < G) {
-        float2 t = make_float2(0.f, 0.f);
-        for (int k = 0; k < Cg; ++k) { t.x += red[threadIdx.x * Cg + k].x; t.y += red[threadIdx.x * Cg + k].y; }
-        part[((long)n * nblk + blk) * G + threadIdx.x] = t;
+        float2 u = make_float2(0.f, 0.f);
+        for (int k = 0; k < Cg; ++k) { u.x += red[0][threadIdx.x * Cg + k].x; u.y += red[0][threadIdx.x * Cg + k].y; }
+        part[((long)n * nblk + blk) * G + threadIdx.x] = u;
     }
 }
 
@@ -205,33 +212,42 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
                                                               const float* __restrict__ dy, const float2* __restrict__ stats,
                                                               const float* __restrict__ gamma, float2* __restrict__ gpart,
                                                               float2* __restrict__ cpart, int HW, int C, int G) {
-    __shared__ float2 red[256];
+    __shared__ float2 red[4][256];
     const int blk = blockIdx.x, n = blockIdx.y, nblk = gridDim.x;
-    const int Cg = C / G, c = threadIdx.x % C, rl = threadIdx.x / C, nrl = 256 / C;
+    const int Cq = C >> 2, Cg = C / G, cq = threadIdx.x % Cq, rl = threadIdx.x / Cq, nrl = 256 / Cq;
     const int r0 = blk * GN_ROWS, r1 = min(r0 + GN_ROWS, HW);
-    const float2 st = stats[n * G + c / Cg];
-    float a = 0.f, b = 0.f;
-    const long base = (long)n * HW * C + c;
+    const float2 st = stats[n * G + (4 * cq) / Cg];      // (Cg % 4 == 0: the four channels share a group)
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+    const long base = (long)n * HW * C + 4 * cq;
+#pragma unroll 4
     for (int r = r0 + rl; r < r1; r += nrl) {
         const long o = base + (long)r * C;
-        const float d = y[o] > 0.f ? dy[o] : 0.f;
-        a += d * (x[o] - st.x) * st.y;
-        b += d;
+        const float4 yv = *reinterpret_cast<const float4*>(y + o), dv = *reinterpret_cast<const float4*>(dy + o),
+                     xv = *reinterpret_cast<const float4*>(x + o);
+        const float d0 = yv.x > 0.f ? dv.x : 0.f, d1 = yv.y > 0.f ? dv.y : 0.f, d2 = yv.z > 0.f ? dv.z : 0.f, d3 = yv.w > 0.f ? dv.w : 0.f;
+        a[0] += d0 * (xv.x - st.x) * st.y; a[1] += d1 * (xv.y - st.x) * st.y; a[2] += d2 * (xv.z - st.x) * st.y; a[3] += d3 * (xv.w - st.x) * st.y;
+        b[0] += d0; b[1] += d1; b[2] += d2; b[3] += d3;
     }
-    red[threadIdx.x] = make_float2(a, b);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = make_float2(a[k], b[k]);
+    __syncthreads();
+    float2 t = make_float2(0.f, 0.f);
+    if (threadIdx.x < C) {
+        const int k = threadIdx.x & 3, cq2 = threadIdx.x >> 2;
+        t = red[k][cq2];
+        for (int j = 1; j < nrl; ++j) { t.x += red[k][j * Cq + cq2].x; t.y += red[k][j * Cq + cq2].y; }
+        cpart[((long)n * nblk + blk) * C + threadIdx.x] = t;
+    }
     __syncthreads();
     if (threadIdx.x < C) {
-        float2 t = red[threadIdx.x];
-        for (int k = 1; k < nrl; ++k) { t.x += red[k * C + threadIdx.x].x; t.y += red[k * C + threadIdx.x].y; }
-        cpart[((long)n * nblk + blk) * C + threadIdx.x] = t;
         const float gm = gamma[threadIdx.x];
-        red[threadIdx.x] = make_float2(gm * t.y, gm * t.x);          // (sum g, sum g*xhat) of this channel
+        red[0][threadIdx.x] = make_float2(gm * t.y, gm * t.x);          // (sum g, sum g*xhat) of this channel
     }
     __syncthreads();
     if (threadIdx.x < G) {
-        float2 t = make_float2(0.f, 0.f);
-        for (int k = 0; k < Cg; ++k) { t.x += red[threadIdx.x * Cg + k].x; t.y += red[threadIdx.x * Cg + k].y; }
-        gpart[((long)n * nblk + blk) * G + threadIdx.x] = t;
+        float2 u = make_float2(0.f, 0.f);
+        for (int k = 0; k < Cg; ++k) { u.x += red[0][threadIdx.x * Cg + k].x; u.y += red[0][threadIdx.x * Cg + k].y; }
+        gpart[((long)n * nblk + blk) * G + threadIdx.x] = u;
     }
 }
 
@@ -341,7 +357,8 @@ extern "C" int wc_col2im3x3(const float* dcols, float* dx, int N, int H, int W, 
 extern "C" int wc_groupnorm_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
                                      float* part, int N, int HW, int C, int G, float eps, void* stream) {
     WC_CHECK_ARG(x && gamma && beta && y && stats && part && N > 0 && N <= 65535 && HW > 0 && C > 0 && G > 0 && C % G == 0 &&
-                 C <= 256 && 256 % C == 0, "wc_groupnorm_relu_fwd: bad argument (C must divide 256)");
+                 C <= 256 && 256 % C == 0 && (C / G) % 4 == 0 && ((uintptr_t)x | (uintptr_t)y) % 16 == 0,
+                 "wc_groupnorm_relu_fwd: bad argument (C must divide 256, 4 | C / G, 16-byte aligned rows)");
     hipStream_t st = (hipStream_t)stream;
     const int nblk = wc_cdiv(HW, GN_ROWS);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, N), dim3(256), 0, st, x, (float2*)part, HW, C, G);
@@ -360,7 +377,9 @@ extern "C" int wc_groupnorm_relu_bwd(const float* x, const float* y, const float
                                      float* dx, float* dgamma, float* dbeta, float* gpart, float* cpart, float* gsum, int N,
                                      int HW, int C, int G, void* stream) {
     WC_CHECK_ARG(x && y && dy && stats && gamma && dx && dgamma && dbeta && gpart && cpart && gsum && N > 0 && N <= 65535 &&
-                 HW > 0 && C > 0 && G > 0 && C % G == 0 && C <= 256 && 256 % C == 0, "wc_groupnorm_relu_bwd: bad argument (C must divide 256)");
+                 HW > 0 && C > 0 && G > 0 && C % G == 0 && C <= 256 && 256 % C == 0 && (C / G) % 4 == 0 &&
+                 ((uintptr_t)x | (uintptr_t)y | (uintptr_t)dy | (uintptr_t)dx) % 16 == 0,
+                 "wc_groupnorm_relu_bwd: bad argument (C must divide 256, 4 | C / G, 16-byte aligned rows)");
     hipStream_t st = (hipStream_t)stream;
     const int nblk = wc_cdiv(HW, GN_ROWS);
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nblk, N), dim3(256), 0, st, x, y, dy, (const float2*)stats, gamma,

@@ -760,6 +760,11 @@ __global__ __launch_bounds__(256) void rowvec_matmul_kernel(const float* __restr
 #pragma unroll
     for (int k = 0; k < RVM_PB; ++k) acc[k] = 0.f;
     if (e < E) {
+        // rows past P read row P - 1 and are dropped at the end: a bounds branch per c load made hipcc wait for each of the 32
+        // loads of an iteration before issuing the next one
+        long crow[RVM_PB];
+#pragma unroll
+        for (int k = 0; k < RVM_PB; ++k) crow[k] = (long)min(p0 + k, P - 1) * N;
         int n = nbeg + wv;
         for (; n + 12 < nend; n += 16) {              // four W rows in flight per wave (one per iteration: latency bound)
             float w4[4];
@@ -768,14 +773,12 @@ __global__ __launch_bounds__(256) void rowvec_matmul_kernel(const float* __restr
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int k = 0; k < RVM_PB; ++k)
-                    if (p0 + k < P) acc[k] = fmaf(c[(long)(p0 + k) * N + n + 4 * u], w4[u], acc[k]);
+                for (int k = 0; k < RVM_PB; ++k) acc[k] = fmaf(c[crow[k] + n + 4 * u], w4[u], acc[k]);
         }
         for (; n < nend; n += 4) {
             const float w = W[(long)n * E + e];
 #pragma unroll
-            for (int k = 0; k < RVM_PB; ++k)
-                if (p0 + k < P) acc[k] = fmaf(c[(long)(p0 + k) * N + n], w, acc[k]);
+            for (int k = 0; k < RVM_PB; ++k) acc[k] = fmaf(c[crow[k] + n], w, acc[k]);
         }
     }
 #pragma unroll

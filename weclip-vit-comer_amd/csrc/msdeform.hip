@@ -127,6 +127,24 @@ __device__ __forceinline__ float4 msda_ld4(const __half* p) {
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 
+// The four corner rows of a bilinear sample, loaded UNCONDITIONALLY from clamped addresses and zeroed afterwards where the corner
+// (or, `in` false, the whole sample) lies outside the map.  A bounds BRANCH around each load made hipcc put `s_waitcnt vmcnt(0)`
+// behind every one of them: 4 x nL x P dependent-latency loads per thread (round 4: found in the ISA, not in a profile).
+template <typename VT>
+__device__ __forceinline__ void msda_corners(const VT* __restrict__ vl, int y0, int x0, int H, int W, long MD, bool in, float4& v00,
+                                             float4& v01, float4& v10, float4& v11) {
+    const int ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1);
+    const int xa = min(max(x0, 0), W - 1), xb = min(max(x0 + 1, 0), W - 1);
+    const float4 a = msda_ld4(vl + ((long)ya * W + xa) * MD), b = msda_ld4(vl + ((long)ya * W + xb) * MD);
+    const float4 c = msda_ld4(vl + ((long)yb * W + xa) * MD), d = msda_ld4(vl + ((long)yb * W + xb) * MD);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool top = in && y0 >= 0, bot = in && y0 + 1 < H, lef = x0 >= 0, rig = x0 + 1 < W;
+    v00 = (top && lef) ? a : z;
+    v01 = (top && rig) ? b : z;
+    v10 = (bot && lef) ? c : z;
+    v11 = (bot && rig) ? d : z;
+}
+
 // VT: value as f32 or f16 (f16 halves the gather traffic that bounds these kernels: 4 corners x nL*P samples per query and head)
 template <typename VT>
 __global__ __launch_bounds__(256) void msda_fwd4_kernel(const VT* __restrict__ value, const float* __restrict__ loc,
@@ -148,14 +166,13 @@ __global__ __launch_bounds__(256) void msda_fwd4_kernel(const VT* __restrict__ v
         for (int p = 0; p < P; ++p) {
             const float x = lb[(l * P + p) * 2] * W - 0.5f, y = lb[(l * P + p) * 2 + 1] * H - 0.5f;
             const float w = ab[l * P + p];
-            if (y > -1.f && x > -1.f && y < H && x < W) {
-                const int y0 = (int)floorf(y), x0 = (int)floorf(x);
-                const float ly = y - y0, lx = x - x0, hy = 1.f - ly, hx = 1.f - lx;
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 v00 = (y0 >= 0 && x0 >= 0) ? msda_ld4(vl + ((long)y0 * W + x0) * MD) : z;
-                const float4 v01 = (y0 >= 0 && x0 + 1 < W) ? msda_ld4(vl + ((long)y0 * W + x0 + 1) * MD) : z;
-                const float4 v10 = (y0 + 1 < H && x0 >= 0) ? msda_ld4(vl + ((long)(y0 + 1) * W + x0) * MD) : z;
-                const float4 v11 = (y0 + 1 < H && x0 + 1 < W) ? msda_ld4(vl + ((long)(y0 + 1) * W + x0 + 1) * MD) : z;
+            {
+                const bool in = y > -1.f && x > -1.f && y < H && x < W;
+                const float yc = in ? y : 0.f, xc = in ? x : 0.f;       // (an outside sample contributes exact zeros)
+                const int y0 = (int)floorf(yc), x0 = (int)floorf(xc);
+                const float ly = yc - y0, lx = xc - x0, hy = 1.f - ly, hx = 1.f - lx;
+                float4 v00, v01, v10, v11;
+                msda_corners(vl, y0, x0, H, W, MD, in, v00, v01, v10, v11);
                 const float w00 = w * hy * hx, w01 = w * hy * lx, w10 = w * ly * hx, w11 = w * ly * lx;
                 acc.x += w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x;
                 acc.y += w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y;
@@ -194,14 +211,13 @@ __global__ __launch_bounds__(256) void msda_bwd4_kernel(const VT* __restrict__ v
             const float x = lb[(l * P + p) * 2] * W - 0.5f, y = lb[(l * P + p) * 2 + 1] * H - 0.5f;
             const float w = ab[l * P + p];
             float gx = 0.f, gy = 0.f, ga = 0.f;
-            if (y > -1.f && x > -1.f && y < H && x < W) {
-                const int y0 = (int)floorf(y), x0 = (int)floorf(x);
-                const float ly = y - y0, lx = x - x0, hy = 1.f - ly, hx = 1.f - lx;
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 v00 = (y0 >= 0 && x0 >= 0) ? msda_ld4(vl + ((long)y0 * W + x0) * MD) : z;
-                const float4 v01 = (y0 >= 0 && x0 + 1 < W) ? msda_ld4(vl + ((long)y0 * W + x0 + 1) * MD) : z;
-                const float4 v10 = (y0 + 1 < H && x0 >= 0) ? msda_ld4(vl + ((long)(y0 + 1) * W + x0) * MD) : z;
-                const float4 v11 = (y0 + 1 < H && x0 + 1 < W) ? msda_ld4(vl + ((long)(y0 + 1) * W + x0 + 1) * MD) : z;
+            {
+                const bool in = y > -1.f && x > -1.f && y < H && x < W;
+                const float yc = in ? y : 0.f, xc = in ? x : 0.f;       // (an outside sample contributes exact zeros)
+                const int y0 = (int)floorf(yc), x0 = (int)floorf(xc);
+                const float ly = yc - y0, lx = xc - x0, hy = 1.f - ly, hx = 1.f - lx;
+                float4 v00, v01, v10, v11;
+                msda_corners(vl, y0, x0, H, W, MD, in, v00, v01, v10, v11);
                 // per channel: bilinear value, d/dx, d/dy; dotted with the output gradient of the lane's 4 channels
                 const float b0 = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
                 const float b1 = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
@@ -293,14 +309,13 @@ __global__ __launch_bounds__(256) void msda_fwd4f_kernel(const VT* __restrict__ 
         for (int p = 0; p < P; ++p) {
             const int t = l * P + p;
             const float x = sx[t] * W - 0.5f, y = sy[t] * H - 0.5f, w = aw[t];
-            if (y > -1.f && x > -1.f && y < H && x < W) {
-                const int y0 = (int)floorf(y), x0 = (int)floorf(x);
-                const float ly = y - y0, lx = x - x0, hy = 1.f - ly, hx = 1.f - lx;
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 v00 = (y0 >= 0 && x0 >= 0) ? msda_ld4(vl + ((long)y0 * W + x0) * MD) : z;
-                const float4 v01 = (y0 >= 0 && x0 + 1 < W) ? msda_ld4(vl + ((long)y0 * W + x0 + 1) * MD) : z;
-                const float4 v10 = (y0 + 1 < H && x0 >= 0) ? msda_ld4(vl + ((long)(y0 + 1) * W + x0) * MD) : z;
-                const float4 v11 = (y0 + 1 < H && x0 + 1 < W) ? msda_ld4(vl + ((long)(y0 + 1) * W + x0 + 1) * MD) : z;
+            {
+                const bool in = y > -1.f && x > -1.f && y < H && x < W;
+                const float yc = in ? y : 0.f, xc = in ? x : 0.f;       // (an outside sample contributes exact zeros)
+                const int y0 = (int)floorf(yc), x0 = (int)floorf(xc);
+                const float ly = yc - y0, lx = xc - x0, hy = 1.f - ly, hx = 1.f - lx;
+                float4 v00, v01, v10, v11;
+                msda_corners(vl, y0, x0, H, W, MD, in, v00, v01, v10, v11);
                 const float w00 = w * hy * hx, w01 = w * hy * lx, w10 = w * ly * hx, w11 = w * ly * lx;
                 acc.x += w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x;
                 acc.y += w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y;
@@ -331,42 +346,60 @@ __global__ __launch_bounds__(256) void msda_bwd4f_kernel(const VT* __restrict__ 
     const float* lb = loc + (nq * M + m) * T * 2;
     const float* ab = attn + (nq * M + m) * T;
     const float4 go = msda_ld4(gout + nq * MD + (long)m * D + d4);
-    float aw[T], ga[T], gx[T], gy[T];
+    // Loads first, reductions last: all T locations / weights of the (query, head), then per level the 4 x P corner rows in flight
+    // together, the un-reduced per-lane sums kept in registers; the 3 T head reductions run afterwards as ONE loop over the shuffle
+    // distance with 3 T independent shuffles per step.  (The sample-after-sample form -- location load, wait, four corner loads,
+    // wait, three shuffle loops -- exposed two memory latencies per sample: 24 per thread at T = 12.)
+    float aw[T], ga[T], gx[T], gy[T], px[T], py[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        px[t] = lb[t * 2];
+        py[t] = lb[t * 2 + 1];
+        aw[t] = ab[t];
+    }
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
         const int H = sh.H[l], W = sh.W[l];
         const VT* vl = vb + (long)sh.start[l] * MD;
+        float4 c00[P], c01[P], c10[P], c11[P];
+        float fy[P], fx[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const int t = l * P + p;
-            const float x = lb[t * 2] * W - 0.5f, y = lb[t * 2 + 1] * H - 0.5f;
-            const float w = ab[t];
-            aw[t] = w;
-            float sgx = 0.f, sgy = 0.f, sga = 0.f;
-            if (y > -1.f && x > -1.f && y < H && x < W) {
-                const int y0 = (int)floorf(y), x0 = (int)floorf(x);
-                const float ly = y - y0, lx = x - x0, hy = 1.f - ly, hx = 1.f - lx;
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 v00 = (y0 >= 0 && x0 >= 0) ? msda_ld4(vl + ((long)y0 * W + x0) * MD) : z;
-                const float4 v01 = (y0 >= 0 && x0 + 1 < W) ? msda_ld4(vl + ((long)y0 * W + x0 + 1) * MD) : z;
-                const float4 v10 = (y0 + 1 < H && x0 >= 0) ? msda_ld4(vl + ((long)(y0 + 1) * W + x0) * MD) : z;
-                const float4 v11 = (y0 + 1 < H && x0 + 1 < W) ? msda_ld4(vl + ((long)(y0 + 1) * W + x0 + 1) * MD) : z;
-                const float b0 = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
-                const float b1 = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
-                const float b2 = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
-                const float b3 = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
-                sga = go.x * b0 + go.y * b1 + go.z * b2 + go.w * b3;
-                const float dx0 = hy * (v01.x - v00.x) + ly * (v11.x - v10.x), dx1 = hy * (v01.y - v00.y) + ly * (v11.y - v10.y);
-                const float dx2 = hy * (v01.z - v00.z) + ly * (v11.z - v10.z), dx3 = hy * (v01.w - v00.w) + ly * (v11.w - v10.w);
-                const float dy0 = hx * (v10.x - v00.x) + lx * (v11.x - v01.x), dy1 = hx * (v10.y - v00.y) + lx * (v11.y - v01.y);
-                const float dy2 = hx * (v10.z - v00.z) + lx * (v11.z - v01.z), dy3 = hx * (v10.w - v00.w) + lx * (v11.w - v01.w);
-                // d out / d offset = d out / d loc / (W, H) and d loc = pixel / (W, H): the two level sizes cancel
-                sgx = w * (go.x * dx0 + go.y * dx1 + go.z * dx2 + go.w * dx3);
-                sgy = w * (go.x * dy0 + go.y * dy1 + go.z * dy2 + go.w * dy3);
-            }
-            gx[t] = head_sum(sgx, dq);
-            gy[t] = head_sum(sgy, dq);
-            ga[t] = head_sum(sga, dq);
+            const float x = px[t] * W - 0.5f, y = py[t] * H - 0.5f;
+            const bool in = y > -1.f && x > -1.f && y < H && x < W;
+            const float yc = in ? y : 0.f, xc = in ? x : 0.f;       // (an outside sample contributes exact zeros)
+            const int y0 = (int)floorf(yc), x0 = (int)floorf(xc);
+            fy[p] = yc - y0;
+            fx[p] = xc - x0;
+            msda_corners(vl, y0, x0, H, W, MD, in, c00[p], c01[p], c10[p], c11[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int t = l * P + p;
+            const float w = aw[t];
+            const float ly = fy[p], lx = fx[p], hy = 1.f - ly, hx = 1.f - lx;
+            const float4 v00 = c00[p], v01 = c01[p], v10 = c10[p], v11 = c11[p];
+            const float b0 = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+            const float b1 = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+            const float b2 = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+            const float b3 = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+            ga[t] = go.x * b0 + go.y * b1 + go.z * b2 + go.w * b3;
+            const float dx0 = hy * (v01.x - v00.x) + ly * (v11.x - v10.x), dx1 = hy * (v01.y - v00.y) + ly * (v11.y - v10.y);
+            const float dx2 = hy * (v01.z - v00.z) + ly * (v11.z - v10.z), dx3 = hy * (v01.w - v00.w) + ly * (v11.w - v10.w);
+            const float dy0 = hx * (v10.x - v00.x) + lx * (v11.x - v01.x), dy1 = hx * (v10.y - v00.y) + lx * (v11.y - v01.y);
+            const float dy2 = hx * (v10.z - v00.z) + lx * (v11.z - v01.z), dy3 = hx * (v10.w - v00.w) + lx * (v11.w - v01.w);
+            // d out / d offset = d out / d loc / (W, H) and d loc = pixel / (W, H): the two level sizes cancel
+            gx[t] = w * (go.x * dx0 + go.y * dx1 + go.z * dx2 + go.w * dx3);
+            gy[t] = w * (go.x * dy0 + go.y * dy1 + go.z * dy2 + go.w * dy3);
+        }
+    }
+    for (int o = dq >> 1; o > 0; o >>= 1) {          // sums over the D / 4 lanes of the head (same order as head_sum)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            gx[t] += __shfl_xor(gx[t], o, 64);
+            gy[t] += __shfl_xor(gy[t], o, 64);
+            ga[t] += __shfl_xor(ga[t], o, 64);
         }
     }
     __half* drow = dow16 + nq * ld;
@@ -384,11 +417,33 @@ __global__ __launch_bounds__(256) void msda_bwd4f_kernel(const VT* __restrict__ 
     for (int c = 3 * M * T + j; c < ld; c += tpq) drow[c] = __float2half(0.f);      // K padding of the gradient GEMMs
 }
 
-// max |gout| as the bit pattern of a non-negative float (unsigned compare == float compare); *gmax zeroed by the caller
+// max |gout| as the bit pattern of a non-negative float (unsigned compare == float compare); *gmax zeroed by the caller.
+// 16-byte loads, four in flight per thread (n is a multiple of 16 / sizeof(GT), g 16-byte aligned: checked by the launcher).
 template <typename GT>
 __global__ __launch_bounds__(256) void msda_absmax_kernel(const GT* __restrict__ g, unsigned int* __restrict__ gmax, long n) {
+    constexpr int VEC = 16 / (int)sizeof(GT);
+    const uint4* g4 = reinterpret_cast<const uint4*>(g);
+    const long n4 = n / VEC, stride = (long)gridDim.x * 256;
     float m = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf((float)g[i]));
+    auto fold = [&](const uint4& u) {
+        if constexpr (sizeof(GT) == 2) {
+            const __half2* h = reinterpret_cast<const __half2*>(&u);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float2 f = __half22float2(h[k]);
+                m = fmaxf(m, fmaxf(fabsf(f.x), fabsf(f.y)));
+            }
+        } else {
+            const float* f = reinterpret_cast<const float*>(&u);
+            m = fmaxf(fmaxf(m, fabsf(f[0])), fmaxf(fabsf(f[1]), fmaxf(fabsf(f[2]), fabsf(f[3]))));
+        }
+    };
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const uint4 a = g4[i], b = g4[i + stride], c = g4[i + 2 * stride], d = g4[i + 3 * stride];
+        fold(a); fold(b); fold(c); fold(d);
+    }
+    for (; i < n4; i += stride) fold(g4[i]);
     __shared__ float red[16];
     m = block_max(m, red);
     if (threadIdx.x == 0) atomicMax(gmax, __float_as_uint(m));
@@ -648,8 +703,9 @@ static int msda_bwd_value(const float* loc, const float* attn, const GT* gout, f
                           const MsdaShapes& sh, int n_levels, int S, int N, int Lq, int M, int D, int P, hipStream_t st) {
     hipMemsetAsync(gmax, 0, sizeof(unsigned int), st);
     const long ng = (long)N * Lq * M * D;
-    hipLaunchKernelGGL(msda_absmax_kernel<GT>, dim3((unsigned)(ng / 256 / 8 + 1 > 512 ? 512 : ng / 256 / 8 + 1)), dim3(256), 0, st, gout,
-                       (unsigned int*)gmax, ng);
+    WC_CHECK_ARG((uintptr_t)gout % 16 == 0 && D % (16 / (int)sizeof(GT)) == 0, "wc_msda_bwd: grad_out must be 16-byte aligned");
+    const long nv = ng / (16 / (long)sizeof(GT)) / 256 / 4 + 1;
+    hipLaunchKernelGGL(msda_absmax_kernel<GT>, dim3((unsigned)(nv > 2048 ? 2048 : nv)), dim3(256), 0, st, gout, (unsigned int*)gmax, ng);
     WC_LAUNCH_CHECK("msda_absmax_kernel");
     int maxhw = 0;
     for (int l = 0; l < n_levels; ++l) maxhw = sh.H[l] * sh.W[l] > maxhw ? sh.H[l] * sh.W[l] : maxhw;

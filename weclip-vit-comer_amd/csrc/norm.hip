@@ -18,36 +18,44 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (row >= rows) return;
     const int nv = D >> 2;   // float4 per row
     const float4* xr = reinterpret_cast<const float4*>(x + row * ldx);
-    float4 v[MAXV];
+    const float4* wr = reinterpret_cast<const float4*>(w);
+    const float4* br = reinterpret_cast<const float4*>(b);
+    // Every load is issued UNCONDITIONALLY from a clamped index and masked afterwards: behind an `if (j < nv)` hipcc waits for each
+    // load before it issues the next (round 4, found in the ISA: 3 dependent HBM latencies per row at D = 768).  For rows of up to
+    // 1024 values the affine parameters are requested together with the row as well.
+    constexpr bool HOIST = MAXV <= 4;
+    float4 v[MAXV], ww[HOIST ? MAXV : 1], bb[HOIST ? MAXV : 1];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int j = lane + 64 * i;
-        if (j < nv) {
-            v[i] = xr[j];
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const int j = lane + 64 * i, jc = j < nv ? j : nv - 1;
+        v[i] = xr[jc];
+        if constexpr (HOIST) {
+            ww[i] = wr[jc];
+            bb[i] = br[jc];
         }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (lane + 64 * i >= nv) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum(s) / D;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int j = lane + 64 * i;
-        if (j < nv) {
-            const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-            q += (a * a + bb * bb) + (c * c + d * d);
-        }
+        const float a = v[i].x - mean, b2 = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        const float t = (a * a + b2 * b2) + (c * c + d * d);
+        q += lane + 64 * i < nv ? t : 0.f;
     }
     const float rstd = rsqrtf(wave_sum(q) / D + eps);
-    const float4* wr = reinterpret_cast<const float4*>(w);
-    const float4* br = reinterpret_cast<const float4*>(b);
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int j = lane + 64 * i;
         if (j < nv) {
-            const float4 ww = wr[j], bb = br[j];
-            float o[4] = {(v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y,
-                          (v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w};
+            const float4 w4 = HOIST ? ww[HOIST ? i : 0] : wr[j], b4 = HOIST ? bb[HOIST ? i : 0] : br[j];
+            float o[4] = {(v[i].x - mean) * rstd * w4.x + b4.x, (v[i].y - mean) * rstd * w4.y + b4.y,
+                          (v[i].z - mean) * rstd * w4.z + b4.z, (v[i].w - mean) * rstd * w4.w + b4.w};
             const long off = row * D + 4L * j;
             if (y32) *reinterpret_cast<float4*>(y32 + off) = make_float4(o[0], o[1], o[2], o[3]);
             if (y16) {

@@ -95,6 +95,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     // the partial-sum matrix the final column reduction reads has gridDim.x rows instead of rows / 16 (86 016 rows: 11 MB ->
     // 2 MB; colsum_final 19.8 -> ~6 us).  dy may arrive as fp16 (dy16: the producing GEMM then writes and this kernel reads
     // half the bytes).
+    float wv_[NV];              // gamma: the same for every group of the block
+#pragma unroll
+    for (int i = 0; i < NV; i += 4) {
+        const int e = LN_E(i);
+        const float4 wa = *reinterpret_cast<const float4*>(w + (e < D ? e : 0));
+        wv_[i] = e < D ? wa.x : 0.f; wv_[i + 1] = e < D ? wa.y : 0.f; wv_[i + 2] = e < D ? wa.z : 0.f; wv_[i + 3] = e < D ? wa.w : 0.f;
+    }
     for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     // the LNB_ROWS rows of a wave are processed TOGETHER: all their loads in flight at once and their four reduction
     // chains interleaved (the row-after-row loop exposed one load latency and four shuffle chains per row: 29 us for
@@ -102,31 +109,59 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     const long r0 = (grp * 4 + wv) * LNB_ROWS;
     float xv[LNB_ROWS][NV], dv[LNB_ROWS][NV], s[LNB_ROWS];
     bool live[LNB_ROWS];
+    // Every load of the group is issued UNCONDITIONALLY from a clamped address and masked afterwards (behind a bounds branch hipcc
+    // waits for each load before it issues the next one); the fp16 / fp32 form of dy is ONE uniform branch around all of its loads;
+    // for rows of up to 256 values the residual gradient `add` is requested here as well instead of after the reduction chains.
+    constexpr bool HOIST = NV <= 4;
+    float4 av[LNB_ROWS][HOIST ? NV / 4 : 1];
+    long rowc[LNB_ROWS];
 #pragma unroll
     for (int r = 0; r < LNB_ROWS; ++r) {
         live[r] = r0 + r < rows;
-        const long row = live[r] ? r0 + r : rows - 1;
-        const float* xr = x + row * D;
+        rowc[r] = live[r] ? r0 + r : rows - 1;
+#pragma unroll
+        for (int i = 0; i < NV; i += 4) {
+            const int e = LN_E(i), ec = e < D ? e : 0;
+            const float4 xa = *reinterpret_cast<const float4*>(x + rowc[r] * D + ec);
+            xv[r][i] = xa.x; xv[r][i + 1] = xa.y; xv[r][i + 2] = xa.z; xv[r][i + 3] = xa.w;
+            if constexpr (HOIST) {
+                if (add) av[r][i >> 2] = *reinterpret_cast<const float4*>(add + rowc[r] * D + ec);
+            }
+        }
+    }
+    if (dy16) {
+#pragma unroll
+        for (int r = 0; r < LNB_ROWS; ++r)
+#pragma unroll
+            for (int i = 0; i < NV; i += 4) {
+                const int e = LN_E(i), ec = e < D ? e : 0;
+                const uint2 hq = *reinterpret_cast<const uint2*>(dy16 + rowc[r] * D + ec);
+                const __half* hp = reinterpret_cast<const __half*>(&hq);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dv[r][i + k] = __half2float(hp[k]);
+            }
+    } else {
+#pragma unroll
+        for (int r = 0; r < LNB_ROWS; ++r)
+#pragma unroll
+            for (int i = 0; i < NV; i += 4) {
+                const int e = LN_E(i), ec = e < D ? e : 0;
+                const float4 da = *reinterpret_cast<const float4*>(dy + rowc[r] * D + ec);
+                dv[r][i] = da.x; dv[r][i + 1] = da.y; dv[r][i + 2] = da.z; dv[r][i + 3] = da.w;
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < LNB_ROWS; ++r) {
         s[r] = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; i += 4) {
-            const int e = LN_E(i);
-            float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), da = xa;
-            if (e < D) {
-                xa = *reinterpret_cast<const float4*>(xr + e);
-                if (live[r]) {
-                    if (dy16) {
-                        const uint2 hq = *reinterpret_cast<const uint2*>(dy16 + row * D + e);
-                        const __half* hp = reinterpret_cast<const __half*>(&hq);
-                        da = make_float4(__half2float(hp[0]), __half2float(hp[1]), __half2float(hp[2]), __half2float(hp[3]));
-                    } else {
-                        da = *reinterpret_cast<const float4*>(dy + row * D + e);
-                    }
-                }
+            const bool in = LN_E(i) < D;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                xv[r][i + k] = in ? xv[r][i + k] : 0.f;
+                dv[r][i + k] = (in && live[r]) ? dv[r][i + k] : 0.f;
             }
-            xv[r][i] = xa.x; xv[r][i + 1] = xa.y; xv[r][i + 2] = xa.z; xv[r][i + 3] = xa.w;
-            dv[r][i] = da.x; dv[r][i + 1] = da.y; dv[r][i + 2] = da.z; dv[r][i + 3] = da.w;
-            s[r] += (xa.x + xa.y) + (xa.z + xa.w);
+            s[r] += (xv[r][i] + xv[r][i + 1]) + (xv[r][i + 2] + xv[r][i + 3]);
         }
     }
     float mean[LNB_ROWS], rstd[LNB_ROWS], sg[LNB_ROWS], sgx[LNB_ROWS];
@@ -144,13 +179,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 #pragma unroll
     for (int r = 0; r < LNB_ROWS; ++r) rstd[r] = rsqrtf(wave_sum(s[r]) / D + eps);
-    float wv_[NV];
-#pragma unroll
-    for (int i = 0; i < NV; i += 4) {
-        const int e = LN_E(i);
-        const float4 wa = e < D ? *reinterpret_cast<const float4*>(w + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-        wv_[i] = wa.x; wv_[i + 1] = wa.y; wv_[i + 2] = wa.z; wv_[i + 3] = wa.w;
-    }
 #pragma unroll
     for (int r = 0; r < LNB_ROWS; ++r) {
         float a = 0.f, bsum = 0.f;
@@ -173,6 +201,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         sg[r] = wave_sum(sg[r]) / D;
         sgx[r] = wave_sum(sgx[r]) / D;
     }
+    // the finished values of all rows first, then nothing but stores: a load (or anything the compiler must wait for with vmcnt)
+    // between the stores of two rows would wait for the earlier row's stores as well -- loads and stores share the counter
+#pragma unroll
+    for (int r = 0; r < LNB_ROWS; ++r)
+#pragma unroll
+        for (int i = 0; i < NV; i += 4) {
+            float4 aa = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (add) {
+                if constexpr (HOIST) aa = av[r][i >> 2];
+                else aa = *reinterpret_cast<const float4*>(add + rowc[r] * D + (LN_E(i) < D ? LN_E(i) : 0));
+            }
+            const float a4[4] = {aa.x, aa.y, aa.z, aa.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (xv[r][i + k] - mean[r]) * rstd[r];
+                dv[r][i + k] = rstd[r] * (dv[r][i + k] * wv_[i + k] - sg[r] - xh * sgx[r]) + a4[k];
+            }
+        }
 #pragma unroll
     for (int r = 0; r < LNB_ROWS; ++r) {
         if (!live[r]) continue;
@@ -181,21 +227,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         for (int i = 0; i < NV; i += 4) {
             const int e = LN_E(i);
             if (e < D) {
-                float v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float xh = (xv[r][i + k] - mean[r]) * rstd[r];
-                    v[k] = rstd[r] * (dv[r][i + k] * wv_[i + k] - sg[r] - xh * sgx[r]);
-                }
-                if (add) {
-                    const float4 aa = *reinterpret_cast<const float4*>(add + row * D + e);
-                    v[0] += aa.x; v[1] += aa.y; v[2] += aa.z; v[3] += aa.w;
-                }
-                if (dx32) *reinterpret_cast<float4*>(dx32 + row * D + e) = make_float4(v[0], v[1], v[2], v[3]);
+                if (dx32) *reinterpret_cast<float4*>(dx32 + row * D + e) = make_float4(dv[r][i], dv[r][i + 1], dv[r][i + 2], dv[r][i + 3]);
                 if (dx16) {
                     __half hv[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) hv[k] = __float2half(v[k] * out_scale);
+                    for (int k = 0; k < 4; ++k) hv[k] = __float2half(dv[r][i + k] * out_scale);
                     *reinterpret_cast<uint2*>(dx16 + row * D + e) = *reinterpret_cast<const uint2*>(hv);
                 }
             }
