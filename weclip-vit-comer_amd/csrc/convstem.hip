@@ -82,24 +82,23 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
         float acc[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) acc[v] = 0.f;
+        // all nine taps are LOADED (a tap that does not exist for this pixel reads the pixel-independent address dcols + c: one
+        // cached line) and masked by a multiplication: behind the `continue`s hipcc waited for every load before the next one
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const int ty = iy + 1 - ky;
-            if (ty < 0 || ty % stride) continue;
-            const int oy = ty / stride;
-            if (oy >= Ho) continue;
+            const int ty = iy + 1 - ky, oy = ty / stride;
+            const bool oky = ty >= 0 && ty % stride == 0 && oy < Ho;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int tx = ix + 1 - kx;
-                if (tx < 0 || tx % stride) continue;
-                const int ox = tx / stride;
-                if (ox >= Wo) continue;
-                const float* src = dcols + ((n * Ho + oy) * Wo + ox) * Kp + (ky * 3 + kx) * C + c;
+                const int tx = ix + 1 - kx, ox = tx / stride;
+                const bool ok = oky && tx >= 0 && tx % stride == 0 && ox < Wo;
+                const float* src = dcols + (ok ? ((n * Ho + oy) * Wo + ox) * Kp + (ky * 3 + kx) * C : 0) + c;
+                const float msk = ok ? 1.f : 0.f;
                 if constexpr (V == 4) {
                     const float4 t = *reinterpret_cast<const float4*>(src);
-                    acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
+                    acc[0] += t.x * msk; acc[1] += t.y * msk; acc[2] += t.z * msk; acc[3] += t.w * msk;
                 } else {
-                    acc[0] += src[0];
+                    acc[0] += src[0] * msk;
                 }
             }
         }

@@ -198,6 +198,7 @@ __global__ __launch_bounds__(512) void cam_head_kernel(const float* __restrict__
 
 // (c) dx2[p,l,:] = gs * LNpost_bwd(df[p]/(L-1); x2[img,l,:]) for l >= 1, 0 for l = 0.
 //     outputs: fp32 and fp16 hi/lo (GEMM operand).  One wave per row.
+template <int NV>   // NV > 0: E <= 64 * NV, register form; 0: any E
 __global__ __launch_bounds__(256) void lnpost_bwd_kernel(const float* __restrict__ df,
                                                           const float* __restrict__ x2,
                                                           const float* __restrict__ w, float eps, float gs,
@@ -220,27 +221,69 @@ __global__ __launch_bounds__(256) void lnpost_bwd_kernel(const float* __restrict
     const float* xr = x2 + ((long)pair_img[p] * L + l) * E;
     const float* g0 = df + (long)p * E;
     const float invn = 1.0f / (L - 1);
-    float s = 0.f;
-    for (int e = lane; e < E; e += 64) s += xr[e];
-    const float mean = wave_sum(s) / E;
-    float q = 0.f;
-    for (int e = lane; e < E; e += 64) { const float d = xr[e] - mean; q += d * d; }
-    const float rstd = rsqrtf(wave_sum(q) / E + eps);
-    float sg = 0.f, sgx = 0.f;
-    for (int e = lane; e < E; e += 64) {
-        const float g = g0[e] * invn * w[e];
-        sg += g;
-        sgx += g * (xr[e] - mean) * rstd;
-    }
-    sg = wave_sum(sg) / E;
-    sgx = wave_sum(sgx) / E;
-    for (int e = lane; e < E; e += 64) {
-        const float g = g0[e] * invn * w[e];
-        const float v = gs * rstd * (g - sg - (xr[e] - mean) * rstd * sgx);
-        d32[o + e] = v;
-        const __half h = __float2half(v);
-        dhi[o + e] = h;
-        if (dlo) dlo[o + e] = __float2half(v - __half2float(h));
+    if constexpr (NV > 0) {
+        // E <= 64 * NV: the row and its upstream gradient live in registers -- one read of each, all loads of the row in flight
+        // together (clamped addresses, multiplicative mask: see ln2_bwd_add_kernel), the same summation order as the loop form
+        float xv[NV], gv[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = lane + 64 * i, ec = e < E ? e : 0;
+            const float ok = e < E ? 1.f : 0.f;
+            xv[i] = xr[ec] * ok;
+            gv[i] = g0[ec] * invn * w[ec] * ok;
+            s += xv[i];
+        }
+        const float mean = wave_sum(s) / E;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float d = (lane + 64 * i < E) ? xv[i] - mean : 0.f;
+            q += d * d;
+        }
+        const float rstd = rsqrtf(wave_sum(q) / E + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            sg += gv[i];
+            sgx += gv[i] * (xv[i] - mean) * rstd;
+        }
+        sg = wave_sum(sg) / E;
+        sgx = wave_sum(sgx) / E;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = lane + 64 * i;
+            if (e < E) {
+                const float v = gs * rstd * (gv[i] - sg - (xv[i] - mean) * rstd * sgx);
+                d32[o + e] = v;
+                const __half h = __float2half(v);
+                dhi[o + e] = h;
+                if (dlo) dlo[o + e] = __float2half(v - __half2float(h));
+            }
+        }
+    } else {
+        float s = 0.f;
+        for (int e = lane; e < E; e += 64) s += xr[e];
+        const float mean = wave_sum(s) / E;
+        float q = 0.f;
+        for (int e = lane; e < E; e += 64) { const float d = xr[e] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) / E + eps);
+        float sg = 0.f, sgx = 0.f;
+        for (int e = lane; e < E; e += 64) {
+            const float g = g0[e] * invn * w[e];
+            sg += g;
+            sgx += g * (xr[e] - mean) * rstd;
+        }
+        sg = wave_sum(sg) / E;
+        sgx = wave_sum(sgx) / E;
+        for (int e = lane; e < E; e += 64) {
+            const float g = g0[e] * invn * w[e];
+            const float v = gs * rstd * (g - sg - (xr[e] - mean) * rstd * sgx);
+            d32[o + e] = v;
+            const __half h = __float2half(v);
+            dhi[o + e] = h;
+            if (dlo) dlo[o + e] = __float2half(v - __half2float(h));
+        }
     }
 }
 
@@ -263,11 +306,13 @@ __global__ __launch_bounds__(256) void ln2_bwd_add_kernel(const float* __restric
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int e = lane + 64 * i;
-        const bool ok = e < E;
-        xv[i] = ok ? xr[e] : 0.f;
-        gv[i] = ok ? da2[o + e] * w[e] : 0.f;
-        dv[i] = ok ? dx2[o + e] : 0.f;
+        // (clamped addresses and a multiplicative mask: `ok ? load : 0` is compiled into a branch around the load, and behind a
+        //  branch hipcc waits for every load before it issues the next one -- 16 dependent latencies per row)
+        const int e = lane + 64 * i, ec = e < E ? e : 0;
+        const float ok = e < E ? 1.f : 0.f;
+        xv[i] = xr[ec] * ok;
+        gv[i] = da2[o + ec] * w[ec] * ok;
+        dv[i] = dx2[o + ec] * ok;
         s += xv[i];
     }
     const float mean = wave_sum(s) / E;
@@ -680,8 +725,14 @@ extern "C" int wc_lnpost_bwd(const float* df, const float* x2, const float* lnw,
     WC_CHECK_ARG(df && x2 && lnw && pair_img && d32 && dhi && P > 0 && L > 1 && E > 0,
                  "wc_lnpost_bwd: bad argument");
     const long rows = (long)P * L;
-    hipLaunchKernelGGL(lnpost_bwd_kernel, dim3(wc_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, df, x2,
-                       lnw, 1e-5f, gs, pair_img, d32, (__half*)dhi, (__half*)dlo, L, E, rows);
+#define LNPOST_BWD(NV_)                                                                                            \
+    hipLaunchKernelGGL(lnpost_bwd_kernel<NV_>, dim3(wc_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, df, x2, \
+                       lnw, 1e-5f, gs, pair_img, d32, (__half*)dhi, (__half*)dlo, L, E, rows)
+    if (E <= 256) LNPOST_BWD(4);
+    else if (E <= 768) LNPOST_BWD(12);
+    else if (E <= 1024) LNPOST_BWD(16);
+    else LNPOST_BWD(0);
+#undef LNPOST_BWD
     WC_LAUNCH_CHECK("lnpost_bwd_kernel");
     return WC_OK;
 }
@@ -694,6 +745,9 @@ extern "C" int wc_ln2_bwd_add(const float* da2, const float* dx2, const float* x
     WC_CHECK_ARG(E <= 1024, "wc_ln2_bwd_add: E <= 1024");
     if (E <= 256)
         hipLaunchKernelGGL(ln2_bwd_add_kernel<4>, dim3(wc_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, da2,
+                           dx2, x1, lnw, 1e-5f, 1.0f / gs, pair_img, (__half*)g16, L, E, rows);
+    else if (E <= 768)
+        hipLaunchKernelGGL(ln2_bwd_add_kernel<12>, dim3(wc_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, da2,
                            dx2, x1, lnw, 1e-5f, 1.0f / gs, pair_img, (__half*)g16, L, E, rows);
     else
         hipLaunchKernelGGL(ln2_bwd_add_kernel<16>, dim3(wc_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, da2,

@@ -323,14 +323,13 @@ __global__ __launch_bounds__(256) void seg_loss_fused_kernel(const float* __rest
 #pragma unroll
         for (int c = 0; c < NCT; ++c) {
             accT[c] = accB[c] = 0.f;
-            av[c] = dv[c] = 0.f;
-            if (c < nc) {
-                const float* Sc = S + (long)c * h * w;
-                const float a = (1.f - lx) * Sc[ys * w + x0] + lx * Sc[ys * w + x1];
-                const float bb = (1.f - lx) * Sc[y1s * w + x0] + lx * Sc[y1s * w + x1];
-                av[c] = a;
-                dv[c] = bb - a;
-            }
+            // (classes past nc read class nc - 1 and are masked: behind an `if (c < nc)` hipcc waited for the four loads of a
+            //  class before issuing the next class's -- 24 dependent latencies at the head of every thread)
+            const float* Sc = S + (long)min(c, nc - 1) * h * w;
+            const float a = (1.f - lx) * Sc[ys * w + x0] + lx * Sc[ys * w + x1];
+            const float bb = (1.f - lx) * Sc[y1s * w + x0] + lx * Sc[y1s * w + x1];
+            av[c] = c < nc ? a : 0.f;
+            dv[c] = c < nc ? bb - a : 0.f;
         }
         const float iy = 1.0f / sy;
         int y_lo = ys == 0 ? 0 : (int)floorf((ys + 0.5f) * iy - 0.5f) - 1;

@@ -358,19 +358,38 @@ __global__ __launch_bounds__(256) void sigmoid_gram_bwd_kernel(const float* __re
 }
 
 // out32[r,c] = x[r,c] * cs[(r / rpb), c];  hi/lo = fp16 split of it   (dropout-mask backward + operand split)
+// V = 4: four consecutive values per thread (C % 4 == 0, 16-byte aligned buffers): 16-byte loads, 8-byte fp16 stores -- the
+// one-value-per-thread form issued 22 M threads for an 86 016 x 256 operand and ran at a third of the HBM rate.
+template <int V>
 __global__ __launch_bounds__(256) void colscale_split_kernel(const float* __restrict__ x, const float* __restrict__ cs,
                                                               float* __restrict__ out32, __half* __restrict__ hi,
                                                               __half* __restrict__ lo, long rows, int C, int rpb,
                                                               float alpha) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * V;
     if (i >= rows * C) return;
     const long r = i / C;
     const int c = i - r * C;
-    const float v = alpha * x[i] * (cs ? cs[(r / rpb) * C + c] : 1.f);
-    if (out32) out32[i] = v;
-    const __half h = __float2half(v);
-    hi[i] = h;
-    if (lo) lo[i] = __float2half(v - __half2float(h));
+    float v[V];
+    if constexpr (V == 4) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + i);
+        const float4 sv = cs ? *reinterpret_cast<const float4*>(cs + (r / rpb) * C + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+        v[0] = alpha * xv.x * sv.x; v[1] = alpha * xv.y * sv.y; v[2] = alpha * xv.z * sv.z; v[3] = alpha * xv.w * sv.w;
+        if (out32) *reinterpret_cast<float4*>(out32 + i) = make_float4(v[0], v[1], v[2], v[3]);
+        __half h[4], l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            h[k] = __float2half(v[k]);
+            l[k] = __float2half(v[k] - __half2float(h[k]));
+        }
+        *reinterpret_cast<uint2*>(hi + i) = *reinterpret_cast<const uint2*>(h);
+        if (lo) *reinterpret_cast<uint2*>(lo + i) = *reinterpret_cast<const uint2*>(l);
+    } else {
+        v[0] = alpha * x[i] * (cs ? cs[(r / rpb) * C + c] : 1.f);
+        if (out32) out32[i] = v[0];
+        const __half h = __float2half(v[0]);
+        hi[i] = h;
+        if (lo) lo[i] = __float2half(v[0] - __half2float(h));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -464,8 +483,13 @@ extern "C" int wc_sigmoid_gram_bwd(const float* dAP, const float* AP, void* hi, 
 extern "C" int wc_colscale_split(const float* x, const float* cs, float* out32, void* hi, void* lo, long rows, int C,
                                  int rows_per_batch, float alpha, void* stream) {
     WC_CHECK_ARG(x && hi && rows > 0 && C > 0 && rows_per_batch > 0, "wc_colscale_split: bad argument");
-    hipLaunchKernelGGL(colscale_split_kernel, dim3(wc_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, x, cs,
-                       out32, (__half*)hi, (__half*)lo, rows, C, rows_per_batch, alpha);
+    const bool vec = C % 4 == 0 && ((uintptr_t)x | (uintptr_t)cs | (uintptr_t)out32) % 16 == 0 && ((uintptr_t)hi | (uintptr_t)lo) % 8 == 0;
+    if (vec)
+        hipLaunchKernelGGL(colscale_split_kernel<4>, dim3(wc_cdiv(rows * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, cs,
+                           out32, (__half*)hi, (__half*)lo, rows, C, rows_per_batch, alpha);
+    else
+        hipLaunchKernelGGL(colscale_split_kernel<1>, dim3(wc_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, x, cs,
+                           out32, (__half*)hi, (__half*)lo, rows, C, rows_per_batch, alpha);
     WC_LAUNCH_CHECK("colscale_split_kernel");
     return WC_OK;
 }
