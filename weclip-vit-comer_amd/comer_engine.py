@@ -36,7 +36,9 @@ GS = 4096.0
 INV = 1.0 / GS
 
 
-_WGRAD_WGS = int(__import__('os').environ.get('CB_WGRAD_WGS', '256'))     # (experiment hook of tools/comer_bench.py)
+# workgroups a split-K weight-gradient GEMM may use: the inserts reduce ~50 partial sets per step, so fewer, longer slices pay
+# (inserts alone, same box: 1024 -> 12.99, 512 -> 12.91, 256 -> 12.82, 128 -> 12.44 vs 11.92 ms at 256 after the load fixes)
+_WGRAD_WGS = 256
 
 
 def _shape_array(shapes):

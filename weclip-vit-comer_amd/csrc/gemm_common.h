@@ -139,20 +139,36 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, ACC& acc, int m
         // act 4: the fp32 aux rows (row-mapped, 16 B per lane and row) of chunk c+1 are requested before chunk c is
         // processed, so their HBM latency hides behind one chunk of epilogue work instead of stalling every chunk
         float ua[2][4][4];
+        // (the four row-map entries of a chunk are requested together, then the four 16-byte aux rows, all from clamped addresses
+        //  and masked afterwards: behind per-row bounds branches hipcc waited for each row-map load AND each aux load in turn --
+        //  eight dependent latencies per chunk)
         auto aux_load = [&](int c, float (&dst)[4][4]) {
+            long arow[4];
+            bool okr[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int grow = m0 + wr * 64 + c * 16 + it * 4 + (lane >> 4);
-                dst[it][0] = dst[it][1] = dst[it][2] = dst[it][3] = 0.f;
-                if (grow < g.M && gcol < g.N && (NI == 2 || c4 < 32)) {
-                    const long arow = g.rowmap ? (long)g.rowmap[(grow + g.row0) / g.rpg] * g.rpg + (grow + g.row0) % g.rpg : grow;
-                    const float* up = g.aux + arow * g.ldaux + gcol;
-                    if (full) {
-                        const float4 u4 = *reinterpret_cast<const float4*>(up);
-                        dst[it][0] = u4.x; dst[it][1] = u4.y; dst[it][2] = u4.z; dst[it][3] = u4.w;
-                    } else {
-                        for (int k = 0; k < 4 && gcol + k < g.N; ++k) dst[it][k] = up[k];
-                    }
+                okr[it] = grow < g.M && gcol < g.N && (NI == 2 || c4 < 32);
+                arow[it] = grow < g.M ? grow : g.M - 1;
+            }
+            if (g.rowmap) {
+                int mi_[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) mi_[it] = g.rowmap[(arow[it] + g.row0) / g.rpg];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) arow[it] = (long)mi_[it] * g.rpg + (arow[it] + g.row0) % g.rpg;
+            }
+            float4 u4[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) u4[it] = *reinterpret_cast<const float4*>(g.aux + arow[it] * g.ldaux + (full ? gcol : 0));
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const bool k4 = okr[it] && full;
+                dst[it][0] = k4 ? u4[it].x : 0.f; dst[it][1] = k4 ? u4[it].y : 0.f;
+                dst[it][2] = k4 ? u4[it].z : 0.f; dst[it][3] = k4 ? u4[it].w : 0.f;
+                if (okr[it] && !full) {          // the ragged last columns of an N % 4 != 0 output
+                    const float* up = g.aux + arow[it] * g.ldaux + gcol;
+                    for (int k = 0; k < 4 && gcol + k < g.N; ++k) dst[it][k] = up[k];
                 }
             }
         };

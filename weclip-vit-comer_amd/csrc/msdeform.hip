@@ -465,6 +465,7 @@ __global__ __launch_bounds__(256) void msda_absmax_kernel(const GT* __restrict__
 // {row of grad_out = query * M + head, bit pattern of bilinear weight * attention weight}.  (Round 4: the entries were pair ids,
 // and the gather re-derived row and weight from loc / attn with two dependent random loads per pair.)
 #define MSDA_VT 1024
+#define MSDA_UN 4              // samples per thread whose loads are in flight together
 __global__ __launch_bounds__(MSDA_VT) void msda_bucket_kernel(const float* __restrict__ loc, const float* __restrict__ attn,
                                                            int* __restrict__ ws, MsdaShapes sh, int S, int Lq, int M, int P, int N) {
     extern __shared__ int sm[];
@@ -481,16 +482,30 @@ __global__ __launch_bounds__(MSDA_VT) void msda_bucket_kernel(const float* __res
     int* list = ws + 2 * NMS + (((long)n * M + m) * sh.n_levels + l) * nsamp * 8;
     for (int i = tid; i < HW; i += MSDA_VT) { cnt[i] = 0; cur[i] = 0; }
     __syncthreads();
-    for (long e = tid; e < nsamp; e += MSDA_VT) {
+    // (both passes: the locations [and weights] of MSDA_UN samples per thread are requested together from clamped addresses --
+    //  one sample per iteration exposed a scattered-load latency per sample, 21 per pass at 5 376 queries x 4 points)
+    auto loc_of = [&](long e) {
         const int q = (int)(e / P), p = (int)(e - (long)q * P);
-        const float* lb = loc + ((((long)n * Lq + q) * M + m) * sh.n_levels + l) * P * 2 + p * 2;
-        const float x = lb[0] * W - 0.5f, y = lb[1] * H - 0.5f;
-        if (!(y > -1.f && x > -1.f && y < H && x < W)) continue;
-        const int y0 = (int)floorf(y), x0 = (int)floorf(x);
+        return loc + ((((long)n * Lq + q) * M + m) * sh.n_levels + l) * P * 2 + p * 2;
+    };
+    for (long e0 = tid; e0 < nsamp; e0 += MSDA_UN * MSDA_VT) {
+        float lx_[MSDA_UN], ly_[MSDA_UN];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int px = x0 + (c & 1), py = y0 + (c >> 1);
-            if (px >= 0 && px < W && py >= 0 && py < H) atomicAdd(&cnt[py * W + px], 1);
+        for (int u = 0; u < MSDA_UN; ++u) {
+            const float* lb = loc_of(min(e0 + (long)u * MSDA_VT, nsamp - 1));
+            lx_[u] = lb[0];
+            ly_[u] = lb[1];
+        }
+#pragma unroll
+        for (int u = 0; u < MSDA_UN; ++u) {
+            const float x = lx_[u] * W - 0.5f, y = ly_[u] * H - 0.5f;
+            if (e0 + (long)u * MSDA_VT >= nsamp || !(y > -1.f && x > -1.f && y < H && x < W)) continue;
+            const int y0 = (int)floorf(y), x0 = (int)floorf(x);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int px = x0 + (c & 1), py = y0 + (c >> 1);
+                if (px >= 0 && px < W && py >= 0 && py < H) atomicAdd(&cnt[py * W + px], 1);
+            }
         }
     }
     __syncthreads();
@@ -512,23 +527,36 @@ __global__ __launch_bounds__(MSDA_VT) void msda_bucket_kernel(const float* __res
     int run = base + incl - tsum;
     for (int i = c0; i < c1; ++i) { const int v = cnt[i]; cnt[i] = run; gstart[i] = run; gsize[i] = v; run += v; }
     __syncthreads();
-    for (long e = tid; e < nsamp; e += MSDA_VT) {
-        const int q = (int)(e / P), p = (int)(e - (long)q * P);
-        const float* lb = loc + ((((long)n * Lq + q) * M + m) * sh.n_levels + l) * P * 2 + p * 2;
-        const float x = lb[0] * W - 0.5f, y = lb[1] * H - 0.5f;
-        if (!(y > -1.f && x > -1.f && y < H && x < W)) continue;
-        const int y0 = (int)floorf(y), x0 = (int)floorf(x);
-        const float lx = x - floorf(x), ly = y - floorf(y);
-        const long qm = ((long)n * Lq + q) * M + m;
-        const float aw = attn[(qm * sh.n_levels + l) * P + p];
+    for (long e0 = tid; e0 < nsamp; e0 += MSDA_UN * MSDA_VT) {
+        float lx_[MSDA_UN], ly_[MSDA_UN], aw_[MSDA_UN];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int px = x0 + (c & 1), py = y0 + (c >> 1);
-            if (px >= 0 && px < W && py >= 0 && py < H) {
-                const int pix = py * W + px;
-                const int pos = cnt[pix] + atomicAdd(&cur[pix], 1);
-                const float wgt = ((c & 1) ? lx : 1.f - lx) * ((c >> 1) ? ly : 1.f - ly) * aw;
-                *reinterpret_cast<int2*>(list + 2 * (long)pos) = make_int2((int)qm, __float_as_int(wgt));
+        for (int u = 0; u < MSDA_UN; ++u) {
+            const long e = min(e0 + (long)u * MSDA_VT, nsamp - 1);
+            const float* lb = loc_of(e);
+            lx_[u] = lb[0];
+            ly_[u] = lb[1];
+            const int q = (int)(e / P), p = (int)(e - (long)q * P);
+            aw_[u] = attn[((((long)n * Lq + q) * M + m) * sh.n_levels + l) * P + p];
+        }
+#pragma unroll
+        for (int u = 0; u < MSDA_UN; ++u) {
+            const long e = e0 + (long)u * MSDA_VT;
+            const float x = lx_[u] * W - 0.5f, y = ly_[u] * H - 0.5f;
+            if (e >= nsamp || !(y > -1.f && x > -1.f && y < H && x < W)) continue;
+            const int q = (int)(e / P);
+            const int y0 = (int)floorf(y), x0 = (int)floorf(x);
+            const float lx = x - floorf(x), ly = y - floorf(y);
+            const long qm = ((long)n * Lq + q) * M + m;
+            const float aw = aw_[u];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int px = x0 + (c & 1), py = y0 + (c >> 1);
+                if (px >= 0 && px < W && py >= 0 && py < H) {
+                    const int pix = py * W + px;
+                    const int pos = cnt[pix] + atomicAdd(&cur[pix], 1);
+                    const float wgt = ((c & 1) ? lx : 1.f - lx) * ((c >> 1) ? ly : 1.f - ly) * aw;
+                    *reinterpret_cast<int2*>(list + 2 * (long)pos) = make_int2((int)qm, __float_as_int(wgt));
+                }
             }
         }
     }

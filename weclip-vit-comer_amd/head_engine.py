@@ -21,7 +21,7 @@ from .clip import vit_engine as VE
 from .ops import F16, F32, Split
 
 GRAD_SCALE = 4096.0
-_WGRAD_WGS = 512   # workgroups a split-K weight-gradient GEMM may use
+_WGRAD_WGS = 512   # workgroups a split-K weight-gradient GEMM may use (round 4, same box: 512 -> 12.71, 256 -> 12.90, 128 -> 13.27 ms per step)
 
 
 def _f(p):
