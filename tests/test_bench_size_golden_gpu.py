@@ -144,7 +144,7 @@ def test_cam_chain_at_512_matches_reference(golden, request, seg_trans, precisio
     # cam_map 4.9e-4, affinity 1.8e-4, trans_rows 2.0e-4, refined 2.2e-4, par 3.4e-4, seg 8.4e-4, attn_pred 5.5e-3 abs
     # (sigmoid of a 256-long Gram product of fp16-rounded adapter outputs), labels 0.012 % of the pixels)
     # attn_pred = sigmoid(F^T F): the Gram product already runs on hi+lo operands in `fast`; tools/head_lo_probe.py (round 3)
-    # shows where the rest comes from: every operand of the adapter -> fuse chain hi+lo (WECLIP_HEAD_LO=63) still leaves
+    # shows where the rest comes from: every operand of the adapter -> fuse chain hi+lo (config.head_lo = 63) still leaves
     # 3.2e-3, i.e. the fast encoder's token error (3.4e-4 relative) amplified ~10x by the 256-long Gram of width-256
     # features; `exact` measures 9.6e-4.  In front of the sigmoid that is |dG| = 0.025 on Gram entries of magnitude up to
     # 9.2 (93 % of the entries lie beyond and saturate), i.e. a few 1e-4 of the largest entries.

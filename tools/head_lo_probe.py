@@ -1,4 +1,4 @@
-"""attn_pred / seg error at 512^2 against the reference fixture for every WECLIP_HEAD_LO mask of interest, and the head's time."""
+"""attn_pred / seg error at 512^2 against the reference fixture for every config.head_lo mask of interest, and the head's time."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -17,7 +17,7 @@ def exact():
 # remainder (hi+lo) in the FORWARD GEMMs.  Bit mask: 1 = cat (fuse input), 2 = linear_fuse weight, 4 = t1 (proj output),
 # 8 = proj_2 weights, 16 = proj weights, 32 = the encoder's block outputs (the adapters' input).  attn_pred squares F's rounding error (256-long Gram product) and feeds
 # get_aff_loss and the seg-trans affinity; measured at 512^2 against the reference fixture: see DESIGN.md §3.
-head_lo = int(os.environ.get("WECLIP_HEAD_LO", "0"))
+head_lo = 0            # (an attribute, not an environment switch: tools/head_lo_probe.py sets it per measurement)
 
 # `fast` precision only: PAR affinities kept as 16-bit fixed point between the sweeps (csrc/par.hip wc_par_forward_h); False =
 # fp32 affinities like the reference (WeCLIP_model/PAR.py:64-92) with the fast GEMMs unchanged.

@@ -562,27 +562,38 @@ __global__ __launch_bounds__(MSDA_VT) void msda_bucket_kernel(const float* __res
     }
 }
 
-// grid: ceil(S / (256 / D)) x M x N workgroups of 256 threads = 256 / D pixels x D lanes.
-// The D lanes of a pixel work as SL = 16 / sizeof(GT) pair SLOTS of CL = D / SL lanes: a slot fetches one pair's grad_out row
-// (D values) as 16 bytes per lane, so a wave instruction moves SL rows per pixel group -- 512 B per 32 lanes at fp16 -- where
-// the round-3 form (one value per lane, one pair per group and instruction) moved 64 B; the bucket entries already hold the
-// row and the weight (no dependent loads).  A lane accumulates its 16 / sizeof(GT) channels over its slot's pairs in 64-bit
-// FIXED POINT (2^24 / max|grad_out| per product, 64-bit sums); the SL slots are added at the end -- integer sums, so the result
-// does not depend on the bucket order or on the slot a pair falls into (bit-reproducible).
+// grid: (blocks of all levels) x M x N workgroups of 256 threads.  A pixel is served by GL lanes, GL chosen PER LEVEL by the
+// launcher from the level's mean bucket length (GatherPlan): the GL lanes work as SL = GL / CL pair SLOTS of CL = D / VEC lanes
+// (VEC = 16 / sizeof(GT) channels per lane): a slot fetches one pair's grad_out row (D values) as 16 bytes per lane -- 512 B per
+// 32 lanes at fp16, where the round-3 form (one value per lane, one pair per group and instruction) moved 64 B; the bucket entries
+// already hold the row and the weight (no dependent loads).  With D lanes per pixel on every level (the first round-4 form) a
+// level whose buckets hold ~4 entries (the 64 x 64 map of the three-level direction: 76 % of its pixels) kept 7 of 8 slots idle
+// and paid the three dependent latencies of a pixel (bucket bounds -> entries -> rows) for 4 useful loads: 1.6 TB/s algorithmic,
+// against 7.9 TB/s for the one-level direction with ~84 entries per bucket; 4 lanes per pixel there put 8x the pixels in flight.
+// A lane accumulates its VEC channels over its slot's pairs in 64-bit FIXED POINT (2^24 / max|grad_out| per product, 64-bit
+// sums); the slots are added at the end -- integer sums, so the result does not depend on the bucket order, on the slot a pair
+// falls into or on GL (bit-reproducible).
+struct GatherPlan {
+    int blk0[MSDA_MAX_LEVELS + 1];       // first workgroup of each level (+ total)
+    int gl[MSDA_MAX_LEVELS];             // lanes per pixel of the level: CL, 2 CL, ... <= D
+};
+
 template <typename GT>
 __global__ __launch_bounds__(256) void msda_gather_kernel(const GT* __restrict__ gout, const unsigned int* __restrict__ gmax,
                                                            const int* __restrict__ ws, float* __restrict__ gvalue,
-                                                           __half* __restrict__ gvalue16, MsdaShapes sh,
+                                                           __half* __restrict__ gvalue16, MsdaShapes sh, GatherPlan plan,
                                                            int S, int Lq, int M, int D, int P, int N) {
-    constexpr int VEC = 16 / sizeof(GT);                 // channels per lane = pair slots per pixel group
+    constexpr int VEC = 16 / sizeof(GT);                 // channels per lane
     const int m = blockIdx.y, n = blockIdx.z;
-    const int grp = threadIdx.x / D, d = threadIdx.x - grp * D;
-    const int s = blockIdx.x * (256 / D) + grp;              // pixel index over all levels
-    if (s >= S) return;                                      // (a whole group leaves together: D divides 64)
-    const int CL = D / VEC;                                  // lanes per pair
-    const int slot = d / CL, ch = (d - slot * CL) * VEC;     // this lane's pair slot and first channel
     int l = 0;
-    while (l + 1 < sh.n_levels && s >= sh.start[l + 1]) ++l;
+    while (l + 1 < sh.n_levels && (int)blockIdx.x >= plan.blk0[l + 1]) ++l;        // (uniform: a workgroup serves one level)
+    const int GL = plan.gl[l];
+    const int grp = threadIdx.x / GL, d = threadIdx.x - grp * GL;
+    const int pix = ((int)blockIdx.x - plan.blk0[l]) * (256 / GL) + grp;
+    if (pix >= sh.H[l] * sh.W[l]) return;                    // (a whole group leaves together: GL divides 64)
+    const int s = sh.start[l] + pix;                         // pixel index over all levels
+    const int CL = D / VEC, SL = GL / CL;                    // lanes per pair, pair slots of the pixel
+    const int slot = d / CL, ch = (d - slot * CL) * VEC;     // this lane's pair slot and first channel
     const long nsamp = (long)Lq * P;
     const long NMS = (long)N * M * S;
     const long pm = ((long)n * M + m) * S + s;
@@ -597,28 +608,25 @@ __global__ __launch_bounds__(256) void msda_gather_kernel(const GT* __restrict__
     long long acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = 0;
-    for (int k0 = 0; k0 < nb; k0 += D) {
+    for (int k0 = 0; k0 < nb; k0 += GL) {
         int part[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) part[v] = 0;
-        // lane j holds entry k0 + j of the bucket (coalesced 8-byte reads); rows / weights travel to their slots by shuffles
-        int rowj = 0;
-        float wj = 0.f;
-        if (k0 + d < nb) {
-            const int2 e = list[k0 + d];
-            rowj = e.x;
-            wj = __int_as_float(e.y) * scale;
-        }
-        const int cntk = min(D, nb - k0);
-        for (int k = 0; k < cntk; k += 4 * VEC) {            // 4 rounds of SL pairs: four 16-byte loads in flight per lane
+        // lane j holds entry k0 + j of the bucket (coalesced 8-byte reads; clamped index, masked weight: no branch around the
+        // load); rows / weights travel to their slots by shuffles
+        const int2 e = list[min(k0 + d, nb - 1)];
+        const int rowj = e.x;
+        const float wj = __int_as_float(e.y) * scale * (k0 + d < nb ? 1.f : 0.f);
+        const int cntk = min(GL, nb - k0);
+        for (int k = 0; k < cntk; k += 4 * SL) {             // 4 rounds of SL pairs: four 16-byte loads in flight per lane
             GT gk[4][VEC];
             float wk[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int kk = k + u * VEC + slot;
+                const int kk = k + u * SL + slot;
                 const int kc = kk < cntk ? kk : 0;            // (clamped: the weight of a padded slot is zeroed)
-                const long row = (long)__shfl(rowj, kc, D) * D;
-                const float wsh = __shfl(wj, kc, D);      // (every lane of the group takes part: the condition below differs per slot,
+                const long row = (long)__shfl(rowj, kc, GL) * D;
+                const float wsh = __shfl(wj, kc, GL);     // (every lane of the group takes part: the condition below differs per slot,
                 wk[u] = kk < cntk ? wsh : 0.f;            //  and a lane skipped by a conditional shuffle cannot serve as a source)
                 *reinterpret_cast<u32x4*>(gk[u]) = *reinterpret_cast<const u32x4*>(gout + row + ch);
             }
@@ -631,11 +639,11 @@ __global__ __launch_bounds__(256) void msda_gather_kernel(const GT* __restrict__
         for (int v = 0; v < VEC; ++v) acc[v] += part[v];
     }
     // add the SL slots: lanes d, d + CL, d + 2 CL, ... hold the same channels
-    for (int o = CL; o < D; o <<= 1) {
+    for (int o = CL; o < GL; o <<= 1) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            const int lo = __shfl_xor((int)(acc[v] & 0xffffffffLL), o, D);
-            const int hi = __shfl_xor((int)(acc[v] >> 32), o, D);
+            const int lo = __shfl_xor((int)(acc[v] & 0xffffffffLL), o, GL);
+            const int hi = __shfl_xor((int)(acc[v] >> 32), o, GL);
             acc[v] += ((long long)hi << 32) | (unsigned int)lo;
         }
     }
@@ -740,6 +748,8 @@ static int msda_bwd_value(const float* loc, const float* attn, const GT* gout, f
     WC_CHECK_ARG(maxhw <= 16384 && ws, "wc_msda_bwd: a level may have at most 16384 pixels; ws workspace missing");
     WC_CHECK_ARG(((uintptr_t)gout | (uintptr_t)gvalue | (uintptr_t)gvalue16 | (uintptr_t)ws) % 16 == 0 && D % (16 / (int)sizeof(GT)) == 0,
                  "wc_msda_bwd: grad_out / grad_value / ws must be 16-byte aligned (16-byte gathers)");
+    WC_CHECK_ARG(D <= 64 && (D & (D - 1)) == 0 && D >= 16 / (int)sizeof(GT),
+                 "wc_msda_bwd: the head width must be a power of two of at most 64 (lane groups of the gather)");
     static bool attr_set = false;
     if (!attr_set) {
         WC_CHECK_ARG(hipFuncSetAttribute((const void*)msda_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess,
@@ -750,11 +760,22 @@ static int msda_bwd_value(const float* loc, const float* attn, const GT* gout, f
                        sh, S, Lq, M, P, N);
     WC_LAUNCH_CHECK("msda_bucket_kernel");
     const int prg = wc_prof_begin(st);
-    hipLaunchKernelGGL(msda_gather_kernel<GT>, dim3(wc_cdiv(S, 256 / D), M, N), dim3(256), 0, st, gout,
-                       (const unsigned int*)gmax, (const int*)ws, gvalue, (__half*)gvalue16, sh, S, Lq, M, D, P, N);
+    // lanes per pixel, per level: the smallest power-of-two multiple of CL that covers the level's mean bucket length
+    GatherPlan plan;
+    const int CL = D / (16 / (int)sizeof(GT));
+    plan.blk0[0] = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const long hw = (long)sh.H[l] * sh.W[l], mean = ((long)Lq * P * 4 + hw - 1) / hw;
+        int gl = CL;
+        while (gl < D && gl < mean) gl <<= 1;
+        plan.gl[l] = gl;
+        plan.blk0[l + 1] = plan.blk0[l] + (int)wc_cdiv(hw, 256 / gl);
+    }
+    hipLaunchKernelGGL(msda_gather_kernel<GT>, dim3(plan.blk0[n_levels], M, N), dim3(256), 0, st, gout,
+                       (const unsigned int*)gmax, (const int*)ws, gvalue, (__half*)gvalue16, sh, plan, S, Lq, M, D, P, N);
     // one dh-row of the output gradient per (sample, corner) pair (all corners inside: the upper bound) + the pair id, its
     // location / weight (12 B) + the value-gradient rows written
-    wc_prof_end2(prg, "msda_gather_kernel", 0.0,
+    wc_prof_end2(prg, n_levels == 1 ? "msda_gather_kernel<1>" : "msda_gather_kernel<n>", 0.0,
                  (double)N * Lq * M * n_levels * P * 4 * ((double)D * sizeof(GT) + 8) +
                      (double)N * S * M * D * ((gvalue ? 4 : 0) + (gvalue16 ? 2 : 0)), st);
     WC_LAUNCH_CHECK("msda_gather_kernel");
