@@ -18,7 +18,7 @@ struct CmLevels {
     int sstart[CM_MAX_LEVELS], nstrips;      // horizontal strips of 8 pixels (depth-wise conv kernels): first strip per level, total
 };
 
-__device__ __forceinline__ float cm_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float cm_gelu(float x) { return wc_gelu(x); }
 
 // Depth-wise kernels: a thread owns one channel of a horizontal STRIP of CM_SW consecutive pixels of one map row, so a row
 // segment of CM_SW + k - 1 inputs loaded once serves all k taps of the strip's pixels (3.75 / 7.5 loads per output for the

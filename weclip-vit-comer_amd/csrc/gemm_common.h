@@ -67,7 +67,7 @@ struct GemmArgs {
         _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_) (v_)[e_] = __builtin_amdgcn_rcpf(1.0f + __expf(-(v_)[e_])); \
     } else if (ERF && act == 6) {      /* (erff costs registers: only in the builds that serve act 6 / 7) */ \
         _Pragma("unroll") for (int e_ = 0; e_ < (n_); ++e_)                                       \
-            (v_)[e_] = 0.5f * (v_)[e_] * (1.0f + erff((v_)[e_] * 0.70710678118654752f));          \
+            (v_)[e_] = wc_gelu((v_)[e_]);                                                                  \
     }
 
 // Per-column epilogue constants of a lane's two output columns (bias, scale): fetched BEFORE the K loop of a
@@ -230,7 +230,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, ACC& acc, int m
                         const float (&u)[4] = ua[c & 1][it];
 #pragma unroll
                         for (int k = 0; k < 4; ++k)      // d/du [u * Phi(u)] = Phi(u) + u * phi(u)
-                            f[it][k] *= 0.5f * (1.0f + erff(u[k] * 0.70710678118654752f)) + u[k] * 0.3989422804014327f * __expf(-0.5f * u[k] * u[k]);
+                            f[it][k] *= wc_gelu_grad(u[k]);
                     } else if (!ERF) {
                         const __half* hp = g.auxh + xb + (long)grow * g.ldaux + gcol;
                         if (full && g.auxvec) {          // one 8-byte load of the four saved activations
@@ -339,7 +339,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, ACC& acc, int m
                     } else if (ERF && act == 7) {
                         const long arow = g.rowmap ? (long)g.rowmap[(row + g.row0) / g.rpg] * g.rpg + (row + g.row0) % g.rpg : row;
                         const float u = g.aux[arow * g.ldaux + colc];
-                        uv[r] = 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
+                        uv[r] = wc_gelu_grad(u);
                     } else if (!ERF) {
                         uv[r] = __half2float(g.auxh[xb + (long)row * g.ldaux + colc]) > 0.f ? 1.f : 0.f;   // ReLU'
                     }

@@ -36,8 +36,11 @@ struct KmArgs {
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
 
-__global__ __launch_bounds__(256, 2) void gemm_km_kernel(KmArgs g) {
-    // ring of 4 stages x [32 tokens]: [A tile 8 KiB | X tile 8 KiB]; three stages in flight while one is consumed,
+// NST = stages of the ring: 4 (64 KiB: two workgroups per CU, 2 x 48 KiB in flight) or 8 (128 KiB: for grids of at most one
+// workgroup per CU, which with four stages had 48 KiB in flight per CU and ran at one memory latency per three stages).
+template <int NST>
+__global__ __launch_bounds__(256, NST == 4 ? 2 : 1) void gemm_km_kernel(KmArgs g) {
+    // ring of NST stages x [32 tokens]: [A tile 8 KiB | X tile 8 KiB]; NST - 1 stages in flight while one is consumed,
     // counted vmcnt waits + raw s_barrier (a __syncthreads() drains every outstanding LDS-DMA: with 2 stages of 64
     // tokens the loop ran at one global-memory latency per stage)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -139,18 +142,25 @@ __global__ __launch_bounds__(256, 2) void gemm_km_kernel(KmArgs g) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
 
-    // KM_LOAD advances the token -> X row map, so the stages must be requested in order: 0, 1, 2, then t + 3 in the loop
-    if (nt > 0) KM_LOAD(0, 0);
-    if (nt > 1) KM_LOAD(1, 1);
-    if (nt > 2) KM_LOAD(2, 2);
+    // KM_LOAD advances the token -> X row map, so the stages must be requested in order: 0 .. NST-2, then t + NST-1 in the loop
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0)
+        if (s0 < nt) KM_LOAD(s0, s0);
     for (int t = 0; t < nt; ++t) {
-        const int buf = t & 3;
-        // stage t has landed once at most the requests of stages t+1, t+2 (4 DMA instructions each) are outstanding
-        if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int buf = t & (NST - 1);
+        // stage t has landed once at most the requests of stages t+1 .. t+NST-2 (4 DMA instructions each) are outstanding
+        const int ahead = nt - 1 - t < NST - 2 ? nt - 1 - t : NST - 2;
+        switch (ahead) {
+            case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
         __builtin_amdgcn_s_barrier();     // every wave's part of stage t is in LDS; stage t-1's buffer is free
-        if (t + 3 < nt) KM_LOAD(t + 3, (t + 3) & 3);
+        if (t + NST - 1 < nt) KM_LOAD(t + NST - 1, (t + NST - 1) & (NST - 1));
         // Fragment reads as inline asm: hipcc puts a full `s_waitcnt vmcnt(0)` in front of the ds_read_tr builtin
         // whenever LDS-DMA is outstanding (it cannot tell which LDS bytes the DMA writes), which would drain the ring.
         // Both k-steps' 16 transposing reads are issued, then one lgkmcnt(0) that carries the registers.
@@ -262,7 +272,19 @@ extern "C" int wc_gemm_km_f16_grouped(const void* dY, long lda, const void* X, l
     dim3 grid((unsigned)(g.tiles * g.units));
     const int pr = wc_prof_begin(stream);
     const int sl = shape_log_begin(stream);
-    hipLaunchKernelGGL(gemm_km_kernel, grid, dim3(256), 4 * 64 * 256, (hipStream_t)stream, g);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            n_cu <= 0)
+            n_cu = 256;
+        WC_CHECK_ARG(hipFuncSetAttribute((const void*)gemm_km_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 256) == hipSuccess,
+                     "wc_gemm_km_f16: cannot reserve 128 KiB of LDS");
+    }
+    if ((long)g.tiles * g.units <= n_cu)      // at most one workgroup per CU: the deep ring
+        hipLaunchKernelGGL(gemm_km_kernel<8>, grid, dim3(256), 8 * 64 * 256, (hipStream_t)stream, g);
+    else
+        hipLaunchKernelGGL(gemm_km_kernel<4>, grid, dim3(256), 4 * 64 * 256, (hipStream_t)stream, g);
     shape_log_end(sl, "km", M, N, K1, 1, groups, ns, 0, stream);
     wc_prof_end(pr, "gemm_km_kernel", 2.0 * M * N * K1 * groups, stream);
     WC_LAUNCH_CHECK("gemm_km_kernel");

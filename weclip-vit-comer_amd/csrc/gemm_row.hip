@@ -168,13 +168,21 @@ __global__ __launch_bounds__(256, 2) void gemm_row_kernel(RowArgs g) {
     // column constants in LDS (bias, column scale, two LayerNorm gamma / beta sets): as registers they would not fit beside
     // the 128 weight registers, as global loads inside the row phase their waits would drain the stores issued before them
     {
+        // (six loads issued together, a missing vector reading one dummy word of W; the pin keeps hipcc from sinking them back
+        //  under their conditions, where each was waited for alone: five dependent L2 latencies at the head of every workgroup)
         const int n = tid < g.N ? tid : g.N - 1;
-        Ct[tid] = g.bias ? g.bias[n] : 0.f;
-        Ct[256 + tid] = g.cscale ? g.cscale[n] : 1.f;
-        Ct[512 + tid] = g.ln_o[0] ? g.ln_g[0][n] : 0.f;
-        Ct[768 + tid] = g.ln_o[0] ? g.ln_b[0][n] : 0.f;
-        Ct[1024 + tid] = g.ln_o[1] ? g.ln_g[1][n] : 0.f;
-        Ct[1280 + tid] = g.ln_o[1] ? g.ln_b[1][n] : 0.f;
+        const float* dz = reinterpret_cast<const float*>(g.W);
+        const bool l0 = g.ln_o[0] != nullptr, l1 = g.ln_o[1] != nullptr;
+        float r0 = (g.bias ? g.bias : dz)[g.bias ? n : 0], r1 = (g.cscale ? g.cscale : dz)[g.cscale ? n : 0];
+        float r2 = (l0 ? g.ln_g[0] : dz)[l0 ? n : 0], r3 = (l0 ? g.ln_b[0] : dz)[l0 ? n : 0];
+        float r4 = (l1 ? g.ln_g[1] : dz)[l1 ? n : 0], r5 = (l1 ? g.ln_b[1] : dz)[l1 ? n : 0];
+        asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5));
+        Ct[tid] = g.bias ? r0 : 0.f;
+        Ct[256 + tid] = g.cscale ? r1 : 1.f;
+        Ct[512 + tid] = l0 ? r2 : 0.f;
+        Ct[768 + tid] = l0 ? r3 : 0.f;
+        Ct[1024 + tid] = l1 ? r4 : 0.f;
+        Ct[1280 + tid] = l1 ? r5 : 0.f;
     }
     const bool has_res = g.resid != nullptr;
     const int c4 = lane * 4;                           // row phase: lane l owns columns 4l .. 4l+3
@@ -306,22 +314,19 @@ __global__ __launch_bounds__(256, 2) void gemm_row_kernel(RowArgs g) {
                 for (int k = 0; k < 4; ++k) v[j][k] *= __half2float(hp[k]) > 0.f ? 1.f : 0.f;
             }
         } else if (ERF && (act == 6 || act == 7)) {
-            // one erff live at a time: a non-unrolled loop over the 16 values that rotates them through v[0][0] (four interleaved
-            // copies of erff's polynomial cost ~60 registers on top of the 128 weight registers).  act 7: u = the saved
-            // pre-activation, d/du [u * Phi(u)] = Phi(u) + u * phi(u)
-            const bool d7 = act == 7;
-#pragma unroll 1
-            for (int n = 0; n < RB * 4; ++n) {
-                const float x = d7 ? sd[0][0] : v[0][0];
-                const float ph = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-                const float r = d7 ? v[0][0] * (ph + x * 0.3989422804014327f * __expf(-0.5f * x * x)) : x * ph;
+            // exact GELU / its derivative by the 12-instruction form of common.h (the library erff needed a non-unrolled loop
+            // rotating one value at a time through it to fit beside the 128 weight registers, and made this epilogue VALU-bound).
+            // act 7: u = the saved pre-activation, d/du [u * Phi(u)] = Phi(u) + u * phi(u)
+            if (act == 7) {
 #pragma unroll
                 for (int j = 0; j < RB; ++j)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (j == RB - 1 && k == 3) { v[RB - 1][3] = r; sd[RB - 1][3] = x; }
-                        else { v[j][k] = v[k == 3 ? j + 1 : j][k == 3 ? 0 : k + 1]; sd[j][k] = sd[k == 3 ? j + 1 : j][k == 3 ? 0 : k + 1]; }
-                    }
+                    for (int k = 0; k < 4; ++k) v[j][k] *= wc_gelu_grad(sd[j][k]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < RB; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[j][k] = wc_gelu(v[j][k]);
             }
         }
         if (has_res) {
