@@ -36,18 +36,31 @@ struct KmArgs {
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
 
-// NST = stages of the ring: 4 (64 KiB: two workgroups per CU, 2 x 48 KiB in flight) or 8 (128 KiB: for grids of at most one
-// workgroup per CU, which with four stages had 48 KiB in flight per CU and ran at one memory latency per three stages).
-template <int NST>
-__global__ __launch_bounds__(256, NST == 4 ? 2 : 1) void gemm_km_kernel(KmArgs g) {
-    // ring of NST stages x [32 tokens]: [A tile 8 KiB | X tile 8 KiB]; NST - 1 stages in flight while one is consumed,
+// NST = stages of the ring: 5 (80 KiB: two workgroups fill the CU's 160 KiB, 2 x 64 KiB in flight) or 8 (128 KiB: for grids of at
+// most one workgroup per CU).  What a stage costs (round 4, 86 016 x 256 x 256, debug switches that drop the DMA or the
+// arithmetic): an EMPTY iteration 0.27 us (counted wait + barrier), fragment reads + MFMA issue 0.52 us, DMA issue 0.12 us -- and
+// they ADD UP inside a wave (one wave per SIMD: nothing to overlap with), 1.1 us per 32 tokens although the matrix pipe needs
+// 0.2 us.  Two workgroups per CU interleave their chains (0.85 us per stage and CU) but are then bound by the bytes in flight:
+// the DMA alone needed 33.6 us with 2 x 3 stages in flight against 25.5 us with 7 -- hence five stages per workgroup, not four.
+//
+// HV = 2 (grids of at most one workgroup per CU): the workgroup has EIGHT waves = two halves of four; a stage is 64 tokens, the
+// halves take its first / second 32 tokens into accumulators of their own (a split over tokens inside the workgroup), all eight
+// waves stage it, and the second half's accumulators are added to the first's through LDS at the end (fixed order).  Two waves
+// per SIMD interleave their chains like two workgroups would, the ring is 4 x 32 KiB with 96 KiB in flight, and the launch
+// writes HALF the partial tiles of the two-workgroups-per-CU form (17 MB instead of 34 MB per 256 x 257 gradient, read once
+// more by the slice reduction).
+template <int NST, int HV>
+__global__ __launch_bounds__(256 * HV, (HV == 1 && NST <= 5) ? 2 : 1) void gemm_km_kernel(KmArgs g) {
+    // ring of NST stages x [ST tokens]: [A tile | X tile] of ST x 256 B each; NST - 1 stages in flight while one is consumed,
     // counted vmcnt waits + raw s_barrier (a __syncthreads() drains every outstanding LDS-DMA: with 2 stages of 64
     // tokens the loop ran at one global-memory latency per stage)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TILE = 32 * 256;
-    constexpr int ST = 32;                // tokens per stage
+    constexpr int ST = 32 * HV;           // tokens per stage
+    constexpr int TILE = ST * 256;
+    constexpr int NT_ = 256 * HV;         // threads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int half = HV == 2 ? wave >> 2 : 0, w4 = wave & 3;
+    const int wr = w4 >> 1, wc = w4 & 1;
     // XCD-aware order: workgroup ids go round-robin over the 8 XCDs, so unit u (= one token slice of one group, whose
     // `tiles` workgroups all read the same dY / X rows) takes the ids congruent to u mod 8 of its block of 8 units:
     // the slice's operands (~2-3 MB) are fetched into ONE 4-MiB L2 instead of all eight (33 -> 36 us at N 256, K 1024,
@@ -74,10 +87,11 @@ __global__ __launch_bounds__(256, NST == 4 ? 2 : 1) void gemm_km_kernel(KmArgs g
 
     // DMA bookkeeping: chunk q = i*256 + tid -> tile row q>>4 (token), physical chunk q&15
     int rowi[2], acol[2], xcol[2], xg[2], xr[2];
+    unsigned offA[2], offX[2];
     bool aok[2], xok[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int q = i * 256 + tid;
+        const int q = i * NT_ + tid;
         const int row = q >> 4, pc = q & 15;
         const int lc = pc ^ (((row & 3) << 2) | ((row >> 2) & 3));
         rowi[i] = row;
@@ -88,21 +102,40 @@ __global__ __launch_bounds__(256, NST == 4 ? 2 : 1) void gemm_km_kernel(KmArgs g
         const int m = mbeg + row;
         xg[i] = m / g.x_rpg;
         xr[i] = m - xg[i] * g.x_rpg;
+        // fast path: 32-bit BYTE offsets from the (uniform) operand bases, advanced by constants per stage -- the 64-bit
+        // row * pitch products per DMA instruction were ~80 of the ~110 VALU instructions of an iteration (PMC: a quarter
+        // of a wave's cycles).  A column chunk outside the operand reads column 0 instead: it only feeds outputs that are not
+        // stored.  (The launcher keeps operands of 4 GiB and more off this kernel.)
+        offA[i] = (unsigned)(((long)m * g.lda + (aok[i] ? acol[i] : 0)) * 2);
+        offX[i] = (unsigned)((((long)xg[i] * g.x_gs + xr[i] + g.x_off) * g.ldx + (xok[i] ? xcol[i] : 0)) * 2);
     }
+    const unsigned dA = (unsigned)(ST * g.lda * 2), dX = (unsigned)(ST * g.ldx * 2);
+    const unsigned dXg = (unsigned)(((long)g.x_gs - g.x_rpg) * g.ldx * 2);      // extra step when a token group is crossed
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* gbl_ptr;
 #define KM_LOAD(t_, buf_)                                                                                       \
     {                                                                                                            \
         char* dst_ = smem + (buf_) * (2 * TILE) + wave * 1024;                                                   \
+        if (mbeg + ((t_) + 1) * ST <= mend) {      /* (uniform) every token row of the stage exists */           \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+                __builtin_amdgcn_global_load_lds((gbl_ptr)(reinterpret_cast<const char*>(Ag) + offA[i]), (lds_ptr)(dst_ + i * (4096 * HV)), 16, 0, 0); \
+                __builtin_amdgcn_global_load_lds((gbl_ptr)(reinterpret_cast<const char*>(Xg) + offX[i]), (lds_ptr)(dst_ + TILE + i * (4096 * HV)), 16, 0, 0); \
+            }                                                                                                    \
+        } else {                                   /* ragged last stage: rows past the slice read zeros */       \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+                const int m_ = mbeg + (t_) * ST + rowi[i];                                                       \
+                const bool in_ = m_ < mend;                                                                      \
+                const __half* pa_ = (in_ && aok[i]) ? Ag + (long)m_ * g.lda + acol[i] : g.zeros;                 \
+                const __half* px_ = (in_ && xok[i]) ? Xg + ((long)xg[i] * g.x_gs + xr[i] + g.x_off) * g.ldx + xcol[i] : g.zeros; \
+                __builtin_amdgcn_global_load_lds((gbl_ptr)pa_, (lds_ptr)(dst_ + i * (4096 * HV)), 16, 0, 0);            \
+                __builtin_amdgcn_global_load_lds((gbl_ptr)px_, (lds_ptr)(dst_ + TILE + i * (4096 * HV)), 16, 0, 0);     \
+            }                                                                                                    \
+        }                                                                                                        \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
-            const int m_ = mbeg + (t_) * ST + rowi[i];                                                           \
-            const bool in_ = m_ < mend;                                                                          \
-            const __half* pa_ = (in_ && aok[i]) ? Ag + (long)m_ * g.lda + acol[i] : g.zeros;                     \
-            const __half* px_ = (in_ && xok[i]) ? Xg + ((long)xg[i] * g.x_gs + xr[i] + g.x_off) * g.ldx + xcol[i] : g.zeros; \
-            __builtin_amdgcn_global_load_lds((gbl_ptr)pa_, (lds_ptr)(dst_ + i * 4096), 16, 0, 0);                \
-            __builtin_amdgcn_global_load_lds((gbl_ptr)px_, (lds_ptr)(dst_ + TILE + i * 4096), 16, 0, 0);         \
+            offA[i] += dA;                                                                                       \
+            offX[i] += dX;                                                                                       \
             xr[i] += ST;                                                                                         \
-            while (xr[i] >= g.x_rpg) { xr[i] -= g.x_rpg; xg[i] += 1; }                                           \
+            while (xr[i] >= g.x_rpg) { xr[i] -= g.x_rpg; xg[i] += 1; offX[i] += dXg; }                           \
         }                                                                                                        \
     }
     // transposing fragment reads: lane = 16*grp + 4*q + p; grp = 2*hh + gi
@@ -110,7 +143,7 @@ __global__ __launch_bounds__(256, NST == 4 ? 2 : 1) void gemm_km_kernel(KmArgs g
     int aaddr[2][2], baddr[2][2];      // [mi / ni][r]: byte offset inside an operand tile for k-step 0
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int row = 8 * hh + 4 * r + q;                       // + 16 * ks
+        const int row = 8 * hh + 4 * r + q + 32 * half;           // + 16 * ks
         const int f = (q << 2) | ((2 * hh + r) & 3);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -146,8 +179,8 @@ __global__ __launch_bounds__(256, NST == 4 ? 2 : 1) void gemm_km_kernel(KmArgs g
 #pragma unroll
     for (int s0 = 0; s0 < NST - 1; ++s0)
         if (s0 < nt) KM_LOAD(s0, s0);
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & (NST - 1);
+    int buf = 0, lbuf = NST - 1;           // ring slots of stage t and of stage t + NST - 1
+    for (int t = 0; t < nt; ++t, buf = buf + 1 == NST ? 0 : buf + 1, lbuf = lbuf + 1 == NST ? 0 : lbuf + 1) {
         // stage t has landed once at most the requests of stages t+1 .. t+NST-2 (4 DMA instructions each) are outstanding
         const int ahead = nt - 1 - t < NST - 2 ? nt - 1 - t : NST - 2;
         switch (ahead) {
@@ -160,7 +193,7 @@ __global__ __launch_bounds__(256, NST == 4 ? 2 : 1) void gemm_km_kernel(KmArgs g
             default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         }
         __builtin_amdgcn_s_barrier();     // every wave's part of stage t is in LDS; stage t-1's buffer is free
-        if (t + NST - 1 < nt) KM_LOAD(t + NST - 1, (t + NST - 1) & (NST - 1));
+        if (t + NST - 1 < nt) KM_LOAD(t + NST - 1, lbuf);
         // Fragment reads as inline asm: hipcc puts a full `s_waitcnt vmcnt(0)` in front of the ds_read_tr builtin
         // whenever LDS-DMA is outstanding (it cannot tell which LDS bytes the DMA writes), which would drain the ring.
         // Both k-steps' 16 transposing reads are issued, then one lgkmcnt(0) that carries the registers.
@@ -200,6 +233,33 @@ __global__ __launch_bounds__(256, NST == 4 ? 2 : 1) void gemm_km_kernel(KmArgs g
 #undef KM_TR
 #undef KM_JOIN
 #undef KM_LOAD
+    if constexpr (HV == 2) {
+        // second half -> first half, register by register through 96 KiB of the (idle) ring behind the 32 KiB the storing
+        // waves use as epilogue scratch; a fixed order (first + second), so the result does not depend on timing
+        float* ex = reinterpret_cast<float*>(smem + 32768) + w4 * (6 * 16 * 64) + lane;
+        if (half == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ex[((i * 2 + j) * 16 + r) * 64] = acc[i][j][r];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ex[((4 + i) * 16 + r) * 64] = bacc[i][r];
+            }
+        }
+        __syncthreads();
+        if (half == 1) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += ex[((i * 2 + j) * 16 + r) * 64];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bacc[i][r] += ex[((4 + i) * 16 + r) * 64];
+        }
+    }
     if (edge_bias) {     // every column of bacc holds the row sums: one lane per row group stores them into output column K
         if ((lane & 31) == 0) {
             float* pb = g.e.C32 + (long)z * g.e.sC + (long)grp * g.gP + g.K;
@@ -224,7 +284,7 @@ __global__ __launch_bounds__(256, NST == 4 ? 2 : 1) void gemm_km_kernel(KmArgs g
         }
     }
     const float bv[2] = {0.f, 0.f}, sc[2] = {1.f, 1.f};
-    gemm_epilogue<false>(g.e, acc, n0, k0, wr, wc, lane, z, smem + wave * 8192, bv, sc, (long)z * g.e.sC + (long)grp * g.gP);
+    gemm_epilogue<false>(g.e, acc, n0, k0, wr, wc, lane, z, smem + w4 * 8192, bv, sc, (long)z * g.e.sC + (long)grp * g.gP);
 }
 
 // part: (nslices, N, K + bias) fp32 with nslices = ceil(M / mslice); zeros: device buffer of >= 16 zero bytes.
@@ -248,6 +308,10 @@ extern "C" int wc_gemm_km_f16_grouped(const void* dY, long lda, const void* X, l
                  "wc_gemm_km_f16: operand rows must be 16-byte aligned (lda, ldx %% 8 == 0)");
     WC_CHECK_ARG(mslice > 0 && mslice % 64 == 0, "wc_gemm_km_f16: mslice must be a positive multiple of 64");
     WC_CHECK_ARG(x_rpg >= 1 && x_gs >= 0 && x_off >= 0, "wc_gemm_km_f16: bad row map");
+    {   // the kernel addresses both operands with 32-bit byte offsets from their (group) bases
+        const long xrows = (long)((M - 1) / x_rpg) * x_gs + (x_rpg - 1 < M - 1 ? x_rpg - 1 : M - 1) + x_off + 1;
+        WC_CHECK_ARG((long)M * lda * 2 < (1L << 32) && xrows * ldx * 2 < (1L << 32), "wc_gemm_km_f16: operands of 4 GiB and more are not supported");
+    }
     const int ns = wc_cdiv(M, mslice);
     WC_CHECK_ARG(ns <= 65535, "wc_gemm_km_f16: too many slices");
     KmArgs g;
@@ -278,13 +342,14 @@ extern "C" int wc_gemm_km_f16_grouped(const void* dY, long lda, const void* X, l
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             n_cu <= 0)
             n_cu = 256;
-        WC_CHECK_ARG(hipFuncSetAttribute((const void*)gemm_km_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 256) == hipSuccess,
+        WC_CHECK_ARG(hipFuncSetAttribute((const void*)gemm_km_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 256) == hipSuccess &&
+                         hipFuncSetAttribute((const void*)gemm_km_kernel<5, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 64 * 256) == hipSuccess,
                      "wc_gemm_km_f16: cannot reserve 128 KiB of LDS");
     }
-    if ((long)g.tiles * g.units <= n_cu)      // at most one workgroup per CU: the deep ring
-        hipLaunchKernelGGL(gemm_km_kernel<8>, grid, dim3(256), 8 * 64 * 256, (hipStream_t)stream, g);
+    if ((long)g.tiles * g.units <= n_cu && mslice >= 128)      // at most one workgroup per CU: eight waves, 64-token stages
+        hipLaunchKernelGGL((gemm_km_kernel<4, 2>), grid, dim3(512), 4 * 128 * 256, (hipStream_t)stream, g);
     else
-        hipLaunchKernelGGL(gemm_km_kernel<4>, grid, dim3(256), 4 * 64 * 256, (hipStream_t)stream, g);
+        hipLaunchKernelGGL((gemm_km_kernel<5, 1>), grid, dim3(256), 5 * 64 * 256, (hipStream_t)stream, g);
     shape_log_end(sl, "km", M, N, K1, 1, groups, ns, 0, stream);
     wc_prof_end(pr, "gemm_km_kernel", 2.0 * M * N * K1 * groups, stream);
     WC_LAUNCH_CHECK("gemm_km_kernel");
