@@ -375,6 +375,13 @@ int wc_layernorm_bwd(const float* dy, const float* x, const float* w, const floa
 int wc_layernorm_bwd_h(const void* dy16, const float* x, const float* w, const float* add, float eps,
                        float* dx32, void* dx16, float out_scale, float* part, float* dgb, float alpha,
                        long rows, int D, void* stream);
+/* two LayerNorms of ONE input x (the ViT-CoMer CTI normalises c1 once for the values of one deformable attention and once
+ * for the queries of the other: this package's own WeCLIP_model/comer.py CTI.forward; no reference code) back-propagated in one
+ * pass: dx = LN_bwd_a(dya16) + LN_bwd_b(dyb16) [+ add]; dgba / dgbb (2, D) = alpha * [dgamma; dbeta] of each; D <= 256;
+ * part: >= min(ceil(rows / 16), 2048) * 4 * D floats */
+int wc_layernorm_bwd2_h(const void* dya16, const float* wa, const void* dyb16, const float* wb, const float* x,
+                        const float* add, float eps, float* dx32, void* dx16, float out_scale, float* part, float* dgba,
+                        float* dgbb, float alpha, long rows, int D, void* stream);
 int wc_sigmoid_gram_bwd(const float* dAP, const float* AP, void* hi, void* lo, int B, int n, int ldo,
                         float scale, void* stream);
 int wc_colscale_split(const float* x, const float* cs, float* out32, void* hi, void* lo, long rows, int C,

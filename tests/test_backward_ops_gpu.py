@@ -63,6 +63,34 @@ def test_layernorm_backward(ops, D):
     assert _rel(dgb[0].cpu(), 2 * wr.grad) < 1e-5 and _rel(dgb[1].cpu(), 2 * br.grad) < 1e-5
 
 
+@pytest.mark.parametrize("D,rows", [(64, 333), (256, 1000), (256, 40000)])
+def test_two_layernorms_of_one_input_backward_in_one_pass(ops, D, rows):
+    """wc_layernorm_bwd2_h: y_a = LN(x; w_a), y_b = LN(x; w_b) (the CTI's two norms of c1) -> dx = dLN_a + dLN_b + add and the
+    four parameter gradients, against fp64 autograd on the fp16-rounded gradients; and bit-for-bit the four column sums of the
+    one-norm kernel (same summation order per norm)."""
+    g = torch.Generator().manual_seed(D + rows)
+    x = (torch.randn(rows, D, generator=g) * 2 + 0.5)
+    wa, wb = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    dya, dyb = torch.randn(rows, D, generator=g).half(), torch.randn(rows, D, generator=g).half()
+    add = torch.randn(rows, D, generator=g)
+    dx32, dx16, ga, gb = ops.layernorm_bwd2(dya.cuda(), wa.cuda(), dyb.cuda(), wb.cuda(), x.cuda(), add=add.cuda(), want16=True,
+                                            out_scale=0.5, alpha=2.0)
+    xr = x.double().requires_grad_(True)
+    war, wbr = wa.double().requires_grad_(True), wb.double().requires_grad_(True)
+    bar, bbr = [torch.zeros(D, dtype=torch.float64, requires_grad=True) for _ in range(2)]
+    ya = torch.nn.functional.layer_norm(xr, (D,), war, bar, 1e-5)
+    yb = torch.nn.functional.layer_norm(xr, (D,), wbr, bbr, 1e-5)
+    ((ya * dya.double()).sum() + (yb * dyb.double()).sum()).backward()
+    assert _rel(dx32.cpu(), xr.grad + add.double()) < 1e-5
+    assert _rel(dx16.float().cpu(), 0.5 * (xr.grad + add.double())) < 2e-3
+    tol = 1e-5 if rows < 10000 else 1e-4          # fp32 column sums over 40 000 rows
+    assert _rel(ga[0].cpu(), 2 * war.grad) < tol and _rel(ga[1].cpu(), 2 * bar.grad) < tol
+    assert _rel(gb[0].cpu(), 2 * wbr.grad) < tol and _rel(gb[1].cpu(), 2 * bbr.grad) < tol
+    _, _, ga1 = ops.layernorm_bwd(dya.cuda(), x.cuda(), wa.cuda(), alpha=2.0)
+    _, _, gb1 = ops.layernorm_bwd(dyb.cuda(), x.cuda(), wb.cuda(), alpha=2.0)
+    assert torch.equal(ga, ga1) and torch.equal(gb, gb1)
+
+
 def test_transpose_colsum_and_wgrad(ops):
     """dW = dY^T X through transposes + the TN GEMM, db = colsum(dY)."""
     g = torch.Generator().manual_seed(0)

@@ -331,6 +331,21 @@ class ComerEngine:
             self._pending = None
         return out
 
+    def _ln_dest(self, ln):
+        """(2, D) destination of a LayerNorm's [dgamma; dbeta]: the adjacent views of the gradient bucket, or None."""
+        gw, gb = self._direct(ln.weight), self._direct(ln.bias)
+        if gw is not None and gb is not None and gb.data_ptr() == gw.data_ptr() + 4 * gw.numel():
+            return torch.as_strided(gw, (2, gw.numel()), (gw.numel(), 1))
+        return None
+
+    def _ln_bwd2(self, dya, lna, dyb, lnb, x, add, grads):
+        """Both LayerNorms of one input in one pass (csrc/train_ops.hip ln_bwd_kernel<.., true>): -> (dx f32, dx f16)."""
+        dx, dx16, ga, gb = ops.layernorm_bwd2(dya, self._b(lna.weight), dyb, self._b(lnb.weight), x, add=add, want32=True,
+                                              want16=True, alpha=INV, eps=lna.eps, dgba=self._ln_dest(lna), dgbb=self._ln_dest(lnb))
+        grads[id(lna.weight)], grads[id(lna.bias)] = ga[0], ga[1]
+        grads[id(lnb.weight)], grads[id(lnb.bias)] = gb[0], gb[1]
+        return dx, dx16
+
     def _ln_bwd(self, dy, x, ln, add, grads, want16=False):
         """dx = LN_bwd(dy) + add (f32) [and its f16 copy: the next GEMMs' operand, no separate conversion pass]."""
         gw, gb = self._direct(ln.weight), self._direct(ln.bias)
@@ -389,7 +404,7 @@ class ComerEngine:
             dq2 = torch.empty(Mc, C, device=dev, dtype=F16)
             self._mm(dow2, WT(f"c{i}.ow"), Mc, C, s["ld2"], out16=dq2)
             self._ow_grads(dow2, s["q2"], Mc, s["n2"], s["ld2"], t.to_c, grads)
-            dc1 = self._ln_bwd(dq2, s["c1"], t.nc_q, dc2, grads)
+            # (LN_nc_q(c1) and LN_nv_f(c1) normalise the same rows: their backward runs as ONE pass below, once df1 exists)
             df2 = torch.empty(Mv, C, device=dev, dtype=F16)
             self._mm(dval2_16, WT(f"c{i}.vp"), Mv, C, C, out16=df2)
             self._wgrad(dval2_16, s["f2"], Mv, C, C, grads, t.to_c.value_proj.weight, t.to_c.value_proj.bias)
@@ -418,7 +433,11 @@ class ComerEngine:
             df1 = torch.empty(Mc, C, device=dev, dtype=F16)
             self._mm(dval1_16, WT(f"v{i}.vp"), Mc, C, C, out16=df1)
             self._wgrad(dval1_16, s["f1"], Mc, C, C, grads, t.to_v.value_proj.weight, t.to_v.value_proj.bias)
-            dc1, dc1_16 = self._ln_bwd(df1, s["c1"], t.nv_f, dc1, grads, want16=True)
+            if t.nc_q.eps == t.nv_f.eps and C <= 256:
+                dc1, dc1_16 = self._ln_bwd2(dq2, t.nc_q, df1, t.nv_f, s["c1"], dc2, grads)
+            else:
+                dc1 = self._ln_bwd(dq2, s["c1"], t.nc_q, dc2, grads)
+                dc1, dc1_16 = self._ln_bwd(df1, s["c1"], t.nv_f, dc1, grads, want16=True)
             # ---- MRFP
             dx2 = torch.empty(Mc, hid, device=dev, dtype=F16)          # fp16 out: the epilogue's wide (row-major) path
             self._mm(dc1_16, WT(f"m{i}.fc2"), Mc, hid, C, out16=dx2, act=7, aux=s["x2"], ldaux=hid, rpg=1)

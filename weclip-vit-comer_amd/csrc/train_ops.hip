@@ -43,8 +43,9 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     for (long r = r0; r < r1; ++r) s += (float)src[r * ld + c];
     part[(long)blockIdx.y * C + c] = s;
 }
+// out2 (optional): columns [C / 2, C) go to out2[0 .. C / 2) instead of out (two destinations of one partial matrix)
 __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                             int nblk, int C, float alpha, int round16) {
+                                                             int nblk, int C, float alpha, int round16, float* __restrict__ out2 = nullptr) {
     // 64 columns per block, the partial rows dealt over 16 waves (256-B coalesced reads, 4 loads in flight each): the grid
     // is only C/64 blocks, so the block is as wide as it gets (4 waves: 22 us for 1024 partial rows of 512 columns)
     __shared__ float red[16][64];
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += red[k][cl];
         s *= alpha;
-        out[c] = round16 ? __half2float(__float2half(s)) : s;
+        float* o = (out2 && c >= C / 2) ? out2 + (c - C / 2) : out + c;
+        *o = round16 ? __half2float(__float2half(s)) : s;
     }
 }
 
@@ -77,17 +79,25 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
 // dgamma = sum dy*xhat and dbeta = sum dy in part (nblk, 2, D).  One wave per row, LNB_ROWS rows per wave
 // (few rows per wave = many waves: the three dependent wave reductions per row are latency, hidden by occupancy).
 #define LNB_ROWS 4
-template <int NV>   // D <= 64*NV
+// TWO: two LayerNorms of the SAME input x (different affine parameters: in CTI, LN(c1) feeds the values of one attention and the
+// queries of the other) back-propagated in one pass: with g = dy_a * gamma_a + dy_b * gamma_b the input gradient is the ordinary
+// formula in g (both share xhat), the four parameter gradients are separate column sums (part: (nblk, 4, D)).  One read of x,
+// one write of dx instead of two passes with the first one's result re-read as `add` by the second.
+template <int NV, bool TWO = false>   // D <= 64*NV
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const __half* __restrict__ dy16,
                                                       const float* __restrict__ x,
                                                       const float* __restrict__ w, const float* __restrict__ add,
                                                       float eps, float* __restrict__ dx32, __half* __restrict__ dx16,
-                                                      float out_scale, float* __restrict__ part, long rows, int D, long ngroups) {
-    extern __shared__ float sm[];   // [4][2][D]
+                                                      float out_scale, float* __restrict__ part, long rows, int D, long ngroups,
+                                                      const __half* __restrict__ dy16b = nullptr, const float* __restrict__ wb = nullptr) {
+    extern __shared__ float sm[];   // [4][2 or 4][D]
+    constexpr int NP = TWO ? 4 : 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float ag[NV], ab[NV];
+    float ag[NV], ab[NV], ag2[TWO ? NV : 1], ab2[TWO ? NV : 1];
 #pragma unroll
     for (int i = 0; i < NV; ++i) ag[i] = ab[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (TWO ? NV : 1); ++i) ag2[i] = ab2[i] = 0.f;
     // slot i of a lane = element ((i >> 2) * 64 + lane) * 4 + (i & 3): four consecutive elements per lane, 16-byte IO
     // (D % 4 == 0, so a group of four slots is inside the row or outside it as a whole)
 #define LN_E(i_) ((((i_) >> 2) * 64 + lane) * 4 + ((i_) & 3))
@@ -101,6 +111,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         const int e = LN_E(i);
         const float4 wa = *reinterpret_cast<const float4*>(w + (e < D ? e : 0));
         wv_[i] = e < D ? wa.x : 0.f; wv_[i + 1] = e < D ? wa.y : 0.f; wv_[i + 2] = e < D ? wa.z : 0.f; wv_[i + 3] = e < D ? wa.w : 0.f;
+    }
+    float wvb_[TWO ? NV : 1];
+    if constexpr (TWO) {
+#pragma unroll
+        for (int i = 0; i < NV; i += 4) {
+            const int e = LN_E(i);
+            const float4 wa = *reinterpret_cast<const float4*>(wb + (e < D ? e : 0));
+            wvb_[i] = e < D ? wa.x : 0.f; wvb_[i + 1] = e < D ? wa.y : 0.f; wvb_[i + 2] = e < D ? wa.z : 0.f; wvb_[i + 3] = e < D ? wa.w : 0.f;
+        }
     }
     for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     // the LNB_ROWS rows of a wave are processed TOGETHER: all their loads in flight at once and their four reduction
@@ -150,6 +169,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 dv[r][i] = da.x; dv[r][i + 1] = da.y; dv[r][i + 2] = da.z; dv[r][i + 3] = da.w;
             }
     }
+    float dvb[TWO ? LNB_ROWS : 1][TWO ? NV : 1];
+    if constexpr (TWO) {
+#pragma unroll
+        for (int r = 0; r < LNB_ROWS; ++r)
+#pragma unroll
+            for (int i = 0; i < NV; i += 4) {
+                const int e = LN_E(i), ec = e < D ? e : 0;
+                const uint2 hq = *reinterpret_cast<const uint2*>(dy16b + rowc[r] * D + ec);
+                const __half* hp = reinterpret_cast<const __half*>(&hq);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dvb[r][i + k] = (e < D && live[r]) ? __half2float(hp[k]) : 0.f;
+            }
+    }
 #pragma unroll
     for (int r = 0; r < LNB_ROWS; ++r) {
         s[r] = 0.f;
@@ -186,11 +218,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         for (int i = 0; i < NV; ++i) {
             if (LN_E(i) < D) {
                 const float xh = (xv[r][i] - mean[r]) * rstd[r];
-                const float g = dv[r][i] * wv_[i];
-                a += g;
-                bsum += g * xh;
+                float g = dv[r][i] * wv_[i];
                 ag[i] += dv[r][i] * xh;           // a dead row has dv = 0
                 ab[i] += dv[r][i];
+                if constexpr (TWO) {
+                    g = fmaf(dvb[r][i], wvb_[i], g);
+                    ag2[i] += dvb[r][i] * xh;
+                    ab2[i] += dvb[r][i];
+                    dv[r][i] = g;                 // (from here on dv holds g = sum of dy * gamma)
+                }
+                a += g;
+                bsum += g * xh;
             }
         }
         sg[r] = a;
@@ -216,7 +254,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float xh = (xv[r][i + k] - mean[r]) * rstd[r];
-                dv[r][i + k] = rstd[r] * (dv[r][i + k] * wv_[i + k] - sg[r] - xh * sgx[r]) + a4[k];
+                dv[r][i + k] = rstd[r] * ((TWO ? dv[r][i + k] : dv[r][i + k] * wv_[i + k]) - sg[r] - xh * sgx[r]) + a4[k];
             }
         }
 #pragma unroll
@@ -242,16 +280,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int i = 0; i < NV; ++i) {
         const int e = LN_E(i);
         if (e < D) {
-            sm[(wv * 2 + 0) * D + e] = ag[i];
-            sm[(wv * 2 + 1) * D + e] = ab[i];
+            sm[(wv * NP + 0) * D + e] = ag[i];
+            sm[(wv * NP + 1) * D + e] = ab[i];
+            if constexpr (TWO) {
+                sm[(wv * NP + 2) * D + e] = ag2[i];
+                sm[(wv * NP + 3) * D + e] = ab2[i];
+            }
         }
     }
 #undef LN_E
     __syncthreads();
-    for (int e = threadIdx.x; e < 2 * D; e += 256) {
+    for (int e = threadIdx.x; e < NP * D; e += 256) {
         const int which = e / D, k = e - which * D;
-        part[((long)blockIdx.x * 2 + which) * D + k] = sm[(0 * 2 + which) * D + k] + sm[(1 * 2 + which) * D + k] +
-                                                        sm[(2 * 2 + which) * D + k] + sm[(3 * 2 + which) * D + k];
+        part[((long)blockIdx.x * NP + which) * D + k] = sm[(0 * NP + which) * D + k] + sm[(1 * NP + which) * D + k] +
+                                                         sm[(2 * NP + which) * D + k] + sm[(3 * NP + which) * D + k];
     }
 }
 
@@ -445,6 +487,28 @@ extern "C" int wc_layernorm_bwd_h(const void* dy16, const float* x, const float*
                                   long rows, int D, void* stream) {
     WC_CHECK_ARG(dy16 && (uintptr_t)dy16 % 8 == 0, "wc_layernorm_bwd_h: bad argument (dy16)");
     return layernorm_bwd_impl(nullptr, dy16, x, w, add, eps, dx32, dx16, out_scale, part, dgb, alpha, rows, D, stream);
+}
+
+// two LayerNorms of one input (fp16 gradients dya16 / dyb16, gammas wa / wb): dx = LN_bwd_a(dya) + LN_bwd_b(dyb) [+ add];
+// part: >= min(ceil(rows / 16), 2048) * 4 * D floats; dgba / dgbb: (2, D) each = alpha * [dgamma; dbeta].  D <= 256.
+extern "C" int wc_layernorm_bwd2_h(const void* dya16, const float* wa, const void* dyb16, const float* wb, const float* x,
+                                   const float* add, float eps, float* dx32, void* dx16, float out_scale, float* part, float* dgba,
+                                   float* dgbb, float alpha, long rows, int D, void* stream) {
+    WC_CHECK_ARG(dya16 && dyb16 && wa && wb && x && part && dgba && dgbb && rows > 0 && D > 0 && D <= 256 && D % 4 == 0 && (dx32 || dx16),
+                 "wc_layernorm_bwd2_h: bad argument (D <= 256, D %% 4 == 0)");
+    WC_CHECK_ARG(((uintptr_t)x | (uintptr_t)wa | (uintptr_t)wb | (uintptr_t)add | (uintptr_t)dx32) % 16 == 0 &&
+                     ((uintptr_t)dx16 | (uintptr_t)dya16 | (uintptr_t)dyb16) % 8 == 0,
+                 "wc_layernorm_bwd2_h: operands must be 16-byte (fp16: 8-byte) aligned");
+    const long ngroups = (rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS);
+    const int nblk = ngroups < 2048 ? (int)ngroups : 2048;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((ln_bwd_kernel<4, true>), dim3(nblk), dim3(256), 16 * (size_t)D * sizeof(float), st, (const float*)nullptr,
+                       (const __half*)dya16, x, wa, add, eps, dx32, (__half*)dx16, out_scale, part, rows, D, ngroups,
+                       (const __half*)dyb16, wb);
+    WC_LAUNCH_CHECK("ln_bwd_kernel<two>");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(wc_cdiv(4 * D, 64)), dim3(1024), 0, st, part, dgba, nblk, 4 * D, alpha, 0, dgbb);
+    WC_LAUNCH_CHECK("colsum_final_kernel");
+    return WC_OK;
 }
 
 static int layernorm_bwd_impl(const float* dy, const void* dy16, const float* x, const float* w, const float* add, float eps,

@@ -273,6 +273,22 @@ def layernorm_bwd(dy, x, w, *, add=None, want32=True, want16=False, out_scale=1.
     return dx32, dx16, dgb
 
 
+def layernorm_bwd2(dya, wa, dyb, wb, x, *, add=None, want32=True, want16=False, out_scale=1.0, alpha=1.0, eps=1e-5, dgba=None, dgbb=None):
+    """Two LayerNorms of one input x (gammas wa / wb, fp16 gradients dya / dyb) back-propagated in one pass:
+    -> (dx32 or None, dx16 or None, dgba, dgbb), dgb* (2, D) = alpha * [dgamma; dbeta] of each norm."""
+    rows, D = x.shape
+    dev = x.device
+    dx32 = torch.empty(rows, D, device=dev, dtype=F32) if want32 else None
+    dx16 = torch.empty(rows, D, device=dev, dtype=F16) if want16 else None
+    part = torch.empty(min((rows + 15) // 16, 2048) * 4 * D, device=dev, dtype=F32)
+    dgba = torch.empty(2, D, device=dev, dtype=F32) if dgba is None else dgba
+    dgbb = torch.empty(2, D, device=dev, dtype=F32) if dgbb is None else dgbb
+    L.lib().wc_layernorm_bwd2_h(L.ptr(dya, F16, "dya"), L.ptr(wa, F32, "wa"), L.ptr(dyb, F16, "dyb"), L.ptr(wb, F32, "wb"),
+                                L.ptr(x, F32, "x"), L.ptr(add, F32, "add"), eps, L.ptr(dx32), L.ptr(dx16), float(out_scale),
+                                L.ptr(part), L.ptr(dgba), L.ptr(dgbb), float(alpha), rows, D, L.stream())
+    return dx32, dx16, dgba, dgbb
+
+
 def sigmoid_gram_bwd(dAP, AP, scale=1.0, with_lo=True):
     """-> Split (B, n, np): rows zero padded to np = ceil64(n) so n can be a GEMM K dimension."""
     B, n, _ = AP.shape
