@@ -41,7 +41,9 @@ def source_hash():
     """Content hash of every kernel source + header + the compile flags: identifies the build a profile was taken from
     (bench.py accepts a committed PMC traffic file only when its recorded hash equals this one)."""
     h = hashlib.sha1()
-    h.update(" ".join(FLAGS).encode())
+    # (the include path is absolute and differs between checkouts -- /root/repo here, a scratch directory on a GPU box --: the
+    #  hash must not, or a traffic file collected on one box never matches on the next)
+    h.update(" ".join("<csrc>" if f == CSRC else f for f in FLAGS).encode())
     for f in sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))):
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode())

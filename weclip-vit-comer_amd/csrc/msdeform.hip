@@ -756,8 +756,12 @@ static int msda_bwd_value(const float* loc, const float* attn, const GT* gout, f
                      "wc_msda_bwd: cannot reserve 128 KiB of LDS");
         attr_set = true;
     }
+    const int prk = wc_prof_begin(st);
     hipLaunchKernelGGL(msda_bucket_kernel, dim3(n_levels, M, N), dim3(MSDA_VT), (size_t)maxhw * 2 * sizeof(int), st, loc, attn, (int*)ws,
                        sh, S, Lq, M, P, N);
+    // two reads of the locations, one of the weights, one 8-byte entry per (sample, corner) written
+    wc_prof_end2(prk, n_levels == 1 ? "msda_bucket_kernel<1>" : "msda_bucket_kernel<n>", 0.0,
+                 (double)N * Lq * M * n_levels * P * (2 * 8 + 4 + 4 * 8), st);
     WC_LAUNCH_CHECK("msda_bucket_kernel");
     const int prg = wc_prof_begin(st);
     // lanes per pixel, per level: the smallest power-of-two multiple of CL that covers the level's mean bucket length
