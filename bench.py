@@ -244,7 +244,7 @@ def run_leg(args, dev, rank, world, *, comer=False, seg_trans=False, steps=None,
     return res, step, loader
 
 
-def roofline_leg(args, step, loader, dev, use_traffic=True):
+def roofline_leg(args, step, loader, dev, use_traffic=True, traffic_files="r*_traffic.json"):
     """Eager instrumented steps of the same TrainStep: HIP-event pairs at the C library's launch sites."""
     import torch
     from weclip_vit_comer_amd import ops
@@ -284,13 +284,23 @@ def roofline_leg(args, step, loader, dev, use_traffic=True):
     import __graft_entry__
     cur = __graft_entry__._load_build_module().source_hash()
     traffic, tsrc = {}, "none: no profiles/r*_traffic.json carries the source hash of this build (%s)" % cur
-    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+    tpaths = [t for t in glob.glob(os.path.join(ROOT, "profiles", traffic_files))
+              if ("_comer_" in os.path.basename(t)) == ("_comer_" in traffic_files)]
+    for tpath in sorted(tpaths, reverse=True):
         if not (B == 16 and S == 512 and K == 2) or not use_traffic:
-            tsrc = "none: PMC passes exist for B=16, 512x512, K=2 without the inserts only"
+            tsrc = "none: PMC passes exist for B=16, 512x512, K=2 only"
             break
         data = json.load(open(tpath))
         if data.get("__meta__", {}).get("source_hash") == cur:
             traffic = {k: round(v["hbm_bytes_per_launch"]) for k, v in data.items() if k != "__meta__"}
+            # the library times the deformable-attention kernels per direction (<1> / <3> levels) and the weight-gradient GEMM
+            # under one name; rocprofv3 reports template arguments: map the ones that correspond one to one (the gather / bucket
+            # kernels are one instantiation for both directions: no per-direction counter value, left null)
+            for lib, prof in (("msda_fwd4f_kernel<1>", "msda_fwd4f_kernel<__half, 1, 4>"), ("msda_fwd4f_kernel<3>", "msda_fwd4f_kernel<__half, 3, 4>"),
+                              ("msda_bwd4f_kernel<1>", "msda_bwd4f_kernel<__half, __half, 1, 4>"),
+                              ("msda_bwd4f_kernel<3>", "msda_bwd4f_kernel<__half, __half, 3, 4>")):
+                if prof in traffic:
+                    traffic[lib] = traffic[prof]
             tsrc = ("profiles/" + os.path.basename(tpath) + " (committed rocprofv3 --pmc passes of this command on the same "
                     "kernel sources, hash %s; a separate run, as the guide prescribes)" % cur)
             break
@@ -410,7 +420,7 @@ def main():
     B, S, K = args.batch, args.size, args.classes_per_image
     roofs, roof_meta = ([], {})
     if args.timer_stride > 0 and args.roof_steps > 0 and world == 1:
-        roofs, roof_meta = roofline_leg(args, step, loader, dev)
+        roofs, roof_meta = roofline_leg(args, step, loader, dev, traffic_files="r*_comer_traffic.json" if args.comer else "r*_traffic.json")
     del step, loader
     torch.cuda.empty_cache()
     out = {
@@ -480,7 +490,8 @@ def main():
                 # row-streaming GEMM of the 86 016 x 256 x 256 Linear layers report ALGORITHMIC bytes (nL * nP * 4 corner rows of dh
                 # values per (query, head); A + side input + outputs once) -> achieved GB/s of the 8 TB/s HBM peak; the GEMM also
                 # its TFLOP/s.  Same HIP-event pairs at the library's launch sites as the main roofline.
-                croofs, cmeta = roofline_leg(args, cstep, cloader, dev, use_traffic=False)
+                croofs, cmeta = roofline_leg(args, cstep, cloader, dev, traffic_files="r*_comer_traffic.json")
+                r["traffic_source"] = cmeta["traffic_source"]
                 keep = ("msda_", "gemm_row_kernel", "mrfp_", "ln_bwd", "gemm_km")
                 r["roofline"] = [x for x in croofs if x["kernel"].startswith(keep)]
                 r["eager_instrumented_ms_per_step"] = cmeta["eager_instrumented_ms_per_step"]

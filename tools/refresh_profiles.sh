@@ -17,6 +17,12 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/p
 cd $R
 python3 tools/prof_summary.py gpurun_out/prof_stats/p_results.db 14 100 > gpurun_out/${TAG}_kernel_stats.csv
 python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/${TAG}
+# the same two PMC passes with the ViT-CoMer inserts (BASELINE configs[2] as written) -> ${TAG}_comer_traffic.json
+cd /tmp
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_c -- python3 $R/bench.py --comer --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-extras --timer-stride 0 --roof-steps 0 --single-stream > $R/gpurun_out/pmc_fetch_c.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write_c -- python3 $R/bench.py --comer --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-extras --timer-stride 0 --roof-steps 0 --single-stream > $R/gpurun_out/pmc_write_c.log 2>&1
+cd $R
+python3 tools/pmc_traffic.py gpurun_out/pmc_fetch_c gpurun_out/pmc_write_c gpurun_out/${TAG}_comer
 find gpurun_out -name "*.db" -delete                     # gpurun copies back at most 64 MiB
 find gpurun_out -name "*.csv" -size +1M -delete
 echo done
