@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void msda_absmax_kernel(const GT* __restrict__
 // {row of grad_out = query * M + head, bit pattern of bilinear weight * attention weight}.  (Round 4: the entries were pair ids,
 // and the gather re-derived row and weight from loc / attn with two dependent random loads per pair.)
 #define MSDA_VT 1024
-#define MSDA_UN 4              // samples per thread whose loads are in flight together
+#define MSDA_UN 8              // samples per thread whose loads are in flight together
 __global__ __launch_bounds__(MSDA_VT) void msda_bucket_kernel(const float* __restrict__ loc, const float* __restrict__ attn,
                                                            int* __restrict__ ws, MsdaShapes sh, int S, int Lq, int M, int P, int N) {
     extern __shared__ int sm[];

@@ -35,6 +35,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             bb[i] = br[jc];
         }
     }
+    if constexpr (HOIST) {
+        // (pinned behind a scheduling barrier: without them hipcc sinks the gamma / beta loads behind the two reductions, where
+        //  their L2 latency sits between the statistics and the stores of every row)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+            asm volatile("" : "+v"(ww[i].x), "+v"(ww[i].y), "+v"(ww[i].z), "+v"(ww[i].w), "+v"(bb[i].x), "+v"(bb[i].y), "+v"(bb[i].z),
+                         "+v"(bb[i].w));
+    }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         if (lane + 64 * i >= nv) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
