@@ -18,9 +18,10 @@ SRC = os.path.join(ROOT, "weclip-vit-comer_amd", "csrc")
 
 def disassemble(path, out_dir="/tmp/isa"):
     os.makedirs(out_dir, exist_ok=True)
+    path = os.path.abspath(path)
     out = os.path.join(out_dir, os.path.basename(path) + ".s")
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-S", "--cuda-device-only", path, "-o", out], check=True,
-                   stderr=subprocess.DEVNULL, cwd=os.path.dirname(path))
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
+                    "-I", os.path.dirname(path), path, "-o", out], check=True, stderr=subprocess.DEVNULL)
     return out
 
 
@@ -53,14 +54,20 @@ def scan(lines):
     return loads, alone, "".join(seq)
 
 
-def main():
-    files = sys.argv[1:] or sorted(glob.glob(os.path.join(SRC, "*.hip")))
+def report(files, threshold=3):
+    """[(loads waited for alone, loads, file, mangled kernel name, sequence)] of the kernels at or above the threshold."""
     rows = []
     for f in files:
         for name, lines in kernels(disassemble(f)):
             loads, alone, seq = scan(lines)
-            if alone >= 3:
+            if alone >= threshold:
                 rows.append((alone, loads, os.path.basename(f), name, seq))
+    return rows
+
+
+def main():
+    files = sys.argv[1:] or sorted(glob.glob(os.path.join(SRC, "*.hip")))
+    rows = report(files)
     for alone, loads, f, name, seq in sorted(rows, reverse=True):
         print(f"{alone:4d} of {loads:4d} loads waited for alone  {f:18s} {name[:90]}")
         print("      " + seq[:200])

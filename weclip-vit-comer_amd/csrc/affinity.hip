@@ -235,12 +235,17 @@ __global__ __launch_bounds__(256) void aff_weight_colpart_kernel(MapPtrs maps, i
             }
         }
         float cs = 0.f;
+        float sg[AF_RPBW];              // attn_pred factors of the rows (seg-trans mode), requested together
+        if (seg) {
+#pragma unroll
+            for (int r = 0; r < AF_RPBW; ++r) sg[r] = seg[((long)b * hw + min(i0 + r, i1 - 1)) * hw + j];
+        }
 #pragma unroll
         for (int r = 0; r < AF_RPBW; ++r) {
             if (i0 + r >= i1) break;
             const long dst = ((long)b * hw + i0 + r) * hw + j;
             float v = sacc[r];
-            if (seg) v *= seg[dst];
+            if (seg) v *= sg[r];
             W[dst] = v;
             cs += v;
         }
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(256) void aff_sweep_kernel(const float* __restrict_
                 const int jc = okc[ch] ? j + q : 0;          // (unconditional loads, masked: see the row loads below)
                 float v = cb[jc];
                 if (MODE == 2) v *= X[((long)b * hw + jc) * K + k];
-                cx[ch][q][k] = okc[ch] ? v : 0.f;
+                cx[ch][q][k] = v * (okc[ch] ? 1.f : 0.f);
             }
     }
     int buf = 0;
@@ -293,7 +298,8 @@ __global__ __launch_bounds__(256) void aff_sweep_kernel(const float* __restrict_
                 //  load before it issues the next one)
                 const bool ok = okc[ch] && ig + r < i1;
                 const float4 t = *reinterpret_cast<const float4*>(Wb + (long)min(ig + r, i1 - 1) * hw + (okc[ch] ? ch * 1024 + tid * 4 : 0));
-                w[r][ch] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float mk = ok ? 1.f : 0.f;            // (a multiplication: a select is turned back into a branch around the load)
+                w[r][ch] = make_float4(t.x * mk, t.y * mk, t.z * mk, t.w * mk);
             }
         float rix[AF_RG], xix[AF_RG][K];          // MODE 2: r_i and X[i, k] of the group's rows, requested with the rows of W
         if (MODE == 2) {

@@ -186,11 +186,9 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_y_kernel(const float* __rest
             if (y0 != cy0 || y1 != cy1) {          // wave-uniform
                 cy0 = y0; cy1 = y1;
 #pragma unroll
-                for (int c = 0; c < NCT; ++c) {
-                    if (c < nc) {
-                        const float* Sc = S + (long)c * h * w;
-                        s00[c] = Sc[o00]; s01[c] = Sc[o01]; s10[c] = Sc[o10]; s11[c] = Sc[o11];
-                    }
+                for (int c = 0; c < NCT; ++c) {          // (classes past nc re-read class nc - 1: no branch around the loads)
+                    const float* Sc = S + (long)min(c, nc - 1) * h * w;
+                    s00[c] = Sc[o00]; s01[c] = Sc[o01]; s10[c] = Sc[o10]; s11[c] = Sc[o11];
                 }
             }
         }
@@ -207,28 +205,56 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_y_kernel(const float* __rest
 #pragma unroll
             for (int c = 0; c < NCT; ++c) sum += c < nc ? __expf(zc[c] - mx) : 0.f;
         } else {
+            // (the logits of eight classes are requested together from clamped class indices; a class past nc enters the online
+            //  log-sum-exp as -inf: exp(-inf - max) = 0, the maximum is unchanged -- behind `if (c < nc)` every class's four
+            //  loads were waited for before the next class's were issued: 81 dependent latencies per pixel row at COCO's nc)
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-                if (c < nc) {
-                    const float* Sc = S + (long)c * h * w;
-                    const float z = w00 * Sc[o00] + w01 * Sc[o01] + w10 * Sc[o10] + w11 * Sc[o11];
-                    const float nm = fmaxf(mx, z);
-                    sum = sum * __expf(mx - nm) + __expf(z - nm);
-                    mx = nm;
+            for (int c0 = 0; c0 < NCT; c0 += 8) {
+                float zz[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + u;
+                    const float* Sc = S + (long)min(c, nc - 1) * h * w;
+                    zz[u] = w00 * Sc[o00] + w01 * Sc[o01] + w10 * Sc[o10] + w11 * Sc[o11];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (c0 + u < nc) {
+                        const float nm = fmaxf(mx, zz[u]);
+                        sum = sum * __expf(mx - nm) + __expf(zz[u] - nm);
+                        mx = nm;
+                    }
                 }
             }
         }
         const bool valid = lab != ignore && lab >= 0 && lab < nc;
         const float wp = valid ? (lab == 0 ? wbg : wfg) : 0.f;
         const float lse = mx + __logf(sum);
+        if constexpr (CACHE) {
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-            if (c < nc) {
-                float z;
-                if constexpr (CACHE) z = zc[c];
-                else { const float* Sc = S + (long)c * h * w; z = w00 * Sc[o00] + w01 * Sc[o01] + w10 * Sc[o10] + w11 * Sc[o11]; }
-                const float gval = wp * (__expf(z - lse) - (c == lab ? 1.f : 0.f));
-                acc[c] = fmaf(wy, gval, acc[c]);
+            for (int c = 0; c < NCT; ++c) {
+                if (c < nc) {
+                    const float gval = wp * (__expf(zc[c] - lse) - (c == lab ? 1.f : 0.f));
+                    acc[c] = fmaf(wy, gval, acc[c]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c0 = 0; c0 < NCT; c0 += 8) {
+                float zz[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float* Sc = S + (long)min(c0 + u, nc - 1) * h * w;
+                    zz[u] = w00 * Sc[o00] + w01 * Sc[o01] + w10 * Sc[o10] + w11 * Sc[o11];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + u;
+                    if (c < nc) {
+                        const float gval = wp * (__expf(zz[u] - lse) - (c == lab ? 1.f : 0.f));
+                        acc[c] = fmaf(wy, gval, acc[c]);
+                    }
+                }
             }
         }
     }

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 const uint2 hq = *reinterpret_cast<const uint2*>(dy16b + rowc[r] * D + ec);
                 const __half* hp = reinterpret_cast<const __half*>(&hq);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) dvb[r][i + k] = (e < D && live[r]) ? __half2float(hp[k]) : 0.f;
+                for (int k = 0; k < 4; ++k) dvb[r][i + k] = __half2float(hp[k]);      // (masked below, with dv: no select around the load)
             }
     }
 #pragma unroll
@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             for (int k = 0; k < 4; ++k) {
                 xv[r][i + k] = in ? xv[r][i + k] : 0.f;
                 dv[r][i + k] = (in && live[r]) ? dv[r][i + k] : 0.f;
+                if constexpr (TWO) dvb[r][i + k] = (in && live[r]) ? dvb[r][i + k] : 0.f;
             }
             s[r] += (xv[r][i] + xv[r][i + 1]) + (xv[r][i + 2] + xv[r][i + 3]);
         }
@@ -314,23 +315,28 @@ __global__ __launch_bounds__(256) void sigmoid_gram_bwd_kernel(const float* __re
     const bool vec = (n & 3) == 0 && (ldo & 3) == 0 && (((uintptr_t)dAP | (uintptr_t)AP) & 15) == 0 && ((uintptr_t)hi & 7) == 0 &&
                      (!lo || ((uintptr_t)lo & 7) == 0);
     if (vec) {            // 16-byte loads, 8-byte stores: four columns per thread
-        for (int e = threadIdx.x; e < 64 * 16; e += 256) {
-            const int r = e >> 4, c = (e & 15) * 4;
-            float v[4] = {0.f, 0.f, 0.f, 0.f}, vt[4] = {0.f, 0.f, 0.f, 0.f};
-            if (i0 + r < n && j0 + c < n) {
-                const long o = base + (long)(i0 + r) * n + j0 + c;
-                const float4 a = *reinterpret_cast<const float4*>(AP + o), d = *reinterpret_cast<const float4*>(dAP + o);
-                v[0] = d.x * a.x * (1.f - a.x); v[1] = d.y * a.y * (1.f - a.y);
-                v[2] = d.z * a.z * (1.f - a.z); v[3] = d.w * a.w * (1.f - a.w);
-            }
-            if (ti != tj && j0 + r < n && i0 + c < n) {
-                const long o = base + (long)(j0 + r) * n + i0 + c;
-                const float4 a = *reinterpret_cast<const float4*>(AP + o), d = *reinterpret_cast<const float4*>(dAP + o);
-                vt[0] = d.x * a.x * (1.f - a.x); vt[1] = d.y * a.y * (1.f - a.y);
-                vt[2] = d.z * a.z * (1.f - a.z); vt[3] = d.w * a.w * (1.f - a.w);
-            }
+        // the sixteen 16-byte loads of a thread (4 passes x {AP, dAP} x {tile, transposed tile}) are issued together from clamped
+        // addresses and masked afterwards: behind their bounds branches each pair was waited for before the next was requested
+        float4 a4[4], d4[4], at4[4], dt4[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { za[r][c + k] = v[k]; zb[r][c + k] = vt[k]; }
+        for (int q = 0; q < 4; ++q) {
+            const int e = q * 256 + threadIdx.x, r = e >> 4, c = (e & 15) * 4;
+            const long o = base + (long)min(i0 + r, n - 1) * n + min(j0 + c, n - 4);
+            const long ot = base + (long)min(j0 + r, n - 1) * n + min(i0 + c, n - 4);
+            a4[q] = *reinterpret_cast<const float4*>(AP + o);
+            d4[q] = *reinterpret_cast<const float4*>(dAP + o);
+            at4[q] = *reinterpret_cast<const float4*>(AP + ot);
+            dt4[q] = *reinterpret_cast<const float4*>(dAP + ot);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = q * 256 + threadIdx.x, r = e >> 4, c = (e & 15) * 4;
+            const float m = (i0 + r < n && j0 + c < n) ? 1.f : 0.f, mt = (ti != tj && j0 + r < n && i0 + c < n) ? 1.f : 0.f;
+            const float4 a = a4[q], d = d4[q], at = at4[q], dt = dt4[q];
+            za[r][c] = m * (d.x * a.x * (1.f - a.x)); za[r][c + 1] = m * (d.y * a.y * (1.f - a.y));
+            za[r][c + 2] = m * (d.z * a.z * (1.f - a.z)); za[r][c + 3] = m * (d.w * a.w * (1.f - a.w));
+            zb[r][c] = mt * (dt.x * at.x * (1.f - at.x)); zb[r][c + 1] = mt * (dt.y * at.y * (1.f - at.y));
+            zb[r][c + 2] = mt * (dt.z * at.z * (1.f - at.z)); zb[r][c + 3] = mt * (dt.w * at.w * (1.f - at.w));
         }
         __syncthreads();
         for (int e = threadIdx.x; e < 64 * 16; e += 256) {
