@@ -30,7 +30,8 @@ def _sources():
 
 def _stamp(src):
     h = hashlib.sha1()
-    h.update(" ".join(FLAGS).encode())
+    # (include path normalised as in source_hash: objects built in one checkout stay valid when the tree is copied elsewhere)
+    h.update(" ".join("<csrc>" if f == CSRC else f for f in FLAGS).encode())
     for f in [src] + sorted(f for f in os.listdir(CSRC) if f.endswith(".h")):
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
